@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X.
+
+Metric : Msamples/s of Complex<f32> through the 255-tap FIR -> mixer -> decimate
+         chain (BASELINE.json `metric`), whole job over all ranks.
+Step   : one pass of the chain over one resident batch of 2^24 synthetic IQ
+         samples per GPU (BASELINE config 2), node by node through the C ABI
+         (comms_fir_run_dev -> comms_mixer_run_dev -> comms_decimate_run_dev),
+         device-resident in and out, FIR/mixer state carried across steps.
+N > 1  : the long stream is cut into N contiguous shards, one rank per GPU; the
+         only cross-rank step is the one-off 254-sample halo hand-over to the
+         right-hand neighbour over RCCL (setup, untimed).  The data path has no
+         collective -> weak scaling (per-GPU work fixed).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_SAMPLES = 1 << 24          # per GPU per step (BASELINE config 2)
+N_TAPS = 255
+DEC_RATE = 8
+MIX_DPHASE = 2.0 * np.pi * 0.1
+SEED = 0xC0FFEE
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FIR_BYTES_PER_SAMPLE = 16.0  # 8 B read + 8 B write per sample
+
+
+def pmc_traffic():
+    """HBM bytes per FIR launch from the committed rocprofv3 PMC passes (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("kernel") == "fir_os4096_kernel" and d.get("n_samples") == N_SAMPLES:
+            return d.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def cpu_baseline(n):
+    """The oracle's restatement of the reference chain (literal batch_fir with
+    rotate_right per sample, Mixer::mix in f64, decimate), one thread = what one
+    reference node thread does.  Reported baseline, not the target."""
+    import oracle
+
+    x = np.empty(n, np.complex64)
+    from comms_rs_amd import synth_iq
+
+    x[:] = synth_iq(n, 0, SEED)
+    taps = oracle.rrc_taps(N_TAPS, 8.0, 0.35)
+    best = None
+    for _ in range(2):
+        st = oracle.default_state(taps)
+        mx = oracle.Mixer(0.0, MIX_DPHASE)
+        t0 = time.perf_counter()
+        y = oracle.decimate(mx.mix(oracle.batch_fir(x, taps, st)), DEC_RATE)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    assert y.size == n // DEC_RATE
+    return {"value": round(n / best / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "full config-2 batch (%d samples) through oracle batch_fir(255 taps, rotate_right per "
+                      "sample) -> Mixer::mix (f64) -> decimate(8), best of 2, g++ -O3 -ffp-contract=off, "
+                      "1 thread of %d host cores" % (n, os.cpu_count() or 0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--algo", choices=["auto", "direct", "os"], default="auto")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import comms_rs_amd as c
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    dev = torch.device("cuda", local_rank)
+    assert c.device_count() > local_rank, "no MI355X visible (no CPU fallback)"
+
+    n = N_SAMPLES
+    taps = c.rrc_taps(N_TAPS, 8.0, 0.35)
+    # rank r owns stream samples [r*n, (r+1)*n): generated in place on its GPU
+    x = torch.empty(n, dtype=torch.complex64, device=dev)
+    y = torch.empty(n, dtype=torch.complex64, device=dev)
+    z = torch.empty(n // DEC_RATE, dtype=torch.complex64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    c.synth_iq_dev(x.data_ptr(), n, rank * n, SEED, device=local_rank, stream=stream)
+
+    fir = c.BatchFirNode(taps, device=local_rank)
+    if args.algo != "auto":
+        fir.set_algo(c.FIR_DIRECT if args.algo == "direct" else c.FIR_OVERLAP_SAVE)
+    mixer = c.MixerNode(MIX_DPHASE, device=local_rank)
+    dec = c.DecimateNode(DEC_RATE, device=local_rank)
+
+    # ---- one-off halo hand-over to the right-hand neighbour (RCCL send/recv)
+    if world > 1:
+        tail = x[n - N_TAPS:].clone()
+        halo = torch.zeros(N_TAPS, dtype=torch.complex64, device=dev)
+        ops = []
+        if rank + 1 < world:
+            ops.append(dist.P2POp(dist.isend, torch.view_as_real(tail), rank + 1))
+        if rank > 0:
+            ops.append(dist.P2POp(dist.irecv, torch.view_as_real(halo), rank - 1))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        torch.cuda.synchronize()
+        if rank > 0:
+            h = halo.cpu().numpy()
+            assert np.array_equal(h, c.synth_iq(N_TAPS, rank * n - N_TAPS, SEED)), "halo mismatch"
+            fir.set_state(h[::-1].copy())  # reference layout: newest first
+
+    def step():
+        fir.run_dev(x.data_ptr(), n, y.data_ptr(), stream)
+        mixer.run_dev(y.data_ptr(), n, y.data_ptr(), stream)
+        dec.run_dev(y.data_ptr(), n, 8, z.data_ptr(), stream)
+
+    # ---- self-check of the first step against the oracle on a bounded window (fail loudly)
+    step()
+    torch.cuda.synchronize()
+    import oracle
+
+    lo = max(0, rank * n - (N_TAPS - 1))
+    xs = c.synth_iq(rank * n + 8192 - lo, lo, SEED)
+    ref = oracle.batch_fir(xs, taps, oracle.default_state(taps), norotate=True)[rank * n - lo:]
+    ref = oracle.decimate(oracle.Mixer(0.0, MIX_DPHASE).mix(ref), DEC_RATE)
+    got = z[:ref.size].cpu().numpy()
+    err = float(np.max(np.abs(got.astype(np.complex128) - ref.astype(np.complex128))))
+    assert err <= 1e-5 * float(np.sum(np.abs(taps))), "parity check failed: %g" % err
+
+    for _ in range(args.warmup):
+        step()
+    timer = c.KernelTimer(max(args.steps, 1), device=local_rank).attach(fir)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kms = timer.read_ms()
+    timer.close()
+    kernel_ms = float(np.mean(kms)) if kms.size else float("nan")
+    algo = {c.FIR_DIRECT: "fir_direct_kernel", c.FIR_OVERLAP_SAVE: "fir_os4096_kernel"}[fir.algo_for(n)]
+
+    if rank == 0:
+        total = float(world) * n * args.steps
+        achieved = FIR_BYTES_PER_SAMPLE * n / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Msamples/s Complex<f32> through 255-tap FIR->mix->decimate chain",
+            "value": round(total / elapsed / 1e6, 1),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: 255-tap BatchFirNode (rrc_taps(255,8,0.35)) -> mixer "
+                                   "(dphase 2pi*0.1) -> decimate-by-8 on 2^24 Complex<f32> IQ per GPU, "
+                                   "node by node, device-resident",
+                       "samples_per_gpu_per_step": n, "n_taps": N_TAPS, "dec_rate": DEC_RATE,
+                       "fir_kernel": algo, "sharding": "contiguous stream shards, one-off RCCL halo"},
+            "roofline": {"bound": "hbm", "kernel": algo, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic(),
+                         "kernel_ms": round(kernel_ms, 5), "launches_timed": int(kms.size),
+                         "algorithmic_bytes_per_launch": FIR_BYTES_PER_SAMPLE * n},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

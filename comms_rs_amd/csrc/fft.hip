@@ -1,0 +1,616 @@
+// fft.hip -- FFT / IFFT node: unnormalised DFT of Complex<f32> blocks on gfx950.
+//
+// Replaces FFTBatchNode::new(fft_size, ifft) + BatchFFT::run_fft (reference
+// src/fft/fft_node.rs:65-74, src/fft/mod.rs:73-96; arithmetic by rustfft 2.1.0
+// in f64).  Here the transform runs in f32 with twiddles generated in f64 on
+// the host and rounded once.
+//
+// One tile kernel does all power-of-two work.  A workgroup owns a tile of C
+// sub-transforms of length L (C*L <= 16384 points = 128 KiB of LDS), runs
+// radix-4 Stockham passes (radix-2 last when log2 L is odd) in place in LDS
+// -- every lane pulls its 16 points into VGPRs, barrier, butterflies,
+// writes back -- and moves the tile to/from HBM with the contiguous index on
+// the lanes:
+//   * N <= 4096 ............ rows mode: C whole transforms per workgroup;
+//   * N  > 4096 (four-step, N = N1*N2):
+//       pass 1: 16 adjacent columns (128-B row pieces) x N1, FFT over n1,
+//               multiply by W_N^{n2*k1}, store in place;
+//       pass 2: 16 rows x N2, FFT over n2, store transposed (128-B pieces) so
+//               the result is in natural order.
+// Other lengths: exact-index O(N^2) DFT with f64 accumulation (N <= 4096) or
+// Bluestein's chirp-z on the power-of-two path (N > 4096).
+#include <cmath>
+#include <vector>
+
+#include "common.hpp"
+#include "fft_radix.hpp"
+
+namespace comms {
+
+constexpr int FT_MAX_POINTS = 16384;  // per tile
+constexpr int FT_PTS = 16;            // points per lane per pass
+
+struct FftTileParams {
+    int L, logL, C, logC;
+    int in_c_fast, out_c_fast;       // which tile index runs along the lanes for global I/O
+    size_t in_cs, in_ls;             // element (c,l): in_off(tile) + c*in_cs + l*in_ls
+    size_t out_cs, out_ks;           // element (c,k): out_off(tile) + c*out_cs + k*out_ks
+    size_t tiles_per_xform;          // tiles inside one length-N transform
+    size_t tile_step_in, tile_step_out;
+    size_t N;                        // distance between transforms of the batch
+    size_t n_tiles;                  // total (batch * tiles_per_xform)
+    const float2* twL;               // W_L^m, m < L (forward sign)
+    int apply_tw;                    // four-step pass 1: times W_N^{(tile*C + c) * k}
+    const float2* tw_lo;             // W_N^e, e < 4096
+    const float2* tw_hi;             // W_N^{4096 e}
+};
+
+template <int DIR>
+__device__ __forceinline__ float2 tw_apply(float2 x, float2 w) {
+    return DIR < 0 ? cmulf(x, w) : cmulcf(x, w);
+}
+
+template <int DIR>
+__global__ __launch_bounds__(1024) void fft_tile_kernel(const float2* in, float2* out,
+                                                        FftTileParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* tile = reinterpret_cast<float2*>(smem);  // [c][l], row stride L
+    const int T = blockDim.x;
+    const int tid = threadIdx.x;
+    const int L = p.L, C = p.C;
+    const int npts = L * C;
+
+    for (size_t tix = blockIdx.x; tix < p.n_tiles; tix += gridDim.x) {
+        const size_t b = tix / p.tiles_per_xform;
+        const size_t tl = tix - b * p.tiles_per_xform;
+        const float2* src = in + b * p.N + tl * p.tile_step_in;
+        float2* dst = out + b * p.N + tl * p.tile_step_out;
+
+        // ---- load tile
+        for (int i = tid; i < npts; i += T) {
+            int c, l;
+            if (p.in_c_fast) {
+                c = i & (C - 1);
+                l = i >> p.logC;
+            } else {
+                l = i & (L - 1);
+                c = i >> p.logL;
+            }
+            tile[c * L + l] = src[c * p.in_cs + l * p.in_ls];
+        }
+        __syncthreads();
+
+        // ---- Stockham passes, in place (read all -> barrier -> write all)
+        int Ns = 1;
+        int logNs = 0;
+        for (; (Ns << 2) <= L; Ns <<= 2, logNs += 2) {
+            float2 v[FT_PTS];
+            const int nb = npts >> 2;  // radix-4 butterflies in the tile
+            const int q = L >> 2;
+#pragma unroll
+            for (int u = 0; u < FT_PTS / 4; ++u) {
+                const int w = tid + u * T;
+                if (w < nb) {
+                    const int c = w / q, j = w - c * q;
+                    const float2* row = tile + c * L;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[4 * u + r] = row[j + r * q];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < FT_PTS / 4; ++u) {
+                const int w = tid + u * T;
+                if (w < nb) {
+                    const int c = w / q, j = w - c * q;
+                    const int k = j & (Ns - 1);
+                    const int estep = k * (L >> (logNs + 2));  // k * L/(4 Ns)
+                    if (k) {
+                        v[4 * u + 1] = tw_apply<DIR>(v[4 * u + 1], p.twL[estep]);
+                        v[4 * u + 2] = tw_apply<DIR>(v[4 * u + 2], p.twL[2 * estep]);
+                        v[4 * u + 3] = tw_apply<DIR>(v[4 * u + 3], p.twL[3 * estep]);
+                    }
+                    radix4<DIR>(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
+                    const int j0 = ((j >> logNs) << (logNs + 2)) + k;
+                    float2* row = tile + c * L;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) row[j0 + r * Ns] = v[4 * u + r];
+                }
+            }
+            __syncthreads();
+        }
+        if (Ns < L) {  // one radix-2 pass left (Ns == L/2)
+            float2 v[FT_PTS];
+            const int nb = npts >> 1;
+            const int q = L >> 1;
+#pragma unroll
+            for (int u = 0; u < FT_PTS / 2; ++u) {
+                const int w = tid + u * T;
+                if (w < nb) {
+                    const int c = w / q, j = w - c * q;
+                    v[2 * u] = tile[c * L + j];
+                    v[2 * u + 1] = tile[c * L + j + q];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < FT_PTS / 2; ++u) {
+                const int w = tid + u * T;
+                if (w < nb) {
+                    const int c = w / q, j = w - c * q;
+                    // Ns == q here, so k == j and the twiddle is W_L^j
+                    float2 a = v[2 * u];
+                    float2 bb = j ? tw_apply<DIR>(v[2 * u + 1], p.twL[j]) : v[2 * u + 1];
+                    tile[c * L + j] = cadd(a, bb);
+                    tile[c * L + j + q] = csub(a, bb);
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- store tile (optionally times the four-step twiddle)
+        for (int i = tid; i < npts; i += T) {
+            int c, k;
+            if (p.out_c_fast) {
+                c = i & (C - 1);
+                k = i >> p.logC;
+            } else {
+                k = i & (L - 1);
+                c = i >> p.logL;
+            }
+            float2 x = tile[c * L + k];
+            if (p.apply_tw) {
+                const size_t e = (tl * static_cast<size_t>(C) + c) * static_cast<size_t>(k);  // < N
+                const float2 w = cmulf(p.tw_hi[e >> 12], p.tw_lo[e & 4095]);
+                x = tw_apply<DIR>(x, w);
+            }
+            dst[c * p.out_cs + k * p.out_ks] = x;
+        }
+        __syncthreads();
+    }
+}
+
+// Exact-index O(N^2) DFT, one transform per workgroup, f64 accumulation.
+__global__ __launch_bounds__(256) void dft_direct_kernel(const float2* __restrict__ in,
+                                                         float2* __restrict__ out, int N,
+                                                         size_t batch,
+                                                         const float2* __restrict__ twN,
+                                                         int inverse) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* x = reinterpret_cast<float2*>(smem);
+    float2* w = x + N;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        float2 t = twN[i];
+        w[i] = inverse ? make_float2(t.x, -t.y) : t;
+    }
+    for (size_t b = blockIdx.x; b < batch; b += gridDim.x) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < N; i += 256) x[i] = in[b * N + i];
+        __syncthreads();
+        for (int k = threadIdx.x; k < N; k += 256) {
+            double sr = 0.0, si = 0.0;
+            int e = 0;
+            for (int j = 0; j < N; ++j) {
+                const double xr = x[j].x, xi = x[j].y, wr = w[e].x, wi = w[e].y;
+                sr = fma(xr, wr, sr);
+                sr = fma(-xi, wi, sr);
+                si = fma(xr, wi, si);
+                si = fma(xi, wr, si);
+                e += k;
+                if (e >= N) e -= N;
+            }
+            out[b * N + k] = make_float2(static_cast<float>(sr), static_cast<float>(si));
+        }
+    }
+}
+
+// Bluestein helpers: a[n] = x[n] * chirp[n] zero-padded to M;  y[k] = c[k] * chirp[k]
+__global__ void blu_pre_kernel(const float2* __restrict__ in, const float2* __restrict__ chirp,
+                               float2* __restrict__ a, size_t N, size_t M, size_t batch) {
+    const size_t total = batch * M;
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t b = i / M, n = i - b * M;
+        a[i] = n < N ? cmulf(in[b * N + n], chirp[n]) : make_float2(0.f, 0.f);
+    }
+}
+__global__ void blu_mul_kernel(float2* __restrict__ a, const float2* __restrict__ bspec, size_t M,
+                               size_t batch) {
+    const size_t total = batch * M;
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride)
+        a[i] = cmulf(a[i], bspec[i % M]);
+}
+__global__ void blu_post_kernel(const float2* __restrict__ a, const float2* __restrict__ chirp,
+                                float2* __restrict__ out, size_t N, size_t M, size_t batch) {
+    const size_t total = batch * N;
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t b = i / N, k = i - b * N;
+        out[i] = cmulf(a[b * M + k], chirp[k]);
+    }
+}
+
+}  // namespace comms
+
+using namespace comms;
+
+static const double kPiF = 3.14159265358979323846264338327950288;
+
+static int ilog2(size_t v) {
+    int l = 0;
+    while ((static_cast<size_t>(1) << l) < v) ++l;
+    return l;
+}
+
+// Power-of-two plan: one tile pass (N <= 4096) or two (four-step).
+struct Pow2Plan {
+    size_t N = 0;
+    int n_pass = 0;
+    FftTileParams pass[2];
+    float2* d_tw[4] = {nullptr, nullptr, nullptr, nullptr};  // twL(pass0), twL(pass1), tw_lo, tw_hi
+    int threads[2] = {0, 0};
+    size_t lds[2] = {0, 0};
+
+    void release() {
+        for (auto& p : d_tw)
+            if (p) {
+                (void)hipFree(p);
+                p = nullptr;
+            }
+    }
+};
+
+static comms_status_t upload_tw(size_t count, size_t denom, size_t mult, float2** d_out) {
+    // table[m] = exp(-2 pi i * (m * mult) / denom), m < count   (forward sign)
+    std::vector<float2> t(count);
+    for (size_t m = 0; m < count; ++m) {
+        size_t e = (m * mult) % denom;
+        double a = -2.0 * kPiF * static_cast<double>(e) / static_cast<double>(denom);
+        t[m] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
+    }
+    COMMS_HIP_TRY(hipMalloc(d_out, count * sizeof(float2)));
+    COMMS_HIP_TRY(hipMemcpy(*d_out, t.data(), count * sizeof(float2), hipMemcpyHostToDevice));
+    return COMMS_OK;
+}
+
+static void tile_geometry(FftTileParams& p, int L, size_t want_c) {
+    p.L = L;
+    p.logL = ilog2(L);
+    size_t C = FT_MAX_POINTS / L;
+    if (C > want_c) C = want_c;
+    if (C < 1) C = 1;
+    p.C = static_cast<int>(C);
+    p.logC = ilog2(C);
+}
+
+static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
+    pl.N = N;
+    const int logN = ilog2(N);
+    COMMS_ARG(logN <= 24, "power-of-two FFT supports up to 2^24 points (got 2^%d)", logN);
+    if (N <= 4096) {
+        pl.n_pass = 1;
+        FftTileParams& p = pl.pass[0];
+        memset(&p, 0, sizeof(p));
+        tile_geometry(p, static_cast<int>(N), 16);
+        // rows mode: tile = C consecutive transforms; the "transform" seen by the
+        // kernel is the tile itself (distance C*N), one tile per transform
+        p.in_c_fast = 0;
+        p.out_c_fast = 0;
+        p.in_cs = N;
+        p.in_ls = 1;
+        p.out_cs = N;
+        p.out_ks = 1;
+        p.tiles_per_xform = 1;
+        p.tile_step_in = p.tile_step_out = 0;
+        p.N = static_cast<size_t>(p.C) * N;
+        COMMS_TRY(upload_tw(N, N, 1, &pl.d_tw[0]));
+        p.twL = pl.d_tw[0];
+    } else {
+        pl.n_pass = 2;
+        const int log1 = logN / 2, log2v = logN - log1;
+        const size_t N1 = static_cast<size_t>(1) << log1, N2 = static_cast<size_t>(1) << log2v;
+        // pass 1: columns n2, FFT over n1 (stride N2), twiddle, in place
+        FftTileParams& a = pl.pass[0];
+        memset(&a, 0, sizeof(a));
+        tile_geometry(a, static_cast<int>(N1), 16);
+        a.in_c_fast = 1;
+        a.out_c_fast = 1;
+        a.in_cs = 1;
+        a.in_ls = N2;
+        a.out_cs = 1;
+        a.out_ks = N2;
+        a.tiles_per_xform = N2 / a.C;
+        a.tile_step_in = a.tile_step_out = a.C;
+        a.N = N;
+        a.apply_tw = 1;
+        COMMS_TRY(upload_tw(N1, N1, 1, &pl.d_tw[0]));
+        COMMS_TRY(upload_tw(4096, N, 1, &pl.d_tw[2]));
+        COMMS_TRY(upload_tw(N / 4096, N, 4096, &pl.d_tw[3]));
+        a.twL = pl.d_tw[0];
+        a.tw_lo = pl.d_tw[2];
+        a.tw_hi = pl.d_tw[3];
+        // pass 2: rows k1, FFT over n2, transposed store -> X[k1 + N1*k2]
+        FftTileParams& b = pl.pass[1];
+        memset(&b, 0, sizeof(b));
+        tile_geometry(b, static_cast<int>(N2), 16);
+        b.in_c_fast = 0;
+        b.out_c_fast = 1;
+        b.in_cs = N2;
+        b.in_ls = 1;
+        b.out_cs = 1;
+        b.out_ks = N1;
+        b.tiles_per_xform = N1 / b.C;
+        b.tile_step_in = static_cast<size_t>(b.C) * N2;
+        b.tile_step_out = b.C;
+        b.N = N;
+        COMMS_TRY(upload_tw(N2, N2, 1, &pl.d_tw[1]));
+        b.twL = pl.d_tw[1];
+    }
+    for (int i = 0; i < pl.n_pass; ++i) {
+        const int npts = pl.pass[i].L * pl.pass[i].C;
+        int T = npts / FT_PTS;
+        if (T < 64) T = 64;
+        if (T > 1024) T = 1024;
+        pl.threads[i] = T;
+        pl.lds[i] = static_cast<size_t>(npts) * sizeof(float2);
+    }
+    // tiles above 64 KiB need the dynamic-LDS limit raised (160 KiB per CU on gfx950)
+    COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_tile_kernel<1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      FT_MAX_POINTS * sizeof(float2)));
+    COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_tile_kernel<-1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      FT_MAX_POINTS * sizeof(float2)));
+    return COMMS_OK;
+}
+
+// Runs `batch` transforms of length pl.N.  In-place (in == out) is fine: every
+// tile is fully read before it is written and tiles do not overlap; pass 2
+// reads what pass 1 wrote to `out`.
+static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size_t batch,
+                               bool inverse, hipStream_t s, float2* scratch) {
+    for (int i = 0; i < pl.n_pass; ++i) {
+        FftTileParams p = pl.pass[i];
+        const float2* src = in;
+        float2* dst = out;
+        if (pl.n_pass == 1) {
+            // group C transforms per tile; a ragged tail runs with C = 1 tiles
+            const size_t full = batch / p.C;
+            p.n_tiles = full;
+            if (full) {
+                unsigned blocks = static_cast<unsigned>(full < 4u * kNumCU ? full : 4u * kNumCU);
+                if (inverse)
+                    fft_tile_kernel<1><<<dim3(blocks), dim3(pl.threads[i]), pl.lds[i], s>>>(src, dst, p);
+                else
+                    fft_tile_kernel<-1><<<dim3(blocks), dim3(pl.threads[i]), pl.lds[i], s>>>(src, dst, p);
+                COMMS_TRY(launch_ok("fft_tile_kernel"));
+            }
+            const size_t rem = batch - full * p.C;
+            if (rem) {
+                FftTileParams q = p;
+                q.C = 1;
+                q.logC = 0;
+                q.N = pl.N;
+                q.n_tiles = rem;
+                const size_t off = full * p.C * pl.N;
+                int T = static_cast<int>(pl.N) / FT_PTS;
+                if (T < 64) T = 64;
+                unsigned blocks = static_cast<unsigned>(rem < 4u * kNumCU ? rem : 4u * kNumCU);
+                if (inverse)
+                    fft_tile_kernel<1><<<dim3(blocks), dim3(T), pl.N * sizeof(float2), s>>>(src + off, dst + off, q);
+                else
+                    fft_tile_kernel<-1><<<dim3(blocks), dim3(T), pl.N * sizeof(float2), s>>>(src + off, dst + off, q);
+                COMMS_TRY(launch_ok("fft_tile_kernel"));
+            }
+        } else {
+            // pass 1: in -> scratch (same positions, twiddled); pass 2: scratch -> out
+            // (transposed).  in == out is therefore fine.
+            if (i == 0) {
+                dst = scratch;
+            } else {
+                src = scratch;
+            }
+            p.n_tiles = batch * p.tiles_per_xform;
+            unsigned blocks = static_cast<unsigned>(p.n_tiles < 4u * kNumCU ? p.n_tiles : 4u * kNumCU);
+            if (inverse)
+                fft_tile_kernel<1><<<dim3(blocks), dim3(pl.threads[i]), pl.lds[i], s>>>(src, dst, p);
+            else
+                fft_tile_kernel<-1><<<dim3(blocks), dim3(pl.threads[i]), pl.lds[i], s>>>(src, dst, p);
+            COMMS_TRY(launch_ok("fft_tile_kernel"));
+        }
+    }
+    return COMMS_OK;
+}
+
+struct comms_fft : Handle {
+    size_t N = 0;
+    bool inverse = false;
+    int kind = 0;  // 0 pow2, 1 direct O(N^2), 2 Bluestein
+    Pow2Plan plan;           // pow2: length N;  Bluestein: length M
+    float2* d_twN = nullptr;     // direct: W_N^m
+    size_t M = 0;                // Bluestein padded length
+    float2* d_chirp = nullptr;   // exp(-/+ i pi n^2 / N)
+    float2* d_bspec = nullptr;   // FFT_M(conj chirp, wrapped) / M
+    Scratch work;                // four-step transpose buffer / Bluestein work
+    Scratch work2;
+};
+
+static void free_fft(comms_fft* h) {
+    (void)use_device(h->device);
+    h->plan.release();
+    if (h->d_twN) (void)hipFree(h->d_twN);
+    if (h->d_chirp) (void)hipFree(h->d_chirp);
+    if (h->d_bspec) (void)hipFree(h->d_bspec);
+    h->work.release();
+    h->work2.release();
+    h->fini();
+    delete h;
+}
+
+static comms_status_t fft_setup(comms_fft* h) {
+    const size_t N = h->N;
+    if ((N & (N - 1)) == 0) {
+        h->kind = 0;
+        if (N >= 2) COMMS_TRY(pow2_plan_build(h->plan, N));
+        return COMMS_OK;
+    }
+    if (N <= 4096) {
+        h->kind = 1;
+        return upload_tw(N, N, 1, &h->d_twN);
+    }
+    // Bluestein: with chirp[n] = W^{n^2/2} (W = e^{-/+ 2 pi i/N} by direction),
+    //   X[k] = chirp[k] * sum_n (x[n] chirp[n]) * conj(chirp)[k-n]
+    // i.e. one circular convolution of length M >= 2N-1 on the power-of-two path.
+    h->kind = 2;
+    COMMS_ARG(N <= (static_cast<size_t>(1) << 23), "FFT length %zu too large", N);
+    size_t M = 1;
+    while (M < 2 * N - 1) M <<= 1;
+    h->M = M;
+    COMMS_TRY(pow2_plan_build(h->plan, M));
+    const double sgn = h->inverse ? 1.0 : -1.0;
+    std::vector<float2> chirp(N);
+    std::vector<double> cr(N), ci(N);
+    for (size_t n = 0; n < N; ++n) {
+        const size_t e = (n * n) % (2 * N);  // n^2 mod 2N keeps the angle exact
+        const double a = sgn * kPiF * static_cast<double>(e) / static_cast<double>(N);
+        cr[n] = std::cos(a);
+        ci[n] = std::sin(a);
+        chirp[n] = make_float2(static_cast<float>(cr[n]), static_cast<float>(ci[n]));
+    }
+    // b[m] = conj(chirp)[|m|] wrapped to length M; its spectrum via the device plan
+    std::vector<float2> bvec(M, make_float2(0.f, 0.f));
+    for (size_t n = 0; n < N; ++n) {
+        float2 v = make_float2(static_cast<float>(cr[n]), static_cast<float>(-ci[n]));
+        bvec[n] = v;
+        if (n) bvec[M - n] = v;
+    }
+    COMMS_HIP_TRY(hipMalloc(&h->d_chirp, N * sizeof(float2)));
+    COMMS_HIP_TRY(hipMemcpy(h->d_chirp, chirp.data(), N * sizeof(float2), hipMemcpyHostToDevice));
+    COMMS_HIP_TRY(hipMalloc(&h->d_bspec, M * sizeof(float2)));
+    COMMS_HIP_TRY(hipMemcpy(h->d_bspec, bvec.data(), M * sizeof(float2), hipMemcpyHostToDevice));
+    COMMS_TRY(h->work.reserve(M * sizeof(float2)));
+    COMMS_TRY(pow2_run(h->plan, h->d_bspec, h->d_bspec, 1, false, h->stream, static_cast<float2*>(h->work.p)));
+    COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
+    // fold the 1/M of the inverse transform into the spectrum
+    std::vector<float2> spec(M);
+    COMMS_HIP_TRY(hipMemcpy(spec.data(), h->d_bspec, M * sizeof(float2), hipMemcpyDeviceToHost));
+    const float inv = 1.0f / static_cast<float>(M);
+    for (auto& v : spec) {
+        v.x *= inv;
+        v.y *= inv;
+    }
+    COMMS_HIP_TRY(hipMemcpy(h->d_bspec, spec.data(), M * sizeof(float2), hipMemcpyHostToDevice));
+    return COMMS_OK;
+}
+
+extern "C" {
+
+comms_status_t comms_fft_create(size_t fft_size, int32_t inverse, int32_t device,
+                                comms_fft_t** out) {
+    COMMS_ARG(out != nullptr, "out is NULL");
+    *out = nullptr;
+    COMMS_ARG(fft_size >= 1, "fft_size must be >= 1");
+    comms_fft* h = new (std::nothrow) comms_fft;
+    COMMS_ARG(h != nullptr, "out of host memory");
+    comms_status_t st = h->init(device);
+    if (st != COMMS_OK) {
+        delete h;
+        return st;
+    }
+    h->N = fft_size;
+    h->inverse = inverse != 0;
+    st = fft_setup(h);
+    if (st != COMMS_OK) {
+        free_fft(h);
+        return st;
+    }
+    *out = h;
+    return COMMS_OK;
+}
+
+comms_status_t comms_fft_run_dev(comms_fft_t* h, const comms_c32* d_in, size_t n,
+                                 comms_c32* d_out, void* stream) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG(n > 0 && n % h->N == 0,
+              "input length %zu is not a multiple of fft_size %zu (the reference panics)", n, h->N);
+    COMMS_ARG(d_in && d_out, "NULL device pointer");
+    COMMS_TRY(use_device(h->device));
+    hipStream_t s = h->pick(stream);
+    const float2* in = reinterpret_cast<const float2*>(d_in);
+    float2* o = reinterpret_cast<float2*>(d_out);
+    const size_t batch = n / h->N;
+    if (h->N == 1) {
+        if (d_in != d_out) COMMS_HIP_TRY(hipMemcpyAsync(o, in, n * sizeof(float2), hipMemcpyDeviceToDevice, s));
+        return COMMS_OK;
+    }
+    if (h->kind == 0) {
+        float2* scratch = nullptr;
+        if (h->plan.n_pass == 2) {
+            COMMS_TRY(h->work.reserve(n * sizeof(float2)));
+            scratch = static_cast<float2*>(h->work.p);
+        }
+        h->tic(s);
+        comms_status_t st = pow2_run(h->plan, in, o, batch, h->inverse, s, scratch);
+        h->toc(s);
+        return st;
+    }
+    if (h->kind == 1) {
+        COMMS_ARG(!ranges_overlap(d_in, n * 8, d_out, n * 8) , "this fft_size cannot run in place");
+        unsigned blocks = static_cast<unsigned>(batch < 4u * kNumCU ? batch : 4u * kNumCU);
+        dft_direct_kernel<<<dim3(blocks), dim3(256), 2 * h->N * sizeof(float2), s>>>(
+            in, o, static_cast<int>(h->N), batch, h->d_twN, h->inverse ? 1 : 0);
+        return launch_ok("dft_direct_kernel");
+    }
+    // Bluestein, in chunks that bound the work buffer
+    const size_t M = h->M;
+    size_t chunk = (static_cast<size_t>(1) << 24) / M;
+    if (chunk < 1) chunk = 1;
+    if (chunk > batch) chunk = batch;
+    COMMS_TRY(h->work.reserve(chunk * M * sizeof(float2)));
+    if (h->plan.n_pass == 2) COMMS_TRY(h->work2.reserve(chunk * M * sizeof(float2)));
+    float2* a = static_cast<float2*>(h->work.p);
+    float2* sc = static_cast<float2*>(h->work2.p);
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const size_t nb = batch - b0 < chunk ? batch - b0 : chunk;
+        blu_pre_kernel<<<dim3(4 * kNumCU), dim3(256), 0, s>>>(in + b0 * h->N, h->d_chirp, a, h->N, M, nb);
+        COMMS_TRY(launch_ok("blu_pre_kernel"));
+        COMMS_TRY(pow2_run(h->plan, a, a, nb, false, s, sc));
+        blu_mul_kernel<<<dim3(4 * kNumCU), dim3(256), 0, s>>>(a, h->d_bspec, M, nb);
+        COMMS_TRY(launch_ok("blu_mul_kernel"));
+        COMMS_TRY(pow2_run(h->plan, a, a, nb, true, s, sc));
+        blu_post_kernel<<<dim3(4 * kNumCU), dim3(256), 0, s>>>(a, h->d_chirp, o + b0 * h->N, h->N, M, nb);
+        COMMS_TRY(launch_ok("blu_post_kernel"));
+    }
+    return COMMS_OK;
+}
+
+comms_status_t comms_fft_run(comms_fft_t* h, const comms_c32* in, size_t n, comms_c32* out) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG(n > 0 && n % h->N == 0,
+              "input length %zu is not a multiple of fft_size %zu (the reference panics)", n, h->N);
+    COMMS_ARG(in && out, "NULL host pointer");
+    COMMS_TRY(use_device(h->device));
+    COMMS_TRY(h->in_scratch.reserve(n * sizeof(comms_c32)));
+    COMMS_TRY(h->out_scratch.reserve(n * sizeof(comms_c32)));
+    COMMS_HIP_TRY(hipMemcpyAsync(h->in_scratch.p, in, n * sizeof(comms_c32), hipMemcpyHostToDevice, h->stream));
+    COMMS_TRY(comms_fft_run_dev(h, static_cast<comms_c32*>(h->in_scratch.p), n,
+                                static_cast<comms_c32*>(h->out_scratch.p), nullptr));
+    COMMS_HIP_TRY(hipMemcpyAsync(out, h->out_scratch.p, n * sizeof(comms_c32), hipMemcpyDeviceToHost, h->stream));
+    COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
+    return COMMS_OK;
+}
+
+comms_status_t comms_fft_set_timer(comms_fft_t* h, comms_timer_t* t) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    h->timer = t;
+    return COMMS_OK;
+}
+
+comms_status_t comms_fft_destroy(comms_fft_t* h) {
+    if (!h) return COMMS_OK;
+    free_fft(h);
+    return COMMS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,693 @@
+// fir.hip -- FIR filtering of interleaved Complex<f32> streams on gfx950.
+//
+// Replaces fir()/batch_fir() (reference src/filter/fir.rs:43-54, :87-102):
+//     y[n] = sum_{k<N} taps[k] * x[n-k],   history persists across calls.
+//
+// Two kernels behind one handle:
+//   * fir_direct_kernel   time-domain.  256 threads x 8 consecutive outputs;
+//                         input tile + taps staged in LDS, a 16-sample sliding
+//                         window per lane in VGPRs, explicit FMAs.  Bound by
+//                         vector FP32 (8N flop/sample for complex taps, 4N for
+//                         real taps) -- used for short filters and short calls.
+//   * fir_os4096_kernel   overlap-save.  One 4096-point segment per workgroup
+//                         pass: three radix-16 stages in registers (16 points
+//                         per lane), two LDS exchanges per transform, spectrum
+//                         multiply in registers, inverse transform, store of the
+//                         valid 4096-H outputs.  Twiddles and the filter
+//                         spectrum live in VGPRs for the life of the persistent
+//                         workgroup.  ~135 flop/sample at 255 taps, so the
+//                         kernel is HBM-bound: 8 B read + 8 B write per sample.
+//
+// HBM layout: input/output are plain contiguous float2 streams.  The handle
+// keeps the last N input samples in a small device ring (two buffers,
+// ping-pong) in TIME order (oldest first); the reference's `state` vector is
+// the same data newest-first.
+#include <cmath>
+#include <vector>
+
+#include "common.hpp"
+#include "fft_radix.hpp"
+
+namespace comms {
+
+// ---------------------------------------------------------------- history
+// new_hist = last HL samples of concat(old_hist[HL], in[n])
+__global__ void fir_hist_update_kernel(const float2* __restrict__ old_hist,
+                                       const float2* __restrict__ in, size_t n,
+                                       float2* __restrict__ new_hist, int HL) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= HL) return;
+    size_t p = n + static_cast<size_t>(j);  // index into the concatenation
+    new_hist[j] = p < static_cast<size_t>(HL) ? old_hist[p] : in[p - HL];
+}
+
+// Sample g of the logical stream [history | input | zeros]
+__device__ __forceinline__ float2 stream_at(const float2* __restrict__ in,
+                                            const float2* __restrict__ hist, int hist_len,
+                                            long long g, size_t n) {
+    if (g >= 0) return static_cast<size_t>(g) < n ? in[g] : make_float2(0.f, 0.f);
+    return g >= -static_cast<long long>(hist_len) ? hist[hist_len + g] : make_float2(0.f, 0.f);
+}
+
+// ---------------------------------------------------------------- direct form
+constexpr int DT = 8;             // consecutive outputs per lane
+constexpr int DTILE = 256 * DT;   // outputs per workgroup
+constexpr int DROW = 10;          // LDS row: 8 samples + 2 pad (80 B): conflict-free ds_read_b128
+constexpr int DIRECT_MAX_TAPS = 1024;
+
+template <bool REAL_TAPS>
+__global__ __launch_bounds__(256) void fir_direct_kernel(const float2* __restrict__ in,
+                                                         const float2* __restrict__ hist,
+                                                         int hist_len,
+                                                         const float2* __restrict__ taps_pad,
+                                                         int NP, float2* __restrict__ out,
+                                                         size_t n, int out_vec4) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x;
+    const int nrows = (DTILE + NP) / 8;
+    float2* xt = reinterpret_cast<float2*>(smem);
+    float2* tp = xt + nrows * DROW;  // taps (complex) or, if REAL_TAPS, NP floats
+
+    const size_t o0 = static_cast<size_t>(blockIdx.x) * DTILE;
+    if (REAL_TAPS) {
+        float* tr = reinterpret_cast<float*>(tp);
+        for (int k = t; k < NP; k += 256) tr[k] = taps_pad[k].x;
+    } else {
+        for (int k = t; k < NP; k += 256) tp[k] = taps_pad[k];
+    }
+    const long long g0 = static_cast<long long>(o0) - NP;
+    for (int q = t; q < DTILE + NP; q += 256)
+        xt[(q >> 3) * DROW + (q & 7)] = stream_at(in, hist, hist_len, g0 + q, n);
+    __syncthreads();
+
+    float2 acc[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) acc[i] = make_float2(0.f, 0.f);
+
+    float2 wh[8], wl[8];
+    {
+        const float4* r = reinterpret_cast<const float4*>(xt + (NP / 8 + t) * DROW);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 v = r[j];
+            wh[2 * j] = make_float2(v.x, v.y);
+            wh[2 * j + 1] = make_float2(v.z, v.w);
+        }
+    }
+    const int nchunks = NP / 8;
+    for (int c = 0; c < nchunks; ++c) {
+        const float4* r = reinterpret_cast<const float4*>(xt + (NP / 8 + t - c - 1) * DROW);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 v = r[j];
+            wl[2 * j] = make_float2(v.x, v.y);
+            wl[2 * j + 1] = make_float2(v.z, v.w);
+        }
+        if (REAL_TAPS) {
+            const float4* hp = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(tp) + 8 * c);
+            float4 ha = hp[0], hb = hp[1];
+            const float h[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+#pragma unroll
+            for (int o = 0; o < DT; ++o) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int idx = 8 + o - j;
+                    const float2 x = idx >= 8 ? wh[idx - 8] : wl[idx];
+                    acc[o].x = __builtin_fmaf(h[j], x.x, acc[o].x);
+                    acc[o].y = __builtin_fmaf(h[j], x.y, acc[o].y);
+                }
+            }
+        } else {
+            const float4* hp = reinterpret_cast<const float4*>(tp + 8 * c);
+            float2 h[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4 v = hp[j];
+                h[2 * j] = make_float2(v.x, v.y);
+                h[2 * j + 1] = make_float2(v.z, v.w);
+            }
+#pragma unroll
+            for (int o = 0; o < DT; ++o) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int idx = 8 + o - j;
+                    const float2 x = idx >= 8 ? wh[idx - 8] : wl[idx];
+                    acc[o].x = __builtin_fmaf(h[j].x, x.x, acc[o].x);
+                    acc[o].x = __builtin_fmaf(-h[j].y, x.y, acc[o].x);
+                    acc[o].y = __builtin_fmaf(h[j].x, x.y, acc[o].y);
+                    acc[o].y = __builtin_fmaf(h[j].y, x.x, acc[o].y);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wh[j] = wl[j];
+    }
+
+    const size_t ob = o0 + static_cast<size_t>(t) * DT;
+    if (out_vec4 && ob + DT <= n) {
+        float4* o4 = reinterpret_cast<float4*>(out + ob);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o4[j] = make_float4(acc[2 * j].x, acc[2 * j].y, acc[2 * j + 1].x, acc[2 * j + 1].y);
+    } else {
+#pragma unroll
+        for (int j = 0; j < DT; ++j)
+            if (ob + j < n) out[ob + j] = acc[j];
+    }
+}
+
+// ---------------------------------------------------------------- overlap-save, F = 4096
+constexpr int OSF = 4096;
+constexpr int OS_S1 = 272;  // [k0][256 + 16]: odd k0 rows land 32 banks away (ds_read_b64)
+constexpr int OS_S2 = 18;   // [row][16 + 2]: 144-B rows, conflict-free ds_read_b128
+constexpr int OS_LDS = 4608;
+
+struct OsTables {
+    const float2* tw1;   // [16][256]  W4096^{t*k0}
+    const float2* tw2;   // [16][16]   W256^{lo*j}, index [j][lo]
+    const float2* hdev;  // [16][256]  H[k0 + 16*k1 + 256*k2] / 4096 at [k2][16*k0 + k1]
+};
+
+__device__ __forceinline__ void lds_read16_contig(const float2* __restrict__ p, float2 (&v)[16]) {
+    const float4* r = reinterpret_cast<const float4*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float4 x = r[j];
+        v[2 * j] = make_float2(x.x, x.y);
+        v[2 * j + 1] = make_float2(x.z, x.w);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void fir_os4096_kernel(const float2* __restrict__ in,
+                                                            const float2* __restrict__ hist,
+                                                            int hist_len, float2* __restrict__ out,
+                                                            size_t n, int hblk, size_t nseg,
+                                                            OsTables tb) {
+    __shared__ __attribute__((aligned(16))) float2 lds[OS_LDS + 256];
+    const int t = threadIdx.x;
+    const int hi = t >> 4, lo = t & 15;
+
+    // persistent per-lane constants: stage-1 twiddles and the filter spectrum in
+    // VGPRs, the 16x16 stage-2 twiddle table in LDS (read as tw2[j*16 + lo])
+    float2 tw1r[16], hr[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        tw1r[j] = tb.tw1[j * 256 + t];
+        hr[j] = tb.hdev[j * 256 + t];
+    }
+    float2* tw2 = lds + OS_LDS;
+    tw2[t] = tb.tw2[t];
+
+    const int H = 256 * hblk;
+    const int V = OSF - H;
+    float2 v[16];
+
+    for (size_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        const long long base = static_cast<long long>(seg) * V - H;
+        // ---- forward stage 1: lane (b,c) = t holds x[256a + t]; DFT over a -> k0
+        const bool interior = base >= 0 && static_cast<size_t>(base) + OSF <= n;
+        if (interior) {
+#pragma unroll
+            for (int a = 0; a < 16; ++a) v[a] = in[base + 256 * a + t];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 16; ++a) v[a] = stream_at(in, hist, hist_len, base + 256 * a + t, n);
+        }
+        radix16<-1>(v);
+        __syncthreads();  // previous segment's last LDS reads are done
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float2 x = v[R16_POS(k)];
+            if (k) x = cmulf(x, tw1r[k]);
+            lds[k * OS_S1 + t] = x;
+        }
+        __syncthreads();
+        // ---- stage 2: lane (k0,c): DFT over b -> k1
+#pragma unroll
+        for (int b = 0; b < 16; ++b) v[b] = lds[hi * OS_S1 + 16 * b + lo];
+        __syncthreads();
+        radix16<-1>(v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float2 x = v[R16_POS(k)];
+            if (k) x = cmulf(x, tw2[k * 16 + lo]);
+            lds[(hi * 16 + k) * OS_S2 + lo] = x;
+        }
+        __syncthreads();
+        // ---- stage 3: lane (k0,k1): DFT over c -> k2
+        lds_read16_contig(lds + t * OS_S2, v);
+        __syncthreads();
+        radix16<-1>(v);
+        // ---- spectrum multiply (1/4096 folded into hr) and inverse stage 3': over k2 -> c
+        float2 w[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) w[k] = cmulf(v[R16_POS(k)], hr[k]);
+        radix16<1>(w);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float2 x = w[R16_POS(c)];
+            if (c) x = cmulcf(x, tw2[c * 16 + lo]);
+            lds[hi * 288 + c * OS_S2 + lo] = x;  // [k0][c][k1]
+        }
+        __syncthreads();
+        // ---- inverse stage 2': lane (k0,c): over k1 -> b
+        lds_read16_contig(lds + hi * 288 + lo * OS_S2, v);
+        __syncthreads();
+        radix16<1>(v);
+#pragma unroll
+        for (int b = 0; b < 16; ++b) lds[hi * OS_S1 + 16 * b + lo] = v[R16_POS(b)];
+        __syncthreads();
+        // ---- inverse stage 1': lane (b,c) = t: over k0 -> a
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float2 x = lds[k * OS_S1 + t];
+            v[k] = k ? cmulcf(x, tw1r[k]) : x;
+        }
+        radix16<1>(v);
+        // ---- store the V valid outputs: y[256a + t], a >= hblk
+        const size_t obase = seg * static_cast<size_t>(V) + t;
+#pragma unroll
+        for (int a = 1; a < 16; ++a) {
+            if (a >= hblk) {
+                size_t o = obase + static_cast<size_t>(256 * (a - hblk));
+                if (o < n) out[o] = v[R16_POS(a)];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- pulse shaping (polyphase)
+// Reference: PulseNode::run (src/pulse.rs:82-92) = zero-stuff by sps, then FIR.
+//   out[m*sps + p] = sum_j taps[p + j*sps] * sym[m - j]
+__global__ __launch_bounds__(256) void pulse_kernel(const float2* __restrict__ sym,
+                                                    const float2* __restrict__ hist, int hist_len,
+                                                    const float2* __restrict__ taps, int n_taps,
+                                                    int sps, float2* __restrict__ out,
+                                                    size_t n_sym) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* tp = reinterpret_cast<float2*>(smem);
+    for (int k = threadIdx.x; k < n_taps; k += 256) tp[k] = taps[k];
+    __syncthreads();
+    const size_t n_out = n_sym * static_cast<size_t>(sps);
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_out;
+         i += stride) {
+        const size_t m = i / sps;
+        const int p = static_cast<int>(i - m * sps);
+        float2 acc = make_float2(0.f, 0.f);
+        long long s = static_cast<long long>(m);
+        for (int k = p; k < n_taps; k += sps, --s) {
+            const float2 x = stream_at(sym, hist, hist_len, s, n_sym);
+            const float2 h = tp[k];
+            acc.x = __builtin_fmaf(h.x, x.x, acc.x);
+            acc.x = __builtin_fmaf(-h.y, x.y, acc.x);
+            acc.y = __builtin_fmaf(h.x, x.y, acc.y);
+            acc.y = __builtin_fmaf(h.y, x.x, acc.y);
+        }
+        out[i] = acc;
+    }
+}
+
+}  // namespace comms
+
+using namespace comms;
+
+// ================================================================= FIR handle
+struct comms_fir : Handle {
+    int n_eff = 0;       // taps that take part: min(n_taps, n_state)
+    bool real_taps = false;
+    int algo = COMMS_FIR_AUTO;
+    // direct form
+    int NP = 0;          // taps padded to a multiple of 8
+    float2* d_taps_pad = nullptr;
+    // overlap-save
+    bool os_ready = false;
+    int hblk = 0;        // halo = 256*hblk >= n_eff-1
+    float2* d_tw1 = nullptr;
+    float2* d_tw2 = nullptr;
+    float2* d_hdev = nullptr;
+    // history: last n_eff input samples, time order, ping-pong
+    float2* d_hist[2] = {nullptr, nullptr};
+    int cur = 0;
+    std::vector<comms_c32> taps;  // effective taps (host copy)
+};
+
+static void free_fir(comms_fir* h) {
+    (void)use_device(h->device);
+    if (h->d_taps_pad) (void)hipFree(h->d_taps_pad);
+    if (h->d_tw1) (void)hipFree(h->d_tw1);
+    if (h->d_tw2) (void)hipFree(h->d_tw2);
+    if (h->d_hdev) (void)hipFree(h->d_hdev);
+    if (h->d_hist[0]) (void)hipFree(h->d_hist[0]);
+    if (h->d_hist[1]) (void)hipFree(h->d_hist[1]);
+    h->fini();
+    delete h;
+}
+
+static const double kPi = 3.14159265358979323846264338327950288;
+
+// Filter spectrum + twiddle tables for the 4096-point overlap-save kernel (f64 on
+// the host, rounded once to f32).
+static comms_status_t fir_prepare_os(comms_fir* h) {
+    if (h->os_ready) return COMMS_OK;
+    const int N = h->n_eff;
+    COMMS_ARG(N - 1 <= 15 * 256, "overlap-save (F=4096) supports at most 3841 taps, got %d", N);
+    h->hblk = (N - 1 + 255) / 256;
+    if (h->hblk < 1) h->hblk = 1;
+    std::vector<float2> tw1(16 * 256), tw2(16 * 16), hdev(16 * 256);
+    for (int k0 = 0; k0 < 16; ++k0)
+        for (int t = 0; t < 256; ++t) {
+            int e = (t * k0) % OSF;
+            double a = -2.0 * kPi * static_cast<double>(e) / OSF;
+            tw1[k0 * 256 + t] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
+        }
+    for (int j = 0; j < 16; ++j)
+        for (int lo = 0; lo < 16; ++lo) {
+            int e = (lo * j) % 256;
+            double a = -2.0 * kPi * static_cast<double>(e) / 256.0;
+            tw2[j * 16 + lo] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
+        }
+    // H[k] = sum_j taps[j] e^{-2 pi i jk/4096}, exact-index twiddles
+    std::vector<double> cs(OSF), sn(OSF);
+    for (int e = 0; e < OSF; ++e) {
+        double a = -2.0 * kPi * static_cast<double>(e) / OSF;
+        cs[e] = std::cos(a);
+        sn[e] = std::sin(a);
+    }
+    for (int k = 0; k < OSF; ++k) {
+        double re = 0, im = 0;
+        int e = 0;
+        for (int j = 0; j < N; ++j) {
+            double tr = h->taps[j].re, ti = h->taps[j].im;
+            re += tr * cs[e] - ti * sn[e];
+            im += tr * sn[e] + ti * cs[e];
+            e += k;
+            if (e >= OSF) e -= OSF;
+        }
+        int k0 = k & 15, k1 = (k >> 4) & 15, k2 = k >> 8;
+        hdev[k2 * 256 + 16 * k0 + k1] =
+            make_float2(static_cast<float>(re / OSF), static_cast<float>(im / OSF));
+    }
+    COMMS_HIP_TRY(hipMalloc(&h->d_tw1, tw1.size() * sizeof(float2)));
+    COMMS_HIP_TRY(hipMalloc(&h->d_tw2, tw2.size() * sizeof(float2)));
+    COMMS_HIP_TRY(hipMalloc(&h->d_hdev, hdev.size() * sizeof(float2)));
+    COMMS_HIP_TRY(hipMemcpy(h->d_tw1, tw1.data(), tw1.size() * sizeof(float2), hipMemcpyHostToDevice));
+    COMMS_HIP_TRY(hipMemcpy(h->d_tw2, tw2.data(), tw2.size() * sizeof(float2), hipMemcpyHostToDevice));
+    COMMS_HIP_TRY(hipMemcpy(h->d_hdev, hdev.data(), hdev.size() * sizeof(float2), hipMemcpyHostToDevice));
+    h->os_ready = true;
+    return COMMS_OK;
+}
+
+static comms_status_t fir_prepare_direct(comms_fir* h) {
+    if (h->d_taps_pad) return COMMS_OK;
+    COMMS_ARG(h->n_eff <= DIRECT_MAX_TAPS, "direct-form FIR supports at most %d taps, got %d",
+              DIRECT_MAX_TAPS, h->n_eff);
+    h->NP = (h->n_eff + 7) / 8 * 8;
+    std::vector<float2> tp(h->NP, make_float2(0.f, 0.f));
+    for (int k = 0; k < h->n_eff; ++k) tp[k] = make_float2(h->taps[k].re, h->taps[k].im);
+    COMMS_HIP_TRY(hipMalloc(&h->d_taps_pad, tp.size() * sizeof(float2)));
+    COMMS_HIP_TRY(hipMemcpy(h->d_taps_pad, tp.data(), tp.size() * sizeof(float2), hipMemcpyHostToDevice));
+    return COMMS_OK;
+}
+
+// Tap-count crossover of the two kernels (measured on MI355X).
+static int fir_pick(const comms_fir* h, size_t n) {
+    if (h->algo != COMMS_FIR_AUTO) return h->algo;
+    if (h->n_eff > DIRECT_MAX_TAPS) return COMMS_FIR_OVERLAP_SAVE;
+    const int direct_limit = h->real_taps ? 48 : 24;
+    if (h->n_eff <= direct_limit) return COMMS_FIR_DIRECT;
+    // a single short call does not amortise a 4096-point segment
+    if (n * static_cast<size_t>(h->n_eff) < (1u << 18)) return COMMS_FIR_DIRECT;
+    return COMMS_FIR_OVERLAP_SAVE;
+}
+
+static comms_status_t fir_upload_state(comms_fir* h, const comms_c32* state, size_t n_state) {
+    // reference layout: state[0] newest ... -> device ring is time-ordered (oldest first)
+    std::vector<float2> ring(h->n_eff, make_float2(0.f, 0.f));
+    for (int k = 0; k < h->n_eff && static_cast<size_t>(k) < n_state; ++k)
+        ring[h->n_eff - 1 - k] = make_float2(state[k].re, state[k].im);
+    COMMS_HIP_TRY(hipMemcpy(h->d_hist[h->cur], ring.data(), ring.size() * sizeof(float2), hipMemcpyHostToDevice));
+    return COMMS_OK;
+}
+
+extern "C" {
+
+comms_status_t comms_fir_create(const comms_c32* taps, size_t n_taps, const comms_c32* state,
+                                size_t n_state, int32_t device, comms_fir_t** out) {
+    COMMS_ARG(out != nullptr, "out is NULL");
+    *out = nullptr;
+    COMMS_ARG(taps != nullptr && n_taps > 0, "taps must hold at least one tap (the reference panics on an empty state)");
+    COMMS_ARG(state == nullptr || n_state > 0, "a user state must hold at least one sample");
+    size_t n_eff = n_taps;
+    if (state && n_state < n_eff) n_eff = n_state;  // zip(taps, state), fir.rs:53
+    COMMS_ARG(n_eff <= (1u << 20), "too many taps (%zu)", n_eff);
+    comms_fir* h = new (std::nothrow) comms_fir;
+    COMMS_ARG(h != nullptr, "out of host memory");
+    comms_status_t st = h->init(device);
+    if (st != COMMS_OK) {
+        delete h;
+        return st;
+    }
+    h->n_eff = static_cast<int>(n_eff);
+    h->taps.assign(taps, taps + n_eff);
+    h->real_taps = true;
+    for (size_t k = 0; k < n_eff; ++k)
+        if (taps[k].im != 0.0f) h->real_taps = false;
+    for (int i = 0; i < 2; ++i) {
+        hipError_t e = hipMalloc(&h->d_hist[i], n_eff * sizeof(float2));
+        if (e == hipSuccess) e = hipMemset(h->d_hist[i], 0, n_eff * sizeof(float2));
+        if (e != hipSuccess) {
+            free_fir(h);
+            return fail(COMMS_ERR_DEVICE, "FIR history alloc: %s", hipGetErrorString(e));
+        }
+    }
+    if (state) {
+        st = fir_upload_state(h, state, n_state);
+        if (st != COMMS_OK) {
+            free_fir(h);
+            return st;
+        }
+    }
+    *out = h;
+    return COMMS_OK;
+}
+
+comms_status_t comms_fir_set_algo(comms_fir_t* h, int32_t algo) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG(algo == COMMS_FIR_AUTO || algo == COMMS_FIR_DIRECT || algo == COMMS_FIR_OVERLAP_SAVE,
+              "unknown algo %d", algo);
+    COMMS_ARG(algo != COMMS_FIR_DIRECT || h->n_eff <= DIRECT_MAX_TAPS,
+              "direct-form FIR supports at most %d taps", DIRECT_MAX_TAPS);
+    COMMS_ARG(algo != COMMS_FIR_OVERLAP_SAVE || h->n_eff <= 3841,
+              "overlap-save (F=4096) supports at most 3841 taps");
+    h->algo = algo;
+    return COMMS_OK;
+}
+
+comms_status_t comms_fir_get_algo(const comms_fir_t* h, size_t n, int32_t* out_algo) {
+    COMMS_ARG(h && out_algo, "NULL argument");
+    *out_algo = fir_pick(h, n);
+    return COMMS_OK;
+}
+
+comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n,
+                                 comms_c32* d_out, void* stream) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG((d_in && d_out) || !n, "NULL device pointer");
+    COMMS_TRY(use_device(h->device));
+    if (!n) return COMMS_OK;
+    COMMS_ARG(!ranges_overlap(d_in, n * 8, d_out, n * 8), "FIR cannot run in place");
+    COMMS_ARG((reinterpret_cast<uintptr_t>(d_in) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 7) == 0,
+              "device pointers must be 8-byte aligned");
+    hipStream_t s = h->pick(stream);
+    const float2* in = reinterpret_cast<const float2*>(d_in);
+    float2* o = reinterpret_cast<float2*>(d_out);
+    const float2* hist = h->d_hist[h->cur];
+    const int algo = fir_pick(h, n);
+    if (algo == COMMS_FIR_DIRECT) {
+        COMMS_TRY(fir_prepare_direct(h));
+        const unsigned blocks = static_cast<unsigned>((n + DTILE - 1) / DTILE);
+        const int nrows = (DTILE + h->NP) / 8;
+        const size_t lds = static_cast<size_t>(nrows) * DROW * sizeof(float2) + static_cast<size_t>(h->NP) * sizeof(float2);
+        const int vec4 = (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
+        h->tic(s);
+        if (h->real_taps)
+            fir_direct_kernel<true><<<dim3(blocks), dim3(256), lds, s>>>(in, hist, h->n_eff, h->d_taps_pad, h->NP, o, n, vec4);
+        else
+            fir_direct_kernel<false><<<dim3(blocks), dim3(256), lds, s>>>(in, hist, h->n_eff, h->d_taps_pad, h->NP, o, n, vec4);
+        h->toc(s);
+        COMMS_TRY(launch_ok("fir_direct_kernel"));
+    } else {
+        COMMS_TRY(fir_prepare_os(h));
+        const size_t V = OSF - 256 * static_cast<size_t>(h->hblk);
+        const size_t nseg = (n + V - 1) / V;
+        // persistent grid: 2 workgroups per CU, segments split evenly
+        const size_t slots = 2 * kNumCU;
+        const size_t per = (nseg + slots - 1) / slots;
+        const unsigned blocks = static_cast<unsigned>((nseg + per - 1) / per);
+        OsTables tb{h->d_tw1, h->d_tw2, h->d_hdev};
+        h->tic(s);
+        fir_os4096_kernel<<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb);
+        h->toc(s);
+        COMMS_TRY(launch_ok("fir_os4096_kernel"));
+    }
+    // advance the history ring (time order) into the other buffer
+    float2* nh = h->d_hist[h->cur ^ 1];
+    fir_hist_update_kernel<<<dim3((h->n_eff + 255) / 256), dim3(256), 0, s>>>(hist, in, n, nh, h->n_eff);
+    COMMS_TRY(launch_ok("fir_hist_update_kernel"));
+    h->cur ^= 1;
+    return COMMS_OK;
+}
+
+comms_status_t comms_fir_run(comms_fir_t* h, const comms_c32* in, size_t n, comms_c32* out) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG((in && out) || !n, "NULL host pointer");
+    COMMS_TRY(use_device(h->device));
+    if (!n) return COMMS_OK;
+    COMMS_TRY(h->in_scratch.reserve(n * sizeof(comms_c32)));
+    COMMS_TRY(h->out_scratch.reserve(n * sizeof(comms_c32)));
+    COMMS_HIP_TRY(hipMemcpyAsync(h->in_scratch.p, in, n * sizeof(comms_c32), hipMemcpyHostToDevice, h->stream));
+    COMMS_TRY(comms_fir_run_dev(h, static_cast<comms_c32*>(h->in_scratch.p), n,
+                                static_cast<comms_c32*>(h->out_scratch.p), nullptr));
+    COMMS_HIP_TRY(hipMemcpyAsync(out, h->out_scratch.p, n * sizeof(comms_c32), hipMemcpyDeviceToHost, h->stream));
+    COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
+    return COMMS_OK;
+}
+
+comms_status_t comms_fir_get_state(comms_fir_t* h, comms_c32* state, size_t n_state) {
+    COMMS_ARG(h && state, "NULL argument");
+    COMMS_ARG(n_state <= static_cast<size_t>(h->n_eff), "n_state %zu exceeds the %d effective taps", n_state, h->n_eff);
+    COMMS_TRY(use_device(h->device));
+    COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
+    std::vector<float2> ring(h->n_eff);
+    COMMS_HIP_TRY(hipMemcpy(ring.data(), h->d_hist[h->cur], ring.size() * sizeof(float2), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < n_state; ++k) {
+        state[k].re = ring[h->n_eff - 1 - k].x;
+        state[k].im = ring[h->n_eff - 1 - k].y;
+    }
+    return COMMS_OK;
+}
+
+comms_status_t comms_fir_set_state(comms_fir_t* h, const comms_c32* state, size_t n_state) {
+    COMMS_ARG(h && state, "NULL argument");
+    COMMS_ARG(n_state == static_cast<size_t>(h->n_eff), "state must hold exactly the %d effective taps", h->n_eff);
+    COMMS_TRY(use_device(h->device));
+    COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
+    return fir_upload_state(h, state, n_state);
+}
+
+comms_status_t comms_fir_set_timer(comms_fir_t* h, comms_timer_t* t) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    h->timer = t;
+    return COMMS_OK;
+}
+
+comms_status_t comms_fir_destroy(comms_fir_t* h) {
+    if (!h) return COMMS_OK;
+    free_fir(h);
+    return COMMS_OK;
+}
+
+}  // extern "C"
+
+// ================================================================= pulse handle
+struct comms_pulse : Handle {
+    int n_taps = 0;
+    int sps = 1;
+    int hist_len = 0;  // symbols of history kept: ceil(n_taps / sps)
+    float2* d_taps = nullptr;
+    float2* d_hist[2] = {nullptr, nullptr};
+    int cur = 0;
+};
+
+static void free_pulse(comms_pulse* h) {
+    (void)use_device(h->device);
+    if (h->d_taps) (void)hipFree(h->d_taps);
+    if (h->d_hist[0]) (void)hipFree(h->d_hist[0]);
+    if (h->d_hist[1]) (void)hipFree(h->d_hist[1]);
+    h->fini();
+    delete h;
+}
+
+extern "C" {
+
+comms_status_t comms_pulse_create(const comms_c32* taps, size_t n_taps, size_t sam_per_sym,
+                                  int32_t device, comms_pulse_t** out) {
+    COMMS_ARG(out != nullptr, "out is NULL");
+    *out = nullptr;
+    COMMS_ARG(taps != nullptr && n_taps > 0, "taps must hold at least one tap");
+    COMMS_ARG(sam_per_sym >= 1, "sam_per_sym must be >= 1 (0 underflows in the reference, pulse.rs:88)");
+    COMMS_ARG(n_taps <= 8192, "pulse shaping supports at most 8192 taps (got %zu)", n_taps);
+    COMMS_ARG(sam_per_sym <= (1u << 20), "sam_per_sym too large");
+    comms_pulse* h = new (std::nothrow) comms_pulse;
+    COMMS_ARG(h != nullptr, "out of host memory");
+    comms_status_t st = h->init(device);
+    if (st != COMMS_OK) {
+        delete h;
+        return st;
+    }
+    h->n_taps = static_cast<int>(n_taps);
+    h->sps = static_cast<int>(sam_per_sym);
+    h->hist_len = static_cast<int>((n_taps + sam_per_sym - 1) / sam_per_sym);
+    hipError_t e = hipMalloc(&h->d_taps, n_taps * sizeof(float2));
+    if (e == hipSuccess) e = hipMemcpy(h->d_taps, taps, n_taps * sizeof(float2), hipMemcpyHostToDevice);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipMalloc(&h->d_hist[i], h->hist_len * sizeof(float2));
+        if (e == hipSuccess) e = hipMemset(h->d_hist[i], 0, h->hist_len * sizeof(float2));
+    }
+    if (e != hipSuccess) {
+        free_pulse(h);
+        return fail(COMMS_ERR_DEVICE, "pulse alloc: %s", hipGetErrorString(e));
+    }
+    *out = h;
+    return COMMS_OK;
+}
+
+comms_status_t comms_pulse_run_dev(comms_pulse_t* h, const comms_c32* d_sym, size_t n_sym,
+                                   comms_c32* d_out, void* stream) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG((d_sym && d_out) || !n_sym, "NULL device pointer");
+    COMMS_TRY(use_device(h->device));
+    if (!n_sym) return COMMS_OK;
+    COMMS_ARG(n_sym <= SIZE_MAX / 8 / h->sps, "n_sym * sam_per_sym overflows");
+    const size_t n_out = n_sym * h->sps;
+    COMMS_ARG(!ranges_overlap(d_sym, n_sym * 8, d_out, n_out * 8), "pulse shaping cannot run in place");
+    hipStream_t s = h->pick(stream);
+    const float2* sym = reinterpret_cast<const float2*>(d_sym);
+    size_t blocks = (n_out + 255) / 256;
+    if (blocks > 8u * kNumCU) blocks = 8u * kNumCU;
+    pulse_kernel<<<dim3(static_cast<unsigned>(blocks)), dim3(256), h->n_taps * sizeof(float2), s>>>(
+        sym, h->d_hist[h->cur], h->hist_len, h->d_taps, h->n_taps, h->sps,
+        reinterpret_cast<float2*>(d_out), n_sym);
+    COMMS_TRY(launch_ok("pulse_kernel"));
+    fir_hist_update_kernel<<<dim3((h->hist_len + 255) / 256), dim3(256), 0, s>>>(
+        h->d_hist[h->cur], sym, n_sym, h->d_hist[h->cur ^ 1], h->hist_len);
+    COMMS_TRY(launch_ok("fir_hist_update_kernel"));
+    h->cur ^= 1;
+    return COMMS_OK;
+}
+
+comms_status_t comms_pulse_run(comms_pulse_t* h, const comms_c32* sym, size_t n_sym,
+                               comms_c32* out) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG((sym && out) || !n_sym, "NULL host pointer");
+    COMMS_TRY(use_device(h->device));
+    if (!n_sym) return COMMS_OK;
+    const size_t n_out = n_sym * h->sps;
+    COMMS_TRY(h->in_scratch.reserve(n_sym * sizeof(comms_c32)));
+    COMMS_TRY(h->out_scratch.reserve(n_out * sizeof(comms_c32)));
+    COMMS_HIP_TRY(hipMemcpyAsync(h->in_scratch.p, sym, n_sym * sizeof(comms_c32), hipMemcpyHostToDevice, h->stream));
+    COMMS_TRY(comms_pulse_run_dev(h, static_cast<comms_c32*>(h->in_scratch.p), n_sym,
+                                  static_cast<comms_c32*>(h->out_scratch.p), nullptr));
+    COMMS_HIP_TRY(hipMemcpyAsync(out, h->out_scratch.p, n_out * sizeof(comms_c32), hipMemcpyDeviceToHost, h->stream));
+    COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
+    return COMMS_OK;
+}
+
+comms_status_t comms_pulse_destroy(comms_pulse_t* h) {
+    if (!h) return COMMS_OK;
+    free_pulse(h);
+    return COMMS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,458 @@
+// pointwise.hip -- HBM-bound per-sample nodes: mixer, decimate, upsample, FM demod.
+//
+// Data layout: interleaved Complex<f32> (float2) streams in HBM, read and
+// written once, 16 B per lane where alignment allows.  Built with
+// -ffp-contract=off so the complex products keep the reference's unfused
+// 4-mul/2-add form (num-complex `Mul`).
+#include <cmath>
+
+#include "common.hpp"
+
+namespace comms {
+
+// =============================================================== mixer
+// Reference: Mixer::mix (src/mixer.rs:73-84).  The phase of sample n is
+// phase0 + n*dphase reduced modulo T = fl(2*pi) exactly as the reference's
+// `if phase > 2pi { phase -= 2pi }` does.  It is tracked as a 64-bit
+// fixed-point fraction of T ("turns"), so any sample index can be evaluated
+// in closed form: turns(n) = turns0 + n*frac (mod 2^64).  A thread evaluates
+// its first rotor with one f64 sincos and then steps it by a constant rotor
+// (f64 complex multiply) per grid sweep.
+constexpr double kT = 2.0 * 3.14159265358979323846264338327950288;
+
+__device__ inline void rotor_at(uint64_t turns, double& c, double& s) {
+    double ang = static_cast<double>(turns >> 11) * (kT * 0x1.0p-53);
+    sincos(ang, &s, &c);
+}
+__device__ inline float2 mix1(float2 x, double c, double s) {
+    double xr = static_cast<double>(x.x), xi = static_cast<double>(x.y);
+    // (xr + i xi) * (c + i s), num-complex form, f64, then `as f32`
+    return make_float2(static_cast<float>(xr * c - xi * s), static_cast<float>(xr * s + xi * c));
+}
+__device__ inline void rot_step(double& c, double& s, double sc, double ss) {
+    double nc = c * sc - s * ss;
+    double ns = c * ss + s * sc;
+    c = nc;
+    s = ns;
+}
+
+// VEC = samples per thread per sweep (2 -> float4 accesses, needs 16-B alignment)
+template <int VEC>
+__global__ __launch_bounds__(256) void mixer_kernel(const float2* __restrict__ in,
+                                                    float2* __restrict__ out, size_t n,
+                                                    uint64_t turns0, uint64_t frac, double sweep_c,
+                                                    double sweep_s, double d_c, double d_s) {
+    const size_t nthreads = static_cast<size_t>(gridDim.x) * blockDim.x;
+    const size_t gid = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t ngroups = n / VEC;
+    if (gid < ngroups) {
+        double c0, s0;
+        rotor_at(turns0 + static_cast<uint64_t>(gid * VEC) * frac, c0, s0);
+        double c1 = c0, s1 = s0;
+        if (VEC == 2) rot_step(c1, s1, d_c, d_s);
+        for (size_t g = gid; g < ngroups; g += nthreads) {
+            if (VEC == 2) {
+                float4 x = reinterpret_cast<const float4*>(in)[g];
+                float2 a = mix1(make_float2(x.x, x.y), c0, s0);
+                float2 b = mix1(make_float2(x.z, x.w), c1, s1);
+                reinterpret_cast<float4*>(out)[g] = make_float4(a.x, a.y, b.x, b.y);
+                rot_step(c1, s1, sweep_c, sweep_s);
+            } else {
+                out[g] = mix1(in[g], c0, s0);
+            }
+            rot_step(c0, s0, sweep_c, sweep_s);
+        }
+    }
+    // odd tail (VEC == 2 only): one thread, exact evaluation
+    if (VEC == 2 && gid == 0 && (n & 1)) {
+        double c, s;
+        rotor_at(turns0 + static_cast<uint64_t>(n - 1) * frac, c, s);
+        out[n - 1] = mix1(in[n - 1], c, s);
+    }
+}
+
+// =============================================================== decimate / upsample
+// Reference: resample_node.rs:53-65 / :120-131.  Byte-exact copies of a Copy type.
+template <typename V>
+__global__ __launch_bounds__(256) void decimate_kernel(const V* __restrict__ in,
+                                                       V* __restrict__ out, size_t n_out,
+                                                       size_t rate) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t j = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < n_out;
+         j += stride)
+        out[j] = in[j * rate];
+}
+
+template <typename V>
+__global__ __launch_bounds__(256) void upsample_kernel(const V* __restrict__ in,
+                                                       V* __restrict__ out, size_t n_out,
+                                                       size_t rate) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    // one division per thread, then incremental quotient/remainder per sweep
+    size_t q = i / rate, r = i - q * rate;
+    const size_t sq = stride / rate, sr = stride - sq * rate;
+    V zero;
+    memset(&zero, 0, sizeof(V));
+    for (; i < n_out; i += stride) {
+        out[i] = (r == 0) ? in[q] : zero;
+        q += sq;
+        r += sr;
+        if (r >= rate) {
+            r -= rate;
+            ++q;
+        }
+    }
+}
+
+// =============================================================== FM demod
+// Reference: FM::demod (src/modulation/analog.rs:22-35):
+//   theta = samp * prev.conj();  out = atan2(theta.im, theta.re);  prev = samp.
+__device__ inline float fm1(float2 x, float2 p) {
+    float pcr = p.x, pci = -p.y;  // conj()
+    float re = x.x * pcr - x.y * pci;
+    float im = x.x * pci + x.y * pcr;
+    return atan2f(im, re);
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void fmdemod_kernel(const float2* __restrict__ in,
+                                                      const float2* __restrict__ prev,
+                                                      float* __restrict__ out, size_t n) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x * 4;
+    for (size_t i0 = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 4; i0 < n;
+         i0 += stride) {
+        float2 p = (i0 == 0) ? prev[0] : in[i0 - 1];
+        if (ALIGNED && i0 + 4 <= n) {
+            float4 a = reinterpret_cast<const float4*>(in + i0)[0];
+            float4 b = reinterpret_cast<const float4*>(in + i0)[1];
+            float2 x0 = make_float2(a.x, a.y), x1 = make_float2(a.z, a.w);
+            float2 x2 = make_float2(b.x, b.y), x3 = make_float2(b.z, b.w);
+            float4 o = make_float4(fm1(x0, p), fm1(x1, x0), fm1(x2, x1), fm1(x3, x2));
+            *reinterpret_cast<float4*>(out + i0) = o;
+        } else {
+            size_t end = i0 + 4 < n ? i0 + 4 : n;
+            for (size_t i = i0; i < end; ++i) {
+                float2 x = in[i];
+                out[i] = fm1(x, p);
+                p = x;
+            }
+        }
+    }
+}
+
+inline unsigned grid_for(size_t work_items, unsigned per_block, unsigned max_blocks) {
+    size_t b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return static_cast<unsigned>(b);
+}
+
+}  // namespace comms
+
+using namespace comms;
+
+// ------------------------------------------------------------------ mixer handle
+struct comms_mixer : Handle {
+    double dphase;       // wrapped into [0, T) as Mixer::new does
+    uint64_t turns;      // current phase as a fraction of T, 2^-64 units
+    uint64_t frac;       // dphase as a fraction of T
+};
+
+static uint64_t to_turns(double angle) {
+    long double r = fmodl(static_cast<long double>(angle), static_cast<long double>(kT));
+    if (r < 0) r += static_cast<long double>(kT);
+    long double t = r / static_cast<long double>(kT) * 18446744073709551616.0L;
+    if (t >= 18446744073709551616.0L) return 0;
+    return static_cast<uint64_t>(t);
+}
+static void host_rotor(uint64_t turns, double& c, double& s) {
+    double ang = static_cast<double>(turns >> 11) * (kT * 0x1.0p-53);
+    c = std::cos(ang);
+    s = std::sin(ang);
+}
+
+extern "C" {
+
+comms_status_t comms_mixer_create(double dphase, double phase, int32_t device,
+                                  comms_mixer_t** out) {
+    COMMS_ARG(out != nullptr, "out is NULL");
+    *out = nullptr;
+    COMMS_ARG(std::isfinite(dphase) && std::isfinite(phase), "dphase/phase must be finite");
+    comms_mixer* h = new (std::nothrow) comms_mixer;
+    COMMS_ARG(h != nullptr, "out of host memory");
+    comms_status_t st = h->init(device);
+    if (st != COMMS_OK) {
+        delete h;
+        return st;
+    }
+    // Mixer::new (src/mixer.rs:43-51): wrap dphase into [0, 2pi).  The
+    // reference loops; beyond a few turns fmod gives the same value without
+    // the loop's O(|dphase|) trip count.
+    if (std::fabs(dphase) > 64.0 * kT) dphase = std::fmod(dphase, kT);
+    while (dphase >= kT) dphase -= kT;
+    while (dphase < 0.0) dphase += kT;
+    h->dphase = dphase;
+    h->frac = to_turns(dphase);
+    h->turns = to_turns(phase);
+    *out = h;
+    return COMMS_OK;
+}
+
+comms_status_t comms_mixer_run_dev(comms_mixer_t* h, const comms_c32* d_in, size_t n,
+                                   comms_c32* d_out, void* stream) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG((d_in && d_out) || !n, "NULL device pointer");
+    COMMS_TRY(use_device(h->device));
+    if (!n) return COMMS_OK;
+    hipStream_t s = h->pick(stream);
+    const bool vec2 = ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0 && n >= 2;
+    const int VEC = vec2 ? 2 : 1;
+    unsigned blocks = grid_for(n / VEC, 256, 8 * kNumCU);
+    uint64_t sweep = static_cast<uint64_t>(blocks) * 256u * VEC;
+    double sc, ss, dc, ds;
+    host_rotor(sweep * h->frac, sc, ss);
+    host_rotor(h->frac, dc, ds);
+    const float2* in = reinterpret_cast<const float2*>(d_in);
+    float2* o = reinterpret_cast<float2*>(d_out);
+    h->tic(s);
+    if (vec2)
+        mixer_kernel<2><<<dim3(blocks), dim3(256), 0, s>>>(in, o, n, h->turns, h->frac, sc, ss, dc, ds);
+    else
+        mixer_kernel<1><<<dim3(blocks), dim3(256), 0, s>>>(in, o, n, h->turns, h->frac, sc, ss, dc, ds);
+    h->toc(s);
+    COMMS_TRY(launch_ok("mixer_kernel"));
+    h->turns += static_cast<uint64_t>(n) * h->frac;
+    return COMMS_OK;
+}
+
+comms_status_t comms_mixer_run(comms_mixer_t* h, const comms_c32* in, size_t n, comms_c32* out) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG((in && out) || !n, "NULL host pointer");
+    COMMS_TRY(use_device(h->device));
+    if (!n) return COMMS_OK;
+    COMMS_TRY(h->in_scratch.reserve(n * sizeof(comms_c32)));
+    COMMS_HIP_TRY(hipMemcpyAsync(h->in_scratch.p, in, n * sizeof(comms_c32), hipMemcpyHostToDevice, h->stream));
+    comms_c32* d = static_cast<comms_c32*>(h->in_scratch.p);
+    COMMS_TRY(comms_mixer_run_dev(h, d, n, d, nullptr));
+    COMMS_HIP_TRY(hipMemcpyAsync(out, d, n * sizeof(comms_c32), hipMemcpyDeviceToHost, h->stream));
+    COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
+    return COMMS_OK;
+}
+
+comms_status_t comms_mixer_get_phase(const comms_mixer_t* h, double* out_phase) {
+    COMMS_ARG(h && out_phase, "NULL argument");
+    *out_phase = static_cast<double>(h->turns >> 11) * (kT * 0x1.0p-53);
+    return COMMS_OK;
+}
+
+comms_status_t comms_mixer_set_timer(comms_mixer_t* h, comms_timer_t* t) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    h->timer = t;
+    return COMMS_OK;
+}
+
+comms_status_t comms_mixer_destroy(comms_mixer_t* h) {
+    if (!h) return COMMS_OK;
+    (void)use_device(h->device);
+    h->fini();
+    delete h;
+    return COMMS_OK;
+}
+
+// ------------------------------------------------------------------ decimate / upsample
+comms_status_t comms_decimate_out_len(size_t n, size_t rate, size_t* out_n) {
+    COMMS_ARG(out_n != nullptr, "out_n is NULL");
+    *out_n = (rate <= 1) ? n : (n + rate - 1) / rate;
+    return COMMS_OK;
+}
+comms_status_t comms_upsample_out_len(size_t n, size_t rate, size_t* out_n) {
+    COMMS_ARG(out_n != nullptr, "out_n is NULL");
+    if (rate <= 1) {
+        *out_n = n;
+        return COMMS_OK;
+    }
+    COMMS_ARG(n <= SIZE_MAX / rate, "n * rate overflows");
+    *out_n = n * rate;
+    return COMMS_OK;
+}
+
+static bool elem_ok(size_t e) { return e == 1 || e == 2 || e == 4 || e == 8 || e == 16; }
+
+#define COMMS_RESAMPLE_DISPATCH(KERNEL, elem, ...)                                              \
+    switch (elem) {                                                                             \
+        case 1: KERNEL<uint8_t><<<dim3(blocks), dim3(256), 0, s>>>(static_cast<const uint8_t*>(d_in), static_cast<uint8_t*>(d_out), __VA_ARGS__); break;   \
+        case 2: KERNEL<uint16_t><<<dim3(blocks), dim3(256), 0, s>>>(static_cast<const uint16_t*>(d_in), static_cast<uint16_t*>(d_out), __VA_ARGS__); break; \
+        case 4: KERNEL<uint32_t><<<dim3(blocks), dim3(256), 0, s>>>(static_cast<const uint32_t*>(d_in), static_cast<uint32_t*>(d_out), __VA_ARGS__); break; \
+        case 8: KERNEL<uint2><<<dim3(blocks), dim3(256), 0, s>>>(static_cast<const uint2*>(d_in), static_cast<uint2*>(d_out), __VA_ARGS__); break;         \
+        default: KERNEL<uint4><<<dim3(blocks), dim3(256), 0, s>>>(static_cast<const uint4*>(d_in), static_cast<uint4*>(d_out), __VA_ARGS__); break;        \
+    }
+
+comms_status_t comms_decimate_run_dev(const void* d_in, size_t n, size_t elem, size_t rate,
+                                      void* d_out, size_t* out_n, int32_t device, void* stream) {
+    COMMS_ARG(elem_ok(elem), "elem must be 1, 2, 4, 8 or 16 bytes (got %zu)", elem);
+    COMMS_ARG((d_in && d_out) || !n, "NULL device pointer");
+    COMMS_ARG(((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) % elem) == 0,
+              "pointers must be aligned to elem");
+    size_t n_out = 0;
+    COMMS_TRY(comms_decimate_out_len(n, rate, &n_out));
+    if (out_n) *out_n = n_out;
+    COMMS_TRY(use_device(device));
+    if (!n_out) return COMMS_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (rate <= 1) {
+        if (d_in != d_out)
+            COMMS_HIP_TRY(hipMemcpyAsync(d_out, d_in, n * elem, hipMemcpyDeviceToDevice, s));
+        return COMMS_OK;
+    }
+    unsigned blocks = grid_for(n_out, 256, 8 * kNumCU);
+    COMMS_RESAMPLE_DISPATCH(decimate_kernel, elem, n_out, rate)
+    return launch_ok("decimate_kernel");
+}
+
+comms_status_t comms_upsample_run_dev(const void* d_in, size_t n, size_t elem, size_t rate,
+                                      void* d_out, size_t* out_n, int32_t device, void* stream) {
+    COMMS_ARG(elem_ok(elem), "elem must be 1, 2, 4, 8 or 16 bytes (got %zu)", elem);
+    COMMS_ARG((d_in && d_out) || !n, "NULL device pointer");
+    COMMS_ARG(((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) % elem) == 0,
+              "pointers must be aligned to elem");
+    size_t n_out = 0;
+    COMMS_TRY(comms_upsample_out_len(n, rate, &n_out));
+    if (out_n) *out_n = n_out;
+    COMMS_TRY(use_device(device));
+    if (!n_out) return COMMS_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (rate <= 1) {
+        if (d_in != d_out)
+            COMMS_HIP_TRY(hipMemcpyAsync(d_out, d_in, n * elem, hipMemcpyDeviceToDevice, s));
+        return COMMS_OK;
+    }
+    COMMS_ARG(!ranges_overlap(d_in, n * elem, d_out, n_out * elem), "upsample cannot run in place");
+    unsigned blocks = grid_for(n_out, 256, 8 * kNumCU);
+    COMMS_RESAMPLE_DISPATCH(upsample_kernel, elem, n_out, rate)
+    return launch_ok("upsample_kernel");
+}
+
+static comms_status_t resample_host(bool up, const void* in, size_t n, size_t elem, size_t rate,
+                                    void* out, size_t* out_n, int32_t device) {
+    COMMS_ARG(elem_ok(elem), "elem must be 1, 2, 4, 8 or 16 bytes (got %zu)", elem);
+    COMMS_ARG((in && out) || !n, "NULL host pointer");
+    size_t n_out = 0;
+    COMMS_TRY(up ? comms_upsample_out_len(n, rate, &n_out) : comms_decimate_out_len(n, rate, &n_out));
+    if (out_n) *out_n = n_out;
+    COMMS_TRY(use_device(device));
+    if (!n_out) return COMMS_OK;
+    void *d_in = nullptr, *d_out = nullptr;
+    COMMS_HIP_TRY(hipMalloc(&d_in, n * elem));
+    hipError_t e = hipMalloc(&d_out, n_out * elem);
+    if (e != hipSuccess) {
+        (void)hipFree(d_in);
+        return fail(COMMS_ERR_DEVICE, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    comms_status_t st = COMMS_OK;
+    e = hipMemcpy(d_in, in, n * elem, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        st = up ? comms_upsample_run_dev(d_in, n, elem, rate, d_out, nullptr, device, nullptr)
+                : comms_decimate_run_dev(d_in, n, elem, rate, d_out, nullptr, device, nullptr);
+        if (st == COMMS_OK) e = hipMemcpy(out, d_out, n_out * elem, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (st != COMMS_OK) return st;
+    if (e != hipSuccess) return fail(COMMS_ERR_DEVICE, "resample copy: %s", hipGetErrorString(e));
+    return COMMS_OK;
+}
+
+comms_status_t comms_decimate_run(const void* in, size_t n, size_t elem, size_t rate, void* out,
+                                  size_t* out_n, int32_t device) {
+    return resample_host(false, in, n, elem, rate, out, out_n, device);
+}
+comms_status_t comms_upsample_run(const void* in, size_t n, size_t elem, size_t rate, void* out,
+                                  size_t* out_n, int32_t device) {
+    return resample_host(true, in, n, elem, rate, out, out_n, device);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ FM demod handle
+struct comms_fmdemod : Handle {
+    float2* d_prev = nullptr;  // FM.prev (analog.rs:9), starts 0+0i
+};
+
+extern "C" {
+
+comms_status_t comms_fmdemod_create(int32_t device, comms_fmdemod_t** out) {
+    COMMS_ARG(out != nullptr, "out is NULL");
+    *out = nullptr;
+    comms_fmdemod* h = new (std::nothrow) comms_fmdemod;
+    COMMS_ARG(h != nullptr, "out of host memory");
+    comms_status_t st = h->init(device);
+    if (st != COMMS_OK) {
+        delete h;
+        return st;
+    }
+    hipError_t e = hipMalloc(&h->d_prev, sizeof(float2));
+    if (e == hipSuccess) e = hipMemset(h->d_prev, 0, sizeof(float2));
+    if (e != hipSuccess) {
+        h->fini();
+        delete h;
+        return fail(COMMS_ERR_DEVICE, "fmdemod state alloc: %s", hipGetErrorString(e));
+    }
+    *out = h;
+    return COMMS_OK;
+}
+
+comms_status_t comms_fmdemod_run_dev(comms_fmdemod_t* h, const comms_c32* d_in, size_t n,
+                                     float* d_out, void* stream) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG((d_in && d_out) || !n, "NULL device pointer");
+    COMMS_TRY(use_device(h->device));
+    if (!n) return COMMS_OK;
+    COMMS_ARG(!ranges_overlap(d_in, n * 8, d_out, n * 4), "fmdemod cannot run in place");
+    hipStream_t s = h->pick(stream);
+    const float2* in = reinterpret_cast<const float2*>(d_in);
+    unsigned blocks = grid_for((n + 3) / 4, 256, 8 * kNumCU);
+    bool aligned = ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0;
+    h->tic(s);
+    if (aligned)
+        fmdemod_kernel<true><<<dim3(blocks), dim3(256), 0, s>>>(in, h->d_prev, d_out, n);
+    else
+        fmdemod_kernel<false><<<dim3(blocks), dim3(256), 0, s>>>(in, h->d_prev, d_out, n);
+    h->toc(s);
+    COMMS_TRY(launch_ok("fmdemod_kernel"));
+    COMMS_HIP_TRY(hipMemcpyAsync(h->d_prev, in + (n - 1), sizeof(float2), hipMemcpyDeviceToDevice, s));
+    return COMMS_OK;
+}
+
+comms_status_t comms_fmdemod_run(comms_fmdemod_t* h, const comms_c32* in, size_t n, float* out) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG((in && out) || !n, "NULL host pointer");
+    COMMS_TRY(use_device(h->device));
+    if (!n) return COMMS_OK;
+    COMMS_TRY(h->in_scratch.reserve(n * sizeof(comms_c32)));
+    COMMS_TRY(h->out_scratch.reserve(n * sizeof(float)));
+    COMMS_HIP_TRY(hipMemcpyAsync(h->in_scratch.p, in, n * sizeof(comms_c32), hipMemcpyHostToDevice, h->stream));
+    COMMS_TRY(comms_fmdemod_run_dev(h, static_cast<comms_c32*>(h->in_scratch.p), n,
+                                    static_cast<float*>(h->out_scratch.p), nullptr));
+    COMMS_HIP_TRY(hipMemcpyAsync(out, h->out_scratch.p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
+    return COMMS_OK;
+}
+
+comms_status_t comms_fmdemod_set_timer(comms_fmdemod_t* h, comms_timer_t* t) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    h->timer = t;
+    return COMMS_OK;
+}
+
+comms_status_t comms_fmdemod_destroy(comms_fmdemod_t* h) {
+    if (!h) return COMMS_OK;
+    (void)use_device(h->device);
+    if (h->d_prev) (void)hipFree(h->d_prev);
+    h->fini();
+    delete h;
+    return COMMS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,212 @@
+// runtime.hip -- library-wide plumbing: errors, device selection, ref-counted
+// device buffers (the DeviceBuf<T> message type), synthetic IQ generator.
+#include <atomic>
+
+#include "common.hpp"
+
+namespace comms {
+
+comms_status_t use_device(int32_t device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(COMMS_ERR_DEVICE,
+                    "no usable HIP device (%s); libcomms_hip has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n)
+        return fail(COMMS_ERR_ARG, "device %d out of range [0,%d)", device, n);
+    COMMS_HIP_TRY(hipSetDevice(device));
+    return COMMS_OK;
+}
+
+// SplitMix64 finaliser on a counter: stateless, so any index range can be
+// produced anywhere.  Word k of the stream = mix(seed + (k+1)*golden).
+__host__ __device__ inline uint64_t splitmix(uint64_t seed, uint64_t k) {
+    uint64_t z = seed + (k + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ inline float unit_pm1(uint64_t w) {
+    // top 24 bits -> [0, 2) in steps of 2^-23, minus 1 -> [-1, 1)
+    return static_cast<float>(static_cast<uint32_t>(w >> 40)) * (1.0f / 8388608.0f) - 1.0f;
+}
+
+__global__ void synth_iq_kernel(float2* out, size_t n, uint64_t first, uint64_t seed) {
+    size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint64_t g = first + i;
+        out[i] = make_float2(unit_pm1(splitmix(seed, 2 * g)), unit_pm1(splitmix(seed, 2 * g + 1)));
+    }
+}
+
+}  // namespace comms
+
+using namespace comms;
+
+struct comms_buf {
+    void* ptr;
+    size_t bytes;
+    int32_t device;
+    std::atomic<int> refs;
+};
+
+extern "C" {
+
+const char* comms_version(void) { return "comms_hip 0.1.0 (gfx950)"; }
+const char* comms_last_error(void) { return err_buf(); }
+
+comms_status_t comms_device_count(int32_t* out_n) {
+    COMMS_ARG(out_n != nullptr, "out_n is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *out_n = 0;
+        return fail(COMMS_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *out_n = n;
+    return COMMS_OK;
+}
+
+comms_status_t comms_device_info(int32_t device, char* name, size_t name_cap, int32_t* out_cus,
+                                 uint64_t* out_hbm_bytes) {
+    COMMS_TRY(use_device(device));
+    hipDeviceProp_t p;
+    COMMS_HIP_TRY(hipGetDeviceProperties(&p, device));
+    if (name && name_cap) snprintf(name, name_cap, "%s (%s)", p.name, p.gcnArchName);
+    if (out_cus) *out_cus = p.multiProcessorCount;
+    if (out_hbm_bytes) *out_hbm_bytes = p.totalGlobalMem;
+    return COMMS_OK;
+}
+
+comms_status_t comms_buf_alloc(size_t bytes, int32_t device, comms_buf_t** out) {
+    COMMS_ARG(out != nullptr, "out is NULL");
+    *out = nullptr;
+    COMMS_TRY(use_device(device));
+    comms_buf* b = new (std::nothrow) comms_buf;
+    COMMS_ARG(b != nullptr, "out of host memory");
+    b->ptr = nullptr;
+    b->bytes = bytes;
+    b->device = device;
+    b->refs.store(1);
+    if (bytes) {
+        hipError_t e = hipMalloc(&b->ptr, bytes);
+        if (e != hipSuccess) {
+            delete b;
+            return fail(COMMS_ERR_DEVICE, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        }
+    }
+    *out = b;
+    return COMMS_OK;
+}
+comms_status_t comms_buf_retain(comms_buf_t* b) {
+    COMMS_ARG(b != nullptr, "buffer is NULL");
+    b->refs.fetch_add(1);
+    return COMMS_OK;
+}
+comms_status_t comms_buf_release(comms_buf_t* b) {
+    COMMS_ARG(b != nullptr, "buffer is NULL");
+    if (b->refs.fetch_sub(1) == 1) {
+        if (b->ptr) {
+            COMMS_TRY(use_device(b->device));
+            COMMS_HIP_TRY(hipFree(b->ptr));
+        }
+        delete b;
+    }
+    return COMMS_OK;
+}
+comms_status_t comms_buf_upload(comms_buf_t* b, size_t offset, const void* host, size_t bytes) {
+    COMMS_ARG(b && (host || !bytes), "NULL argument");
+    COMMS_ARG(offset <= b->bytes && bytes <= b->bytes - offset, "upload of %zu at %zu exceeds %zu",
+              bytes, offset, b->bytes);
+    COMMS_TRY(use_device(b->device));
+    if (bytes)
+        COMMS_HIP_TRY(hipMemcpy(static_cast<char*>(b->ptr) + offset, host, bytes,
+                                hipMemcpyHostToDevice));
+    return COMMS_OK;
+}
+comms_status_t comms_buf_download(const comms_buf_t* b, size_t offset, void* host, size_t bytes) {
+    COMMS_ARG(b && (host || !bytes), "NULL argument");
+    COMMS_ARG(offset <= b->bytes && bytes <= b->bytes - offset,
+              "download of %zu at %zu exceeds %zu", bytes, offset, b->bytes);
+    COMMS_TRY(use_device(b->device));
+    if (bytes)
+        COMMS_HIP_TRY(hipMemcpy(host, static_cast<const char*>(b->ptr) + offset, bytes,
+                                hipMemcpyDeviceToHost));
+    return COMMS_OK;
+}
+void* comms_buf_ptr(const comms_buf_t* b) { return b ? b->ptr : nullptr; }
+size_t comms_buf_size(const comms_buf_t* b) { return b ? b->bytes : 0; }
+int32_t comms_buf_device(const comms_buf_t* b) { return b ? b->device : -1; }
+
+comms_status_t comms_timer_create(size_t n_pairs, int32_t device, comms_timer_t** out) {
+    COMMS_ARG(out != nullptr, "out is NULL");
+    *out = nullptr;
+    COMMS_ARG(n_pairs >= 1 && n_pairs <= (1u << 20), "n_pairs out of range");
+    COMMS_TRY(use_device(device));
+    comms_timer* t = new (std::nothrow) comms_timer;
+    COMMS_ARG(t != nullptr, "out of host memory");
+    t->device = device;
+    t->n = n_pairs;
+    t->start = new (std::nothrow) hipEvent_t[n_pairs];
+    t->stop = new (std::nothrow) hipEvent_t[n_pairs];
+    for (size_t i = 0; i < n_pairs; ++i) {
+        COMMS_HIP_TRY(hipEventCreate(&t->start[i]));
+        COMMS_HIP_TRY(hipEventCreate(&t->stop[i]));
+    }
+    *out = t;
+    return COMMS_OK;
+}
+comms_status_t comms_timer_reset(comms_timer_t* t) {
+    COMMS_ARG(t != nullptr, "timer is NULL");
+    t->next = 0;
+    return COMMS_OK;
+}
+comms_status_t comms_timer_read(comms_timer_t* t, float* ms, size_t cap, size_t* out_count) {
+    COMMS_ARG(t && out_count && (ms || !cap), "NULL argument");
+    COMMS_TRY(use_device(t->device));
+    const size_t have = t->next < t->n ? t->next : t->n;
+    const size_t first = t->next - have;  // oldest launch still held
+    size_t w = 0;
+    for (size_t i = 0; i < have && w < cap; ++i, ++w) {
+        const size_t slot = (first + i) % t->n;
+        COMMS_HIP_TRY(hipEventSynchronize(t->stop[slot]));
+        COMMS_HIP_TRY(hipEventElapsedTime(&ms[w], t->start[slot], t->stop[slot]));
+    }
+    *out_count = w;
+    return COMMS_OK;
+}
+comms_status_t comms_timer_destroy(comms_timer_t* t) {
+    if (!t) return COMMS_OK;
+    (void)use_device(t->device);
+    for (size_t i = 0; i < t->n; ++i) {
+        (void)hipEventDestroy(t->start[i]);
+        (void)hipEventDestroy(t->stop[i]);
+    }
+    delete[] t->start;
+    delete[] t->stop;
+    delete t;
+    return COMMS_OK;
+}
+
+comms_status_t comms_synth_iq_dev(comms_c32* d_out, size_t n, uint64_t first_index,
+                                  uint64_t seed, int32_t device, void* stream) {
+    COMMS_ARG(d_out || !n, "d_out is NULL");
+    COMMS_TRY(use_device(device));
+    if (!n) return COMMS_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 8 * kNumCU) blocks = 8 * kNumCU;
+    synth_iq_kernel<<<dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                      reinterpret_cast<hipStream_t>(stream)>>>(reinterpret_cast<float2*>(d_out),
+                                                               n, first_index, seed);
+    return launch_ok("synth_iq_kernel");
+}
+void comms_synth_iq_host(comms_c32* out, size_t n, uint64_t first_index, uint64_t seed) {
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t g = first_index + i;
+        out[i].re = unit_pm1(splitmix(seed, 2 * g));
+        out[i].im = unit_pm1(splitmix(seed, 2 * g + 1));
+    }
+}
+
+}  // extern "C"

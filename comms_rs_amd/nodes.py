@@ -1,0 +1,404 @@
+"""Node classes over the C ABI, named and parameterised like the reference's.
+
+Every class has
+  run(x)                  host numpy in -> host numpy out (H2D + kernel + D2H)
+  run_dev(in_ptr, n, out_ptr, stream=0)
+                          raw device pointers (ints), asynchronous on `stream`
+                          (a hipStream_t as int; 0 = the handle's own stream).
+torch tensors are not part of this API: callers pass tensor.data_ptr().
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+_c64 = np.dtype(np.complex64)
+
+
+def _as_c64(a):
+    a = np.ascontiguousarray(a, dtype=np.complex64)
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    n = C.c_int32(0)
+    st = lib().comms_device_count(C.byref(n))
+    return n.value if st == 0 else 0
+
+
+class _Handle:
+    _destroy = None
+
+    def __init__(self):
+        self._h = C.c_void_p()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            getattr(lib(), self._destroy)(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------ device buffers
+class DeviceBuf:
+    """Ref-counted device allocation (comms_buf_*): the device-resident message type."""
+
+    def __init__(self, nbytes, device=0, _h=None):
+        if _h is not None:
+            self._h = _h
+        else:
+            self._h = C.c_void_p()
+            check(lib().comms_buf_alloc(nbytes, device, C.byref(self._h)))
+
+    @property
+    def ptr(self):
+        return lib().comms_buf_ptr(self._h) or 0
+
+    @property
+    def nbytes(self):
+        return lib().comms_buf_size(self._h)
+
+    def clone(self):
+        """Rust `Clone`: bump the refcount, share the allocation."""
+        check(lib().comms_buf_retain(self._h))
+        return DeviceBuf(0, _h=self._h)
+
+    def upload(self, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        check(lib().comms_buf_upload(self._h, offset, _ptr(arr), arr.nbytes))
+        return self
+
+    def download(self, dtype, count, offset=0):
+        out = np.empty(count, dtype)
+        check(lib().comms_buf_download(self._h, offset, _ptr(out), out.nbytes))
+        return out
+
+    def release(self):
+        if self._h:
+            check(lib().comms_buf_release(self._h))
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------ FIR
+class BatchFirNode(_Handle):
+    """BatchFirNode::new(taps, state) / run (fir_node.rs:193-220)."""
+    _destroy = "comms_fir_destroy"
+
+    def __init__(self, taps, state=None, device=0):
+        super().__init__()
+        taps = _as_c64(taps)
+        if state is None:
+            check(lib().comms_fir_create(_ptr(taps), taps.size, None, 0, device, C.byref(self._h)))
+        else:
+            state = _as_c64(state)
+            check(lib().comms_fir_create(_ptr(taps), taps.size, _ptr(state), state.size, device, C.byref(self._h)))
+
+    def set_algo(self, algo):
+        check(lib().comms_fir_set_algo(self._h, algo))
+        return self
+
+    def algo_for(self, n):
+        a = C.c_int32()
+        check(lib().comms_fir_get_algo(self._h, n, C.byref(a)))
+        return a.value
+
+    def run(self, x):
+        x = _as_c64(x)
+        out = np.empty_like(x)
+        check(lib().comms_fir_run(self._h, _ptr(x), x.size, _ptr(out)))
+        return out
+
+    def run_dev(self, in_ptr, n, out_ptr, stream=0):
+        check(lib().comms_fir_run_dev(self._h, in_ptr, n, out_ptr, stream))
+
+    def state(self, n_state):
+        st = np.empty(n_state, np.complex64)
+        check(lib().comms_fir_get_state(self._h, _ptr(st), n_state))
+        return st
+
+    def set_state(self, state):
+        state = _as_c64(state)
+        check(lib().comms_fir_set_state(self._h, _ptr(state), state.size))
+
+
+class FirNode(BatchFirNode):
+    """FirNode::new(taps, state) / run(&Complex<T>) (fir_node.rs:89-113): one sample per call."""
+
+    def run(self, x):
+        return BatchFirNode.run(self, np.array([x], np.complex64))[0]
+
+
+class PulseNode(_Handle):
+    """PulseNode::new(taps, sam_per_sym) / run (pulse.rs:71-92)."""
+    _destroy = "comms_pulse_destroy"
+
+    def __init__(self, taps, sam_per_sym, device=0):
+        super().__init__()
+        taps = _as_c64(taps)
+        self.sam_per_sym = int(sam_per_sym)
+        check(lib().comms_pulse_create(_ptr(taps), taps.size, self.sam_per_sym, device, C.byref(self._h)))
+
+    def run(self, sym):
+        """One symbol (scalar) -> sam_per_sym samples, or a batch of symbols."""
+        scalar = np.isscalar(sym) or np.ndim(sym) == 0
+        s = _as_c64(np.atleast_1d(sym))
+        out = np.empty(s.size * self.sam_per_sym, np.complex64)
+        check(lib().comms_pulse_run(self._h, _ptr(s), s.size, _ptr(out)))
+        return out if not scalar else out
+
+    def run_dev(self, sym_ptr, n_sym, out_ptr, stream=0):
+        check(lib().comms_pulse_run_dev(self._h, sym_ptr, n_sym, out_ptr, stream))
+
+
+# ------------------------------------------------------------------ mixer
+class MixerNode(_Handle):
+    """MixerNode::new(dphase, phase) (mixer.rs:128-141); run() mixes a slice."""
+    _destroy = "comms_mixer_destroy"
+
+    def __init__(self, dphase, phase=None, device=0):
+        super().__init__()
+        check(lib().comms_mixer_create(float(dphase), 0.0 if phase is None else float(phase), device, C.byref(self._h)))
+
+    def run(self, x):
+        scalar = np.ndim(x) == 0
+        a = _as_c64(np.atleast_1d(x))
+        out = np.empty_like(a)
+        check(lib().comms_mixer_run(self._h, _ptr(a), a.size, _ptr(out)))
+        return out[0] if scalar else out
+
+    def run_dev(self, in_ptr, n, out_ptr, stream=0):
+        check(lib().comms_mixer_run_dev(self._h, in_ptr, n, out_ptr, stream))
+
+    @property
+    def phase(self):
+        p = C.c_double()
+        check(lib().comms_mixer_get_phase(self._h, C.byref(p)))
+        return p.value
+
+
+# ------------------------------------------------------------------ resampling
+class DecimateNode:
+    """DecimateNode::new(dec_rate) / decimate (resample_node.rs:23, :53-65)."""
+
+    def __init__(self, dec_rate, device=0):
+        self.dec_rate, self.device = int(dec_rate), device
+
+    def out_len(self, n):
+        m = C.c_size_t()
+        check(lib().comms_decimate_out_len(n, self.dec_rate, C.byref(m)))
+        return m.value
+
+    def run(self, x):
+        x = np.ascontiguousarray(x)
+        elem = x.dtype.itemsize * int(np.prod(x.shape[1:], dtype=np.int64))
+        out = np.empty((self.out_len(x.shape[0]),) + x.shape[1:], x.dtype)
+        m = C.c_size_t()
+        check(lib().comms_decimate_run(_ptr(x), x.shape[0], elem, self.dec_rate, _ptr(out), C.byref(m), self.device))
+        assert m.value == out.shape[0]
+        return out
+
+    decimate = run
+
+    def run_dev(self, in_ptr, n, elem, out_ptr, stream=0):
+        m = C.c_size_t()
+        check(lib().comms_decimate_run_dev(in_ptr, n, elem, self.dec_rate, out_ptr, C.byref(m), self.device, stream))
+        return m.value
+
+
+class UpsampleNode:
+    """UpsampleNode::new(ups_rate) / upsample (resample_node.rs:87, :120-131)."""
+
+    def __init__(self, ups_rate, device=0):
+        self.ups_rate, self.device = int(ups_rate), device
+
+    def out_len(self, n):
+        m = C.c_size_t()
+        check(lib().comms_upsample_out_len(n, self.ups_rate, C.byref(m)))
+        return m.value
+
+    def run(self, x):
+        x = np.ascontiguousarray(x)
+        elem = x.dtype.itemsize * int(np.prod(x.shape[1:], dtype=np.int64))
+        out = np.empty((self.out_len(x.shape[0]),) + x.shape[1:], x.dtype)
+        m = C.c_size_t()
+        check(lib().comms_upsample_run(_ptr(x), x.shape[0], elem, self.ups_rate, _ptr(out), C.byref(m), self.device))
+        assert m.value == out.shape[0]
+        return out
+
+    upsample = run
+
+    def run_dev(self, in_ptr, n, elem, out_ptr, stream=0):
+        m = C.c_size_t()
+        check(lib().comms_upsample_run_dev(in_ptr, n, elem, self.ups_rate, out_ptr, C.byref(m), self.device, stream))
+        return m.value
+
+
+# ------------------------------------------------------------------ FM demod
+class FMDemodNode(_Handle):
+    """FMDemodNode::new() / run (analog_node.rs:43-51)."""
+    _destroy = "comms_fmdemod_destroy"
+
+    def __init__(self, device=0):
+        super().__init__()
+        check(lib().comms_fmdemod_create(device, C.byref(self._h)))
+
+    def run(self, x):
+        x = _as_c64(x)
+        out = np.empty(x.size, np.float32)
+        check(lib().comms_fmdemod_run(self._h, _ptr(x), x.size, _ptr(out)))
+        return out
+
+    def run_dev(self, in_ptr, n, out_ptr, stream=0):
+        check(lib().comms_fmdemod_run_dev(self._h, in_ptr, n, out_ptr, stream))
+
+
+# ------------------------------------------------------------------ FFT
+class FFTBatchNode(_Handle):
+    """FFTBatchNode::new(fft_size, ifft) / run (fft_node.rs:65-83)."""
+    _destroy = "comms_fft_destroy"
+
+    def __init__(self, fft_size, ifft, device=0):
+        super().__init__()
+        self.fft_size = int(fft_size)
+        check(lib().comms_fft_create(self.fft_size, 1 if ifft else 0, device, C.byref(self._h)))
+
+    def run(self, x):
+        x = _as_c64(x)
+        out = np.empty_like(x)
+        check(lib().comms_fft_run(self._h, _ptr(x), x.size, _ptr(out)))
+        return out
+
+    def run_dev(self, in_ptr, n, out_ptr, stream=0):
+        check(lib().comms_fft_run_dev(self._h, in_ptr, n, out_ptr, stream))
+
+
+class FFTSampleNode(FFTBatchNode):
+    """FFTSampleNode::new(fft_size, ifft) / run (fft_node.rs:142-167), #[aggregate]:
+    push one sample; returns None until fft_size samples arrived, then the FFT."""
+
+    def __init__(self, fft_size, ifft, device=0):
+        super().__init__(fft_size, ifft, device)
+        self._samples = []
+
+    def run(self, sample):
+        self._samples.append(np.complex64(sample))
+        if len(self._samples) == self.fft_size:
+            res = FFTBatchNode.run(self, np.array(self._samples, np.complex64))
+            self._samples = []
+            return res
+        return None
+
+
+# ------------------------------------------------------------------ fused chain
+class ChainNode(_Handle):
+    """mixer -> FIR -> decimate [-> FM demod] (additional node, comms_chain_*)."""
+    _destroy = "comms_chain_destroy"
+
+    def __init__(self, dphase, phase, taps, rate, fm_demod, device=0):
+        super().__init__()
+        taps = _as_c64(taps)
+        self.rate, self.fm_demod = int(rate), bool(fm_demod)
+        check(lib().comms_chain_create(float(dphase), float(phase), _ptr(taps), taps.size, self.rate,
+                                       1 if fm_demod else 0, device, C.byref(self._h)))
+
+    def run(self, x):
+        x = _as_c64(x)
+        out = np.empty(x.size // self.rate, np.float32 if self.fm_demod else np.complex64)
+        check(lib().comms_chain_run(self._h, _ptr(x), x.size, _ptr(out)))
+        return out
+
+    def run_dev(self, in_ptr, n, out_ptr, stream=0):
+        check(lib().comms_chain_run_dev(self._h, in_ptr, n, out_ptr, stream))
+
+
+# ------------------------------------------------------------------ tap design
+def _taps(fn, n_taps, *args):
+    out = np.empty(int(n_taps), np.complex64)
+    check(fn(int(n_taps), *args, _ptr(out)))
+    return out
+
+
+def rrc_taps(n_taps, sam_per_sym, beta):
+    """util/math.rs:221-280; raises CommsError(code 1) for beta outside [0,1]."""
+    return _taps(lib().comms_rrc_taps, n_taps, float(sam_per_sym), float(beta))
+
+
+def rc_taps(n_taps, sam_per_sym, beta):
+    return _taps(lib().comms_rc_taps, n_taps, float(sam_per_sym), float(beta))
+
+
+def gaussian_taps(n_taps, sam_per_sym, alpha):
+    return _taps(lib().comms_gaussian_taps, n_taps, float(sam_per_sym), float(alpha))
+
+
+def rect_taps(n_taps):
+    return _taps(lib().comms_rect_taps, n_taps)
+
+
+# ------------------------------------------------------------------ synthetic IQ
+def synth_iq(n, first_index=0, seed=0xC0FFEE):
+    out = np.empty(int(n), np.complex64)
+    lib().comms_synth_iq_host(_ptr(out), out.size, first_index, seed)
+    return out
+
+
+def synth_iq_dev(out_ptr, n, first_index=0, seed=0xC0FFEE, device=0, stream=0):
+    check(lib().comms_synth_iq_dev(out_ptr, n, first_index, seed, device, stream))
+
+
+# ------------------------------------------------------------------ kernel timer
+class KernelTimer:
+    """comms_timer_*: hipEvent pairs recorded around a node's dominant kernel."""
+
+    def __init__(self, n_pairs, device=0):
+        self._h = C.c_void_p()
+        self.n = int(n_pairs)
+        check(lib().comms_timer_create(self.n, device, C.byref(self._h)))
+
+    def attach(self, node):
+        name = {"comms_fir_destroy": "comms_fir_set_timer", "comms_mixer_destroy": "comms_mixer_set_timer",
+                "comms_fmdemod_destroy": "comms_fmdemod_set_timer", "comms_fft_destroy": "comms_fft_set_timer",
+                "comms_chain_destroy": "comms_chain_set_timer"}[node._destroy]
+        check(getattr(lib(), name)(node._h, self._h))
+        self._node, self._setter = node, name
+        return self
+
+    def reset(self):
+        check(lib().comms_timer_reset(self._h))
+
+    def read_ms(self):
+        out = np.zeros(self.n, np.float32)
+        m = C.c_size_t()
+        check(lib().comms_timer_read(self._h, _ptr(out), self.n, C.byref(m)))
+        return out[:m.value].copy()
+
+    def close(self):
+        if self._h:
+            node = getattr(self, "_node", None)
+            if node is not None and node._h:
+                getattr(lib(), self._setter)(node._h, None)
+            lib().comms_timer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
