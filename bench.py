@@ -42,7 +42,7 @@ def pmc_traffic():
     try:
         with open(path) as f:
             d = json.load(f)
-        if d.get("kernel") == "fir_os4096_kernel" and d.get("n_samples") == N_SAMPLES:
+        if d.get("kernel") == "fir_os1024_kernel" and d.get("n_samples") == N_SAMPLES:
             return d.get("hbm_bytes_per_launch")
     except Exception:
         pass
@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--algo", choices=["auto", "direct", "os"], default="auto")
+    ap.add_argument("--algo", choices=["auto", "direct", "os1024", "os4096"], default="auto")
     args = ap.parse_args()
 
     import torch
@@ -115,7 +115,7 @@ def main():
 
     fir = c.BatchFirNode(taps, device=local_rank)
     if args.algo != "auto":
-        fir.set_algo(c.FIR_DIRECT if args.algo == "direct" else c.FIR_OVERLAP_SAVE)
+        fir.set_algo({"direct": c.FIR_DIRECT, "os1024": c.FIR_OS1024, "os4096": c.FIR_OS4096}[args.algo])
     mixer = c.MixerNode(MIX_DPHASE, device=local_rank)
     dec = c.DecimateNode(DEC_RATE, device=local_rank)
 
@@ -174,7 +174,8 @@ def main():
     kms = timer.read_ms()
     timer.close()
     kernel_ms = float(np.mean(kms)) if kms.size else float("nan")
-    algo = {c.FIR_DIRECT: "fir_direct_kernel", c.FIR_OVERLAP_SAVE: "fir_os4096_kernel"}[fir.algo_for(n)]
+    algo = {c.FIR_DIRECT: "fir_direct_kernel", c.FIR_OS1024: "fir_os1024_kernel",
+            c.FIR_OS4096: "fir_os4096_kernel"}[fir.algo_for(n)]
 
     if rank == 0:
         total = float(world) * n * args.steps

@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcomms_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 COMMS_OK, COMMS_ERR_ARG, COMMS_ERR_DEVICE = 0, 1, 2
-FIR_AUTO, FIR_DIRECT, FIR_OVERLAP_SAVE = 0, 1, 2
+FIR_AUTO, FIR_DIRECT, FIR_OVERLAP_SAVE, FIR_OS1024, FIR_OS4096 = 0, 1, 2, 3, 4
+STREAM_HANDLE = C.c_void_p(-1).value  # COMMS_STREAM_HANDLE: the handle's own stream
 
 
 def build(force=False):
@@ -120,6 +121,14 @@ def lib():
             raise ImportError(
                 "%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc, gfx950).  comms_rs_amd has no CPU fallback." % LIB_PATH)
+        # PyTorch bundles its own HIP runtime.  When both live in one process the
+        # runtime torch ships must be the one that is loaded first, or torch
+        # cannot see the GPU afterwards -- so let torch load it if torch is here.
+        if os.environ.get("COMMS_NO_TORCH_PRELOAD") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         l = C.CDLL(LIB_PATH)
         missing = [n for n in all_symbols() if not hasattr(l, n)]
         if missing:

@@ -66,7 +66,7 @@ comms_status_t comms_chain_run_dev(comms_chain_t* h, const comms_c32* d_in, size
     COMMS_ARG(n % h->rate == 0, "n (%zu) must be a multiple of the decimation rate %zu", n, h->rate);
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
-    void* s = h->pick(stream);
+    void* s = stream == COMMS_STREAM_HANDLE ? static_cast<void*>(h->stream) : stream;
     const size_t n_dec = n / h->rate;
     COMMS_TRY(h->t1.reserve(n * sizeof(comms_c32)));
     COMMS_TRY(h->t2.reserve(n * sizeof(comms_c32)));
@@ -92,7 +92,7 @@ comms_status_t comms_chain_run(comms_chain_t* h, const comms_c32* in, size_t n, 
     COMMS_TRY(h->in_scratch.reserve(n * sizeof(comms_c32)));
     COMMS_TRY(h->out_scratch.reserve(out_bytes));
     COMMS_HIP_TRY(hipMemcpyAsync(h->in_scratch.p, in, n * sizeof(comms_c32), hipMemcpyHostToDevice, h->stream));
-    COMMS_TRY(comms_chain_run_dev(h, static_cast<comms_c32*>(h->in_scratch.p), n, h->out_scratch.p, nullptr));
+    COMMS_TRY(comms_chain_run_dev(h, static_cast<comms_c32*>(h->in_scratch.p), n, h->out_scratch.p, COMMS_STREAM_HANDLE));
     COMMS_HIP_TRY(hipMemcpyAsync(out, h->out_scratch.p, out_bytes, hipMemcpyDeviceToHost, h->stream));
     COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
     return COMMS_OK;

@@ -118,7 +118,11 @@ struct Handle {
         COMMS_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         return COMMS_OK;
     }
-    hipStream_t pick(void* s) const { return s ? reinterpret_cast<hipStream_t>(s) : stream; }
+    // `stream` arguments of the C ABI are passed through as HIP does: NULL is the
+    // legacy default stream; COMMS_STREAM_HANDLE selects the handle's own stream.
+    hipStream_t pick(void* s) const {
+        return s == COMMS_STREAM_HANDLE ? stream : reinterpret_cast<hipStream_t>(s);
+    }
     void fini() {
         in_scratch.release();
         out_scratch.release();

@@ -595,7 +595,7 @@ comms_status_t comms_fft_run(comms_fft_t* h, const comms_c32* in, size_t n, comm
     COMMS_TRY(h->out_scratch.reserve(n * sizeof(comms_c32)));
     COMMS_HIP_TRY(hipMemcpyAsync(h->in_scratch.p, in, n * sizeof(comms_c32), hipMemcpyHostToDevice, h->stream));
     COMMS_TRY(comms_fft_run_dev(h, static_cast<comms_c32*>(h->in_scratch.p), n,
-                                static_cast<comms_c32*>(h->out_scratch.p), nullptr));
+                                static_cast<comms_c32*>(h->out_scratch.p), COMMS_STREAM_HANDLE));
     COMMS_HIP_TRY(hipMemcpyAsync(out, h->out_scratch.p, n * sizeof(comms_c32), hipMemcpyDeviceToHost, h->stream));
     COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
     return COMMS_OK;

@@ -23,6 +23,7 @@
 // ping-pong) in TIME order (oldest first); the reference's `state` vector is
 // the same data newest-first.
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
@@ -202,7 +203,10 @@ __global__ __launch_bounds__(256, 2) void fir_os4096_kernel(const float2* __rest
     const int V = OSF - H;
     float2 v[16];
 
-    for (size_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    // workgroup b of the persistent grid owns segments [b*nseg/G, (b+1)*nseg/G)
+    const size_t seg_lo = static_cast<size_t>(blockIdx.x) * nseg / gridDim.x;
+    const size_t seg_hi = static_cast<size_t>(blockIdx.x + 1) * nseg / gridDim.x;
+    for (size_t seg = seg_lo; seg < seg_hi; ++seg) {
         const long long base = static_cast<long long>(seg) * V - H;
         // ---- forward stage 1: lane (b,c) = t holds x[256a + t]; DFT over a -> k0
         const bool interior = base >= 0 && static_cast<size_t>(base) + OSF <= n;
@@ -276,6 +280,163 @@ __global__ __launch_bounds__(256, 2) void fir_os4096_kernel(const float2* __rest
     }
 }
 
+
+// ---------------------------------------------------------------- overlap-save, F = 1024, one WAVE per segment
+// For filters of up to 257 taps.  A 64-lane workgroup (one wavefront) owns a run
+// of consecutive 1024-point segments (768 new samples each + 256 of halo that it
+// keeps in VGPRs from the previous segment), so there is no workgroup barrier
+// anywhere: all latency hiding is wave-level multithreading (3-4 waves/SIMD).
+//   n = 64a + 4b + c   (a,b < 16, c < 4)      k = k0 + 16 k1 + 256 k2   (k2 < 4)
+//   fwd:  R16 over a | x W1024^{lane*k0} | LDS | R16 over b | x W64^{c*k1} | LDS | R4 over c
+//   inv:  the mirror image; the 1/1024 is folded into the filter spectrum.
+// LDS per wave: [k0][64+2] rows for the first exchange, four [c] planes of
+// [17*k0 + k1] for the second (strides chosen against bank conflicts), plus the
+// 64-entry W64 table: 9.2 KiB.
+constexpr int WF = 1024;
+constexpr int WV = 768;        // new samples per segment
+constexpr int W_S1 = 66;
+constexpr int W_P = 272;
+constexpr int W_LDS = 4 * W_P;  // 1088 >= 16*66
+
+struct WTables {
+    const float2* tw1;   // [16][64]  W1024^{lane*k0}
+    const float2* tw2;   // [16][4]   W64^{c*k1}, index [k1][c]
+    const float2* hdev;  // [16][64]  H[k0 + 16 k1 + 256 k2]/1024 at [4j + k2][lane], k1 = lane&15, k0 = (lane>>4) + 4j
+};
+
+// Orders one wave's LDS traffic (other lanes' writes -> this lane's reads).  A
+// wavefront's DS instructions execute in issue order, so no s_waitcnt or
+// s_barrier is needed -- only a compiler-level fence.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// WPB waves per workgroup share the read-only tables in LDS (stage-1 twiddles,
+// filter spectrum, W64 table: 16.5 KiB); every wave has a private 8.5 KiB
+// exchange buffer and runs on its own -- no workgroup barrier after set-up.
+template <int WPB, int MINW>
+__global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2* __restrict__ in,
+                                                                    const float2* __restrict__ hist,
+                                                                    int hist_len,
+                                                                    float2* __restrict__ out, size_t n,
+                                                                    size_t nseg, size_t n_runs,
+                                                                    WTables tb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* tw1 = reinterpret_cast<float2*>(smem);  // [16][64]
+    float2* hsp = tw1 + 1024;                       // [16][64]
+    float2* tw2 = hsp + 1024;                       // [16][4]
+    const int l = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float2* lds = tw2 + 64 + wave * W_LDS;          // this wave's exchange buffer
+    const int q0 = l & 15, q1 = l >> 4;  // stage 2: (k0, c) = (q0, q1); stage 3: k1 = q0, k0 = q1 + 4j
+
+    for (int i = threadIdx.x; i < 1024; i += 64 * WPB) {
+        tw1[i] = tb.tw1[i];
+        hsp[i] = tb.hdev[i];
+    }
+    if (threadIdx.x < 64) tw2[threadIdx.x] = tb.tw2[threadIdx.x];
+    __syncthreads();
+
+    // run r of n_runs owns segments [r*nseg/n_runs, (r+1)*nseg/n_runs): equal shares
+    // (+-1) for every wave, so every CU carries the same load
+    const size_t run = static_cast<size_t>(blockIdx.x) * WPB + wave;
+    const size_t seg0 = run < n_runs ? run * nseg / n_runs : nseg;
+    const size_t seg1 = run < n_runs ? (run + 1) * nseg / n_runs : nseg;
+
+    float2 v[16], carry[4];
+    for (size_t seg = seg0; seg < seg1; ++seg) {
+        const size_t nb = seg * WV;  // first new sample of this segment
+        if (seg == seg0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                v[a] = stream_at(in, hist, hist_len, static_cast<long long>(nb) - 256 + 64 * a + l, n);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) v[a] = carry[a];
+        }
+        if (nb + WV <= n) {
+#pragma unroll
+            for (int a = 4; a < 16; ++a) v[a] = in[nb + 64 * (a - 4) + l];
+        } else {
+#pragma unroll
+            for (int a = 4; a < 16; ++a) {
+                const size_t g = nb + 64 * (a - 4) + l;
+                v[a] = g < n ? in[g] : make_float2(0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) carry[a] = v[12 + a];
+
+        // ---- forward
+        radix16<-1>(v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float2 x = v[R16_POS(k)];
+            if (k) x = cmulf(x, tw1[k * 64 + l]);
+            lds[k * W_S1 + l] = x;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int b = 0; b < 16; ++b) v[b] = lds[q0 * W_S1 + 4 * b + q1];
+        wave_lds_sync();
+        radix16<-1>(v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float2 x = v[R16_POS(k)];
+            if (k) x = cmulf(x, tw2[k * 4 + q1]);
+            lds[q1 * W_P + 17 * q0 + k] = x;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[4 * j + c] = lds[c * W_P + 17 * (q1 + 4 * j) + q0];
+        wave_lds_sync();
+        // ---- R4 over c -> k2, spectrum multiply, inverse R4 over k2 -> c
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            radix4<-1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[4 * j + k] = cmulf(v[4 * j + k], hsp[(4 * j + k) * 64 + l]);
+            radix4<1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) lds[c * W_P + 17 * (q1 + 4 * j) + q0] = v[4 * j + c];
+        }
+        wave_lds_sync();
+        // ---- inverse: lane (k0,c) = (q0,q1): conj W64^{c*k1}, R16 over k1 -> b
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float2 x = lds[q1 * W_P + 17 * q0 + k];
+            v[k] = k ? cmulcf(x, tw2[k * 4 + q1]) : x;
+        }
+        wave_lds_sync();
+        radix16<1>(v);
+#pragma unroll
+        for (int b = 0; b < 16; ++b) lds[q0 * W_S1 + 4 * b + q1] = v[R16_POS(b)];
+        wave_lds_sync();
+        // ---- inverse: lane t: conj W1024^{t*k0}, R16 over k0 -> a
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float2 x = lds[k * W_S1 + l];
+            v[k] = k ? cmulcf(x, tw1[k * 64 + l]) : x;
+        }
+        wave_lds_sync();
+        radix16<1>(v);
+        if (nb + WV <= n) {
+#pragma unroll
+            for (int a = 4; a < 16; ++a) out[nb + 64 * (a - 4) + l] = v[R16_POS(a)];
+        } else {
+#pragma unroll
+            for (int a = 4; a < 16; ++a) {
+                const size_t o = nb + 64 * (a - 4) + l;
+                if (o < n) out[o] = v[R16_POS(a)];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- pulse shaping (polyphase)
 // Reference: PulseNode::run (src/pulse.rs:82-92) = zero-stuff by sps, then FIR.
 //   out[m*sps + p] = sum_j taps[p + j*sps] * sym[m - j]
@@ -320,7 +481,12 @@ struct comms_fir : Handle {
     // direct form
     int NP = 0;          // taps padded to a multiple of 8
     float2* d_taps_pad = nullptr;
-    // overlap-save
+    // overlap-save, F = 1024 (wave per segment)
+    bool w_ready = false;
+    float2* d_wtw1 = nullptr;
+    float2* d_wtw2 = nullptr;
+    float2* d_whdev = nullptr;
+    // overlap-save, F = 4096 (workgroup per segment)
     bool os_ready = false;
     int hblk = 0;        // halo = 256*hblk >= n_eff-1
     float2* d_tw1 = nullptr;
@@ -335,6 +501,9 @@ struct comms_fir : Handle {
 static void free_fir(comms_fir* h) {
     (void)use_device(h->device);
     if (h->d_taps_pad) (void)hipFree(h->d_taps_pad);
+    if (h->d_wtw1) (void)hipFree(h->d_wtw1);
+    if (h->d_wtw2) (void)hipFree(h->d_wtw2);
+    if (h->d_whdev) (void)hipFree(h->d_whdev);
     if (h->d_tw1) (void)hipFree(h->d_tw1);
     if (h->d_tw2) (void)hipFree(h->d_tw2);
     if (h->d_hdev) (void)hipFree(h->d_hdev);
@@ -345,6 +514,12 @@ static void free_fir(comms_fir* h) {
 }
 
 static const double kPi = 3.14159265358979323846264338327950288;
+
+// Tuning knobs read once from the environment (scripts/bench_fir.py sweeps them).
+static int tune_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
 
 // Filter spectrum + twiddle tables for the 4096-point overlap-save kernel (f64 on
 // the host, rounded once to f32).
@@ -398,6 +573,69 @@ static comms_status_t fir_prepare_os(comms_fir* h) {
     return COMMS_OK;
 }
 
+
+// Spectrum of the effective taps zero-padded to F points (f64, exact-index twiddles).
+static void tap_spectrum(const comms_fir* h, int F, std::vector<double>& re, std::vector<double>& im) {
+    std::vector<double> cs(F), sn(F);
+    for (int e = 0; e < F; ++e) {
+        double a = -2.0 * kPi * static_cast<double>(e) / F;
+        cs[e] = std::cos(a);
+        sn[e] = std::sin(a);
+    }
+    re.assign(F, 0.0);
+    im.assign(F, 0.0);
+    for (int k = 0; k < F; ++k) {
+        double r = 0, i = 0;
+        int e = 0;
+        for (int j = 0; j < h->n_eff; ++j) {
+            double tr = h->taps[j].re, ti = h->taps[j].im;
+            r += tr * cs[e] - ti * sn[e];
+            i += tr * sn[e] + ti * cs[e];
+            e += k;
+            if (e >= F) e -= F;
+        }
+        re[k] = r;
+        im[k] = i;
+    }
+}
+
+static comms_status_t upload_f2(const std::vector<float2>& v, float2** d) {
+    COMMS_HIP_TRY(hipMalloc(d, v.size() * sizeof(float2)));
+    COMMS_HIP_TRY(hipMemcpy(*d, v.data(), v.size() * sizeof(float2), hipMemcpyHostToDevice));
+    return COMMS_OK;
+}
+
+static float2 unit_root(long long e, int denom) {
+    e %= denom;
+    double a = -2.0 * kPi * static_cast<double>(e) / denom;
+    return make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
+}
+
+static comms_status_t fir_prepare_os1024(comms_fir* h) {
+    if (h->w_ready) return COMMS_OK;
+    COMMS_ARG(h->n_eff <= 257, "the 1024-point overlap-save kernel supports at most 257 taps, got %d", h->n_eff);
+    std::vector<float2> tw1(16 * 64), tw2(16 * 4), hdev(16 * 64);
+    for (int k0 = 0; k0 < 16; ++k0)
+        for (int t = 0; t < 64; ++t) tw1[k0 * 64 + t] = unit_root(static_cast<long long>(t) * k0, 1024);
+    for (int k1 = 0; k1 < 16; ++k1)
+        for (int c = 0; c < 4; ++c) tw2[k1 * 4 + c] = unit_root(c * k1, 64);
+    std::vector<double> re, im;
+    tap_spectrum(h, WF, re, im);
+    for (int j = 0; j < 4; ++j)
+        for (int k2 = 0; k2 < 4; ++k2)
+            for (int l = 0; l < 64; ++l) {
+                const int k1 = l & 15, k0 = (l >> 4) + 4 * j;
+                const int k = k0 + 16 * k1 + 256 * k2;
+                hdev[(4 * j + k2) * 64 + l] =
+                    make_float2(static_cast<float>(re[k] / WF), static_cast<float>(im[k] / WF));
+            }
+    COMMS_TRY(upload_f2(tw1, &h->d_wtw1));
+    COMMS_TRY(upload_f2(tw2, &h->d_wtw2));
+    COMMS_TRY(upload_f2(hdev, &h->d_whdev));
+    h->w_ready = true;
+    return COMMS_OK;
+}
+
 static comms_status_t fir_prepare_direct(comms_fir* h) {
     if (h->d_taps_pad) return COMMS_OK;
     COMMS_ARG(h->n_eff <= DIRECT_MAX_TAPS, "direct-form FIR supports at most %d taps, got %d",
@@ -410,15 +648,24 @@ static comms_status_t fir_prepare_direct(comms_fir* h) {
     return COMMS_OK;
 }
 
-// Tap-count crossover of the two kernels (measured on MI355X).
+// Kernel choice.  COMMS_FIR_OVERLAP_SAVE means "the right overlap-save size":
+// one wave per 1024-point segment up to 257 taps, one workgroup per 4096-point
+// segment above.  Crossovers measured on MI355X.
 static int fir_pick(const comms_fir* h, size_t n) {
-    if (h->algo != COMMS_FIR_AUTO) return h->algo;
-    if (h->n_eff > DIRECT_MAX_TAPS) return COMMS_FIR_OVERLAP_SAVE;
-    const int direct_limit = h->real_taps ? 48 : 24;
-    if (h->n_eff <= direct_limit) return COMMS_FIR_DIRECT;
-    // a single short call does not amortise a 4096-point segment
-    if (n * static_cast<size_t>(h->n_eff) < (1u << 18)) return COMMS_FIR_DIRECT;
-    return COMMS_FIR_OVERLAP_SAVE;
+    int algo = h->algo;
+    if (algo == COMMS_FIR_AUTO) {
+        const int direct_limit = h->real_taps ? 48 : 24;
+        if (h->n_eff > DIRECT_MAX_TAPS)
+            algo = COMMS_FIR_OVERLAP_SAVE;
+        else if (h->n_eff <= direct_limit)
+            algo = COMMS_FIR_DIRECT;
+        else if (n * static_cast<size_t>(h->n_eff) < (1u << 18))
+            algo = COMMS_FIR_DIRECT;  // a short call does not amortise FFT segments
+        else
+            algo = COMMS_FIR_OVERLAP_SAVE;
+    }
+    if (algo == COMMS_FIR_OVERLAP_SAVE) algo = h->n_eff <= 257 ? COMMS_FIR_OS1024 : COMMS_FIR_OS4096;
+    return algo;
 }
 
 static comms_status_t fir_upload_state(comms_fir* h, const comms_c32* state, size_t n_state) {
@@ -474,11 +721,12 @@ comms_status_t comms_fir_create(const comms_c32* taps, size_t n_taps, const comm
 
 comms_status_t comms_fir_set_algo(comms_fir_t* h, int32_t algo) {
     COMMS_ARG(h != nullptr, "handle is NULL");
-    COMMS_ARG(algo == COMMS_FIR_AUTO || algo == COMMS_FIR_DIRECT || algo == COMMS_FIR_OVERLAP_SAVE,
-              "unknown algo %d", algo);
+    COMMS_ARG(algo >= COMMS_FIR_AUTO && algo <= COMMS_FIR_OS4096, "unknown algo %d", algo);
+    COMMS_ARG(algo != COMMS_FIR_OS1024 || h->n_eff <= 257,
+              "the 1024-point overlap-save kernel supports at most 257 taps");
     COMMS_ARG(algo != COMMS_FIR_DIRECT || h->n_eff <= DIRECT_MAX_TAPS,
               "direct-form FIR supports at most %d taps", DIRECT_MAX_TAPS);
-    COMMS_ARG(algo != COMMS_FIR_OVERLAP_SAVE || h->n_eff <= 3841,
+    COMMS_ARG((algo != COMMS_FIR_OVERLAP_SAVE && algo != COMMS_FIR_OS4096) || h->n_eff <= 3841,
               "overlap-save (F=4096) supports at most 3841 taps");
     h->algo = algo;
     return COMMS_OK;
@@ -517,14 +765,45 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
             fir_direct_kernel<false><<<dim3(blocks), dim3(256), lds, s>>>(in, hist, h->n_eff, h->d_taps_pad, h->NP, o, n, vec4);
         h->toc(s);
         COMMS_TRY(launch_ok("fir_direct_kernel"));
+    } else if (algo == COMMS_FIR_OS1024) {
+        COMMS_TRY(fir_prepare_os1024(h));
+        const size_t nseg = (n + WV - 1) / WV;
+        // one wave per run of consecutive segments
+        static const int wpb = tune_int("COMMS_OS1024_WPB", 4);  // waves per workgroup: 4 or 16
+        static const int min_run = tune_int("COMMS_OS1024_MINRUN", 4);
+        // persistent: every wave slot of the chip gets one run (fewer for short inputs,
+        // where a run is at least min_run segments to amortise its halo load)
+        const size_t waves_per_cu = wpb == 16 ? 16 : 12;
+        size_t runs = waves_per_cu * kNumCU;
+        if (runs * min_run > nseg) runs = (nseg + min_run - 1) / min_run;
+        const size_t per = 0;
+        (void)per;
+        WTables tb{h->d_wtw1, h->d_wtw2, h->d_whdev};
+        h->tic(s);
+        if (wpb == 16) {
+            const size_t lds = (2112 + 16 * W_LDS) * sizeof(float2);
+            static bool attr16 = false;
+            if (!attr16) {
+                COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os1024_kernel<16, 4>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+                attr16 = true;
+            }
+            fir_os1024_kernel<16, 4><<<dim3(static_cast<unsigned>((runs + 15) / 16)), dim3(1024), lds, s>>>(
+                in, hist, h->n_eff, o, n, nseg, runs, tb);
+        } else {
+            const size_t lds = (2112 + 4 * W_LDS) * sizeof(float2);
+            fir_os1024_kernel<4, 3><<<dim3(static_cast<unsigned>((runs + 3) / 4)), dim3(256), lds, s>>>(
+                in, hist, h->n_eff, o, n, nseg, runs, tb);
+        }
+        h->toc(s);
+        COMMS_TRY(launch_ok("fir_os1024_kernel"));
     } else {
         COMMS_TRY(fir_prepare_os(h));
         const size_t V = OSF - 256 * static_cast<size_t>(h->hblk);
         const size_t nseg = (n + V - 1) / V;
         // persistent grid: 2 workgroups per CU, segments split evenly
         const size_t slots = 2 * kNumCU;
-        const size_t per = (nseg + slots - 1) / slots;
-        const unsigned blocks = static_cast<unsigned>((nseg + per - 1) / per);
+        const unsigned blocks = static_cast<unsigned>(nseg < slots ? nseg : slots);
         OsTables tb{h->d_tw1, h->d_tw2, h->d_hdev};
         h->tic(s);
         fir_os4096_kernel<<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb);
@@ -548,7 +827,7 @@ comms_status_t comms_fir_run(comms_fir_t* h, const comms_c32* in, size_t n, comm
     COMMS_TRY(h->out_scratch.reserve(n * sizeof(comms_c32)));
     COMMS_HIP_TRY(hipMemcpyAsync(h->in_scratch.p, in, n * sizeof(comms_c32), hipMemcpyHostToDevice, h->stream));
     COMMS_TRY(comms_fir_run_dev(h, static_cast<comms_c32*>(h->in_scratch.p), n,
-                                static_cast<comms_c32*>(h->out_scratch.p), nullptr));
+                                static_cast<comms_c32*>(h->out_scratch.p), COMMS_STREAM_HANDLE));
     COMMS_HIP_TRY(hipMemcpyAsync(out, h->out_scratch.p, n * sizeof(comms_c32), hipMemcpyDeviceToHost, h->stream));
     COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
     return COMMS_OK;
@@ -678,7 +957,7 @@ comms_status_t comms_pulse_run(comms_pulse_t* h, const comms_c32* sym, size_t n_
     COMMS_TRY(h->out_scratch.reserve(n_out * sizeof(comms_c32)));
     COMMS_HIP_TRY(hipMemcpyAsync(h->in_scratch.p, sym, n_sym * sizeof(comms_c32), hipMemcpyHostToDevice, h->stream));
     COMMS_TRY(comms_pulse_run_dev(h, static_cast<comms_c32*>(h->in_scratch.p), n_sym,
-                                  static_cast<comms_c32*>(h->out_scratch.p), nullptr));
+                                  static_cast<comms_c32*>(h->out_scratch.p), COMMS_STREAM_HANDLE));
     COMMS_HIP_TRY(hipMemcpyAsync(out, h->out_scratch.p, n_out * sizeof(comms_c32), hipMemcpyDeviceToHost, h->stream));
     COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
     return COMMS_OK;

@@ -235,7 +235,7 @@ comms_status_t comms_mixer_run(comms_mixer_t* h, const comms_c32* in, size_t n, 
     COMMS_TRY(h->in_scratch.reserve(n * sizeof(comms_c32)));
     COMMS_HIP_TRY(hipMemcpyAsync(h->in_scratch.p, in, n * sizeof(comms_c32), hipMemcpyHostToDevice, h->stream));
     comms_c32* d = static_cast<comms_c32*>(h->in_scratch.p);
-    COMMS_TRY(comms_mixer_run_dev(h, d, n, d, nullptr));
+    COMMS_TRY(comms_mixer_run_dev(h, d, n, d, COMMS_STREAM_HANDLE));
     COMMS_HIP_TRY(hipMemcpyAsync(out, d, n * sizeof(comms_c32), hipMemcpyDeviceToHost, h->stream));
     COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
     return COMMS_OK;
@@ -434,7 +434,7 @@ comms_status_t comms_fmdemod_run(comms_fmdemod_t* h, const comms_c32* in, size_t
     COMMS_TRY(h->out_scratch.reserve(n * sizeof(float)));
     COMMS_HIP_TRY(hipMemcpyAsync(h->in_scratch.p, in, n * sizeof(comms_c32), hipMemcpyHostToDevice, h->stream));
     COMMS_TRY(comms_fmdemod_run_dev(h, static_cast<comms_c32*>(h->in_scratch.p), n,
-                                    static_cast<float*>(h->out_scratch.p), nullptr));
+                                    static_cast<float*>(h->out_scratch.p), COMMS_STREAM_HANDLE));
     COMMS_HIP_TRY(hipMemcpyAsync(out, h->out_scratch.p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
     return COMMS_OK;

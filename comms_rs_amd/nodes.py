@@ -4,7 +4,8 @@ Every class has
   run(x)                  host numpy in -> host numpy out (H2D + kernel + D2H)
   run_dev(in_ptr, n, out_ptr, stream=0)
                           raw device pointers (ints), asynchronous on `stream`
-                          (a hipStream_t as int; 0 = the handle's own stream).
+                          (a hipStream_t as int; 0 = HIP's legacy default stream,
+                          _lib.STREAM_HANDLE = the handle's own stream).
 torch tensors are not part of this API: callers pass tensor.data_ptr().
 """
 import ctypes as C

@@ -85,20 +85,22 @@ def test_fir_direct_vs_oracle(c, n_taps, real, n):
 
 @pytest.mark.parametrize("n_taps,real", [(2, False), (25, False), (255, True), (255, False), (257, False),
                                          (513, True), (2049, False), (3841, True)])
-@pytest.mark.parametrize("n", [1, 3839, 3840, 3841, 20000])
+@pytest.mark.parametrize("n", [1, 767, 768, 769, 3839, 3840, 3841, 20000])
 def test_fir_overlap_save_vs_oracle(c, n_taps, real, n):
     rng = np.random.default_rng(n_taps * 11 + n)
     taps = rand_c(rng, n_taps) / np.sqrt(n_taps)
     if real:
         taps = taps.real.astype(np.complex64)
     x = rand_c(rng, n)
-    node = c.BatchFirNode(taps).set_algo(c.FIR_OVERLAP_SAVE)
-    got = node.run(x)
     want = oracle.batch_fir(x, taps, oracle.default_state(taps), norotate=True)
-    fir_close(got, want, taps, x)
+    # both segment sizes where the tap count allows (1024-pt wave kernel: <= 257 taps)
+    for algo in ([c.FIR_OS1024, c.FIR_OS4096] if n_taps <= 257 else [c.FIR_OS4096]):
+        node = c.BatchFirNode(taps).set_algo(algo)
+        assert node.algo_for(n) == algo
+        fir_close(node.run(x), want, taps, x)
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 3, 4])
 def test_fir_state_carries_across_calls_and_matches_reference_state(c, algo):
     rng = np.random.default_rng(5)
     taps = rand_c(rng, 255)
@@ -129,7 +131,8 @@ def test_fir_short_and_long_user_state(c):
 def test_fir_auto_selection_and_errors(c):
     taps = np.ones(255, np.complex64)
     node = c.BatchFirNode(taps)
-    assert node.algo_for(1 << 24) == c.FIR_OVERLAP_SAVE
+    assert node.algo_for(1 << 24) == c.FIR_OS1024
+    assert c.BatchFirNode(np.ones(258, np.complex64)).algo_for(1 << 24) == c.FIR_OS4096
     assert node.algo_for(4) == c.FIR_DIRECT
     assert c.BatchFirNode(np.ones(8, np.complex64)).algo_for(1 << 24) == c.FIR_DIRECT
     assert node.run(np.zeros(0, np.complex64)).size == 0
@@ -157,11 +160,15 @@ def test_fir_full_size_config2_properties(c):
     y_os = torch.empty_like(x)
     y_di = torch.empty_like(x)
     s = torch.cuda.current_stream().cuda_stream
+    y_o4 = torch.empty_like(x)
     c.BatchFirNode(taps).set_algo(c.FIR_OVERLAP_SAVE).run_dev(x.data_ptr(), n, y_os.data_ptr(), s)
+    c.BatchFirNode(taps).set_algo(c.FIR_OS4096).run_dev(x.data_ptr(), n, y_o4.data_ptr(), s)
     c.BatchFirNode(taps).set_algo(c.FIR_DIRECT).run_dev(x.data_ptr(), n, y_di.data_ptr(), s)
     torch.cuda.synchronize()
     scale = float(np.sum(np.abs(taps)))
     assert float((y_os - y_di).abs().max()) <= TOL * scale
+    assert float((y_o4 - y_di).abs().max()) <= TOL * scale
+    del y_o4
     rng = np.random.default_rng(7)
     for a in [0, 3840 - 100, 1 << 20, n - 5000] + list(rng.integers(0, n - 5000, 4)):
         a = int(a)
