@@ -21,12 +21,12 @@ timeout -k 10 300 python __graft_entry__.py smoke 2>&1 | tail -n 3 | tee -a $OUT
 rc=${PIPESTATUS[0]}
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "smoke timed out: stopping"; exit 1; fi
 echo "== bench" | tee -a $OUT/summary.txt
-timeout -k 10 600 python bench.py --steps 30 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+timeout -k 10 600 python bench.py --steps 200 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err
 rc=$?
 tail -n 5 $OUT/bench.err | tee -a $OUT/summary.txt
 cat $OUT/bench.json | tee -a $OUT/summary.txt
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "bench timed out: stopping"; exit 1; fi
 echo "== rocprofv3 kernel trace of the bench" | tee -a $OUT/summary.txt
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err
 tail -n 3 $OUT/prof.err | tee -a $OUT/summary.txt
 find $OUT/prof -name '*kernel_stats.csv' | head -1 | xargs -r head -n 12 | tee -a $OUT/summary.txt

@@ -467,9 +467,13 @@ def test_config3_mixer_fir_decimate_fm_chain(c, fm):
             w, g = ofm.demod(w), gfm.run(g)
         got = node.run(x[a:b])
         if fm:
-            # the LPF output has |y| ~ 1 here, so the angle error follows the FIR error
-            assert np.max(circ(g.astype(np.float64) - w)) <= 5e-5
-            assert np.max(circ(got.astype(np.float64) - w)) <= 5e-5
+            # angle error = FIR error / |y|: compare where the LPF output has settled
+            # (|y| ~ 1); the first taps/8 outputs of the stream are the filter's
+            # start-up transient with |y| ~ 0, where the angle is ill-conditioned
+            settled = slice(32, None) if a == 0 else slice(None)
+            assert np.max(circ(g.astype(np.float64) - w)[settled]) <= 5e-5
+            assert np.max(circ(got.astype(np.float64) - w)[settled]) <= 5e-5
+            assert np.max(circ(g.astype(np.float64) - got)) == 0.0  # chain node == the four nodes
         else:
             fir_close(g, w, taps, x)
             fir_close(got, w, taps, x)
