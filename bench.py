@@ -121,20 +121,15 @@ def main():
 
     # ---- one-off halo hand-over to the right-hand neighbour (RCCL send/recv)
     if world > 1:
-        tail = x[n - N_TAPS:].clone()
-        halo = torch.zeros(N_TAPS, dtype=torch.complex64, device=dev)
-        ops = []
-        if rank + 1 < world:
-            ops.append(dist.P2POp(dist.isend, torch.view_as_real(tail), rank + 1))
-        if rank > 0:
-            ops.append(dist.P2POp(dist.irecv, torch.view_as_real(halo), rank - 1))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+        from comms_rs_amd.sharding import halo_exchange, state_from_halo
+
+        tail = torch.view_as_real(x[n - N_TAPS:].clone())
+        halo = halo_exchange(dist, tail, rank, world)
         torch.cuda.synchronize()
         if rank > 0:
-            h = halo.cpu().numpy()
+            h = torch.view_as_complex(halo).cpu().numpy()
             assert np.array_equal(h, c.synth_iq(N_TAPS, rank * n - N_TAPS, SEED)), "halo mismatch"
-            fir.set_state(h[::-1].copy())  # reference layout: newest first
+            fir.set_state(state_from_halo(h))
 
     def step():
         fir.run_dev(x.data_ptr(), n, y.data_ptr(), stream)

@@ -42,6 +42,18 @@ __global__ void fir_hist_update_kernel(const float2* __restrict__ old_hist,
     new_hist[j] = p < static_cast<size_t>(HL) ? old_hist[p] : in[p - HL];
 }
 
+// Folded into every FIR kernel (workgroup 0): new_hist = last HL samples of
+// concat(old_hist[HL], in[n]) -- the reference's `state` after the batch.
+__device__ __forceinline__ void hist_advance(const float2* __restrict__ old_hist,
+                                             const float2* __restrict__ in, size_t n,
+                                             float2* __restrict__ new_hist, int HL) {
+    if (blockIdx.x != 0) return;
+    for (int j = threadIdx.x; j < HL; j += blockDim.x) {
+        const size_t p = n + static_cast<size_t>(j);
+        new_hist[j] = p < static_cast<size_t>(HL) ? old_hist[p] : in[p - HL];
+    }
+}
+
 // Sample g of the logical stream [history | input | zeros]
 __device__ __forceinline__ float2 stream_at(const float2* __restrict__ in,
                                             const float2* __restrict__ hist, int hist_len,
@@ -62,9 +74,11 @@ __global__ __launch_bounds__(256) void fir_direct_kernel(const float2* __restric
                                                          int hist_len,
                                                          const float2* __restrict__ taps_pad,
                                                          int NP, float2* __restrict__ out,
-                                                         size_t n, int out_vec4) {
+                                                         size_t n, int out_vec4,
+                                                         float2* __restrict__ new_hist) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x;
+    hist_advance(hist, in, n, new_hist, hist_len);
     const int nrows = (DTILE + NP) / 8;
     float2* xt = reinterpret_cast<float2*>(smem);
     float2* tp = xt + nrows * DROW;  // taps (complex) or, if REAL_TAPS, NP floats
@@ -183,9 +197,10 @@ __global__ __launch_bounds__(256, 2) void fir_os4096_kernel(const float2* __rest
                                                             const float2* __restrict__ hist,
                                                             int hist_len, float2* __restrict__ out,
                                                             size_t n, int hblk, size_t nseg,
-                                                            OsTables tb) {
+                                                            OsTables tb, float2* __restrict__ new_hist) {
     __shared__ __attribute__((aligned(16))) float2 lds[OS_LDS + 256];
     const int t = threadIdx.x;
+    hist_advance(hist, in, n, new_hist, hist_len);
     const int hi = t >> 4, lo = t & 15;
 
     // persistent per-lane constants: stage-1 twiddles and the filter spectrum in
@@ -322,8 +337,10 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
                                                                     int hist_len,
                                                                     float2* __restrict__ out, size_t n,
                                                                     size_t nseg, size_t n_runs,
-                                                                    WTables tb) {
+                                                                    WTables tb,
+                                                                    float2* __restrict__ new_hist) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    hist_advance(hist, in, n, new_hist, hist_len);
     float2* tw1 = reinterpret_cast<float2*>(smem);  // [16][64]
     float2* hsp = tw1 + 1024;                       // [16][64]
     float2* tw2 = hsp + 1024;                       // [16][4]
@@ -751,6 +768,7 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
     const float2* in = reinterpret_cast<const float2*>(d_in);
     float2* o = reinterpret_cast<float2*>(d_out);
     const float2* hist = h->d_hist[h->cur];
+    float2* nh = h->d_hist[h->cur ^ 1];  // the kernel's workgroup 0 advances the history into it
     const int algo = fir_pick(h, n);
     if (algo == COMMS_FIR_DIRECT) {
         COMMS_TRY(fir_prepare_direct(h));
@@ -760,9 +778,9 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
         const int vec4 = (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
         h->tic(s);
         if (h->real_taps)
-            fir_direct_kernel<true><<<dim3(blocks), dim3(256), lds, s>>>(in, hist, h->n_eff, h->d_taps_pad, h->NP, o, n, vec4);
+            fir_direct_kernel<true><<<dim3(blocks), dim3(256), lds, s>>>(in, hist, h->n_eff, h->d_taps_pad, h->NP, o, n, vec4, nh);
         else
-            fir_direct_kernel<false><<<dim3(blocks), dim3(256), lds, s>>>(in, hist, h->n_eff, h->d_taps_pad, h->NP, o, n, vec4);
+            fir_direct_kernel<false><<<dim3(blocks), dim3(256), lds, s>>>(in, hist, h->n_eff, h->d_taps_pad, h->NP, o, n, vec4, nh);
         h->toc(s);
         COMMS_TRY(launch_ok("fir_direct_kernel"));
     } else if (algo == COMMS_FIR_OS1024) {
@@ -789,11 +807,11 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
                 attr16 = true;
             }
             fir_os1024_kernel<16, 4><<<dim3(static_cast<unsigned>((runs + 15) / 16)), dim3(1024), lds, s>>>(
-                in, hist, h->n_eff, o, n, nseg, runs, tb);
+                in, hist, h->n_eff, o, n, nseg, runs, tb, nh);
         } else {
             const size_t lds = (2112 + 4 * W_LDS) * sizeof(float2);
             fir_os1024_kernel<4, 3><<<dim3(static_cast<unsigned>((runs + 3) / 4)), dim3(256), lds, s>>>(
-                in, hist, h->n_eff, o, n, nseg, runs, tb);
+                in, hist, h->n_eff, o, n, nseg, runs, tb, nh);
         }
         h->toc(s);
         COMMS_TRY(launch_ok("fir_os1024_kernel"));
@@ -806,14 +824,10 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
         const unsigned blocks = static_cast<unsigned>(nseg < slots ? nseg : slots);
         OsTables tb{h->d_tw1, h->d_tw2, h->d_hdev};
         h->tic(s);
-        fir_os4096_kernel<<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb);
+        fir_os4096_kernel<<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh);
         h->toc(s);
         COMMS_TRY(launch_ok("fir_os4096_kernel"));
     }
-    // advance the history ring (time order) into the other buffer
-    float2* nh = h->d_hist[h->cur ^ 1];
-    fir_hist_update_kernel<<<dim3((h->n_eff + 255) / 256), dim3(256), 0, s>>>(hist, in, n, nh, h->n_eff);
-    COMMS_TRY(launch_ok("fir_hist_update_kernel"));
     h->cur ^= 1;
     return COMMS_OK;
 }

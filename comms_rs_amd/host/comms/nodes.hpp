@@ -1,0 +1,456 @@
+// nodes.hpp -- the hot-path DSP nodes of comms-rs, backed by libcomms_hip (MI355X).
+//
+// Same struct names, constructor arguments and public `input` / `output` fields as
+// the reference, so a graph written against comms-rs
+// reads the same here:
+//   FirNode / BatchFirNode::new(taps, state)      src/filter/fir_node.rs:89, :193
+//   FFTBatchNode / FFTSampleNode::new(size, ifft) src/fft/fft_node.rs:65, :142
+//   MixerNode::new(dphase, phase)                 src/mixer.rs:128
+//   PulseNode::new(taps, sam_per_sym)             src/pulse.rs:71
+//   DecimateNode / UpsampleNode::new(rate)        src/util/resample_node.rs:23, :87
+//   FMDemodNode::new()                            src/modulation/analog_node.rs:43
+// Messages are host vectors (std::vector<Complex>), moved through the channels by
+// value as in the reference; every run() goes H2D -> kernel -> D2H through the C
+// ABI.  The *Dev variants at the bottom keep messages device-resident
+// (DeviceBuf<T>, clone = refcount bump) -- what the roofline numbers use.
+//
+// Error convention: comms_status_t 1 -> NodeError::DataError, 2 -> PermanentError.
+// Constructors throw std::runtime_error when a handle cannot be created (the
+// reference panics in the same places); there is no CPU fallback.
+#pragma once
+
+#include <complex>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/comms_hip.h"
+#include "node.hpp"
+
+namespace comms {
+
+using Complex32 = std::complex<float>;
+static_assert(sizeof(Complex32) == sizeof(comms_c32), "Complex<f32> must be interleaved {re, im}");
+
+inline const comms_c32* c32(const Complex32* p) { return reinterpret_cast<const comms_c32*>(p); }
+inline comms_c32* c32(Complex32* p) { return reinterpret_cast<comms_c32*>(p); }
+
+inline void throw_on(comms_status_t st, const char* what) {
+    if (st != COMMS_OK) throw std::runtime_error(std::string(what) + ": " + comms_last_error());
+}
+inline NodeError to_node_error(comms_status_t st) {
+    return st == COMMS_ERR_ARG ? NodeError::DataError : NodeError::PermanentError;
+}
+
+// ---------------------------------------------------------------- device-resident message
+template <class T>
+class DeviceBuf {
+public:
+    DeviceBuf() = default;
+    explicit DeviceBuf(size_t count, int device = 0) : count_(count) {
+        throw_on(comms_buf_alloc(count * sizeof(T), device, &b_), "comms_buf_alloc");
+    }
+    DeviceBuf(const DeviceBuf& o) : b_(o.b_), count_(o.count_) {  // Clone = retain
+        if (b_) comms_buf_retain(b_);
+    }
+    DeviceBuf(DeviceBuf&& o) noexcept : b_(o.b_), count_(o.count_) { o.b_ = nullptr; }
+    DeviceBuf& operator=(DeviceBuf o) noexcept {
+        std::swap(b_, o.b_);
+        std::swap(count_, o.count_);
+        return *this;
+    }
+    ~DeviceBuf() {
+        if (b_) comms_buf_release(b_);
+    }
+    static DeviceBuf from_host(const std::vector<T>& v, int device = 0) {
+        DeviceBuf d(v.size(), device);
+        throw_on(comms_buf_upload(d.b_, 0, v.data(), v.size() * sizeof(T)), "comms_buf_upload");
+        return d;
+    }
+    std::vector<T> to_host() const {
+        std::vector<T> v(count_);
+        throw_on(comms_buf_download(b_, 0, v.data(), count_ * sizeof(T)), "comms_buf_download");
+        return v;
+    }
+    T* ptr() const { return static_cast<T*>(comms_buf_ptr(b_)); }
+    size_t size() const { return count_; }
+    int device() const { return comms_buf_device(b_); }
+
+private:
+    comms_buf_t* b_ = nullptr;
+    size_t count_ = 0;
+};
+
+// ---------------------------------------------------------------- FIR
+class BatchFirNode : public DeriveNode<BatchFirNode> {
+public:
+    NodeReceiver<std::vector<Complex32>> input;
+    NodeSender<std::vector<Complex32>> output;
+
+    BatchFirNode(const std::vector<Complex32>& taps, const std::optional<std::vector<Complex32>>& state = std::nullopt,
+                 int device = 0) {
+        throw_on(comms_fir_create(c32(taps.data()), taps.size(), state ? c32(state->data()) : nullptr,
+                                  state ? state->size() : 0, device, &h_),
+                 "BatchFirNode::new");
+    }
+    BatchFirNode(BatchFirNode&& o) noexcept : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_) { o.h_ = nullptr; }
+    ~BatchFirNode() { comms_fir_destroy(h_); }
+
+    Result<std::vector<Complex32>> run(const std::vector<Complex32>& in) {
+        std::vector<Complex32> out(in.size());
+        comms_status_t st = comms_fir_run(h_, c32(in.data()), in.size(), c32(out.data()));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+    comms_fir_t* handle() const { return h_; }
+
+private:
+    comms_fir_t* h_ = nullptr;
+};
+
+class FirNode : public DeriveNode<FirNode> {
+public:
+    NodeReceiver<Complex32> input;
+    NodeSender<Complex32> output;
+
+    FirNode(const std::vector<Complex32>& taps, const std::optional<std::vector<Complex32>>& state = std::nullopt,
+            int device = 0) {
+        throw_on(comms_fir_create(c32(taps.data()), taps.size(), state ? c32(state->data()) : nullptr,
+                                  state ? state->size() : 0, device, &h_),
+                 "FirNode::new");
+    }
+    FirNode(FirNode&& o) noexcept : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_) { o.h_ = nullptr; }
+    ~FirNode() { comms_fir_destroy(h_); }
+
+    Result<Complex32> run(const Complex32& in) {
+        Complex32 out;
+        comms_status_t st = comms_fir_run(h_, c32(&in), 1, c32(&out));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_fir_t* h_ = nullptr;
+};
+
+// ---------------------------------------------------------------- pulse shaping
+class PulseNode : public DeriveNode<PulseNode> {
+public:
+    NodeReceiver<Complex32> input;
+    NodeSender<std::vector<Complex32>> output;
+
+    PulseNode(const std::vector<Complex32>& taps, size_t sam_per_sym, int device = 0) : sps_(sam_per_sym) {
+        throw_on(comms_pulse_create(c32(taps.data()), taps.size(), sam_per_sym, device, &h_), "PulseNode::new");
+    }
+    PulseNode(PulseNode&& o) noexcept : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), sps_(o.sps_) { o.h_ = nullptr; }
+    ~PulseNode() { comms_pulse_destroy(h_); }
+
+    Result<std::vector<Complex32>> run(const Complex32& sym) {
+        std::vector<Complex32> out(sps_);
+        comms_status_t st = comms_pulse_run(h_, c32(&sym), 1, c32(out.data()));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_pulse_t* h_ = nullptr;
+    size_t sps_;
+};
+
+// ---------------------------------------------------------------- mixer
+class MixerNode : public DeriveNode<MixerNode> {
+public:
+    NodeReceiver<Complex32> input;
+    NodeSender<Complex32> output;
+
+    // NB (dphase, phase): the node's order, not Mixer::new's (mixer.rs:128 vs :43)
+    explicit MixerNode(double dphase, std::optional<double> phase = std::nullopt, int device = 0) {
+        throw_on(comms_mixer_create(dphase, phase.value_or(0.0), device, &h_), "MixerNode::new");
+    }
+    MixerNode(MixerNode&& o) noexcept : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_) { o.h_ = nullptr; }
+    ~MixerNode() { comms_mixer_destroy(h_); }
+
+    Result<Complex32> run(const Complex32& in) {
+        Complex32 out;
+        comms_status_t st = comms_mixer_run(h_, c32(&in), 1, c32(&out));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_mixer_t* h_ = nullptr;
+};
+
+// The reference has no batch mixer node; this one mixes a whole Vec per message.
+class BatchMixerNode : public DeriveNode<BatchMixerNode> {
+public:
+    NodeReceiver<std::vector<Complex32>> input;
+    NodeSender<std::vector<Complex32>> output;
+
+    explicit BatchMixerNode(double dphase, std::optional<double> phase = std::nullopt, int device = 0) {
+        throw_on(comms_mixer_create(dphase, phase.value_or(0.0), device, &h_), "BatchMixerNode::new");
+    }
+    BatchMixerNode(BatchMixerNode&& o) noexcept : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_) { o.h_ = nullptr; }
+    ~BatchMixerNode() { comms_mixer_destroy(h_); }
+
+    Result<std::vector<Complex32>> run(const std::vector<Complex32>& in) {
+        std::vector<Complex32> out(in.size());
+        comms_status_t st = comms_mixer_run(h_, c32(in.data()), in.size(), c32(out.data()));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_mixer_t* h_ = nullptr;
+};
+
+// ---------------------------------------------------------------- decimate / upsample (T: Copy)
+template <class T>
+class DecimateNode : public DeriveNode<DecimateNode<T>> {
+public:
+    NodeReceiver<std::vector<T>> input;
+    NodeSender<std::vector<T>> output;
+    explicit DecimateNode(size_t dec_rate, int device = 0) : rate_(dec_rate), device_(device) {}
+
+    Result<std::vector<T>> run(const std::vector<T>& signal) {
+        std::vector<T> out;
+        comms_status_t st = decimate(signal, out);
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    comms_status_t decimate(const std::vector<T>& data, std::vector<T>& out) const {
+        size_t n_out = 0;
+        comms_decimate_out_len(data.size(), rate_, &n_out);
+        out.resize(n_out);
+        return comms_decimate_run(data.data(), data.size(), sizeof(T), rate_, out.data(), nullptr, device_);
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    size_t rate_;
+    int device_;
+};
+
+template <class T>
+class UpsampleNode : public DeriveNode<UpsampleNode<T>> {
+public:
+    NodeReceiver<std::vector<T>> input;
+    NodeSender<std::vector<T>> output;
+    explicit UpsampleNode(size_t ups_rate, int device = 0) : rate_(ups_rate), device_(device) {}
+
+    Result<std::vector<T>> run(const std::vector<T>& signal) {
+        std::vector<T> out;
+        comms_status_t st = upsample(signal, out);
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    comms_status_t upsample(const std::vector<T>& data, std::vector<T>& out) const {
+        size_t n_out = 0;
+        comms_status_t st = comms_upsample_out_len(data.size(), rate_, &n_out);
+        if (st != COMMS_OK) return st;
+        out.resize(n_out);
+        return comms_upsample_run(data.data(), data.size(), sizeof(T), rate_, out.data(), nullptr, device_);
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    size_t rate_;
+    int device_;
+};
+
+// ---------------------------------------------------------------- FM demod
+class FMDemodNode : public DeriveNode<FMDemodNode> {
+public:
+    NodeReceiver<std::vector<Complex32>> input;
+    NodeSender<std::vector<float>> output;
+
+    explicit FMDemodNode(int device = 0) { throw_on(comms_fmdemod_create(device, &h_), "FMDemodNode::new"); }
+    FMDemodNode(FMDemodNode&& o) noexcept : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_) { o.h_ = nullptr; }
+    ~FMDemodNode() { comms_fmdemod_destroy(h_); }
+
+    Result<std::vector<float>> run(const std::vector<Complex32>& samples) {
+        std::vector<float> out(samples.size());
+        comms_status_t st = comms_fmdemod_run(h_, c32(samples.data()), samples.size(), out.data());
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_fmdemod_t* h_ = nullptr;
+};
+
+// ---------------------------------------------------------------- FFT
+class FFTBatchNode : public DeriveNode<FFTBatchNode> {
+public:
+    NodeReceiver<std::vector<Complex32>> input;
+    NodeSender<std::vector<Complex32>> output;
+
+    FFTBatchNode(size_t fft_size, bool ifft, int device = 0) {
+        throw_on(comms_fft_create(fft_size, ifft ? 1 : 0, device, &h_), "FFTBatchNode::new");
+    }
+    FFTBatchNode(FFTBatchNode&& o) noexcept : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_) { o.h_ = nullptr; }
+    ~FFTBatchNode() { comms_fft_destroy(h_); }
+
+    Result<std::vector<Complex32>> run(const std::vector<Complex32>& data) {
+        std::vector<Complex32> out(data.size());
+        // a wrong length panics inside rustfft in the reference; here it is DataError
+        comms_status_t st = comms_fft_run(h_, c32(data.data()), data.size(), c32(out.data()));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_fft_t* h_ = nullptr;
+};
+
+// #[aggregate]: run returns Some(vec) every fft_size pushes, None otherwise
+class FFTSampleNode : public DeriveNode<FFTSampleNode> {
+public:
+    NodeReceiver<Complex32> input;
+    NodeSender<std::vector<Complex32>> output;
+
+    FFTSampleNode(size_t fft_size, bool ifft, int device = 0) : n_(fft_size) {
+        throw_on(comms_fft_create(fft_size, ifft ? 1 : 0, device, &h_), "FFTSampleNode::new");
+    }
+    FFTSampleNode(FFTSampleNode&& o) noexcept
+        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), n_(o.n_), samples_(std::move(o.samples_)) {
+        o.h_ = nullptr;
+    }
+    ~FFTSampleNode() { comms_fft_destroy(h_); }
+
+    Result<std::optional<std::vector<Complex32>>> run(const Complex32& sample) {
+        samples_.push_back(sample);
+        if (samples_.size() != n_) return std::optional<std::vector<Complex32>>(std::nullopt);
+        std::vector<Complex32> out(n_);
+        comms_status_t st = comms_fft_run(h_, c32(samples_.data()), n_, c32(out.data()));
+        samples_.clear();
+        if (st != COMMS_OK) return to_node_error(st);
+        return std::optional<std::vector<Complex32>>(std::move(out));
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_fft_t* h_ = nullptr;
+    size_t n_;
+    std::vector<Complex32> samples_;
+};
+
+// ---------------------------------------------------------------- tap design
+inline std::vector<Complex32> rrc_taps(uint32_t n_taps, double sam_per_sym, double beta) {
+    std::vector<Complex32> t(n_taps);
+    throw_on(comms_rrc_taps(n_taps, sam_per_sym, beta, c32(t.data())), "rrc_taps");  // MathError::InvalidRolloffError
+    return t;
+}
+inline std::vector<Complex32> rc_taps(uint32_t n_taps, double sam_per_sym, double beta) {
+    std::vector<Complex32> t(n_taps);
+    throw_on(comms_rc_taps(n_taps, sam_per_sym, beta, c32(t.data())), "rc_taps");
+    return t;
+}
+inline std::vector<Complex32> gaussian_taps(uint32_t n_taps, double sam_per_sym, double alpha) {
+    std::vector<Complex32> t(n_taps);
+    throw_on(comms_gaussian_taps(n_taps, sam_per_sym, alpha, c32(t.data())), "gaussian_taps");
+    return t;
+}
+inline std::vector<Complex32> rect_taps(size_t n_taps) {
+    std::vector<Complex32> t(n_taps);
+    throw_on(comms_rect_taps(n_taps, c32(t.data())), "rect_taps");
+    return t;
+}
+
+// ---------------------------------------------------------------- device-resident nodes
+// Messages are DeviceBuf<T>: nothing crosses PCIe between nodes; each run() is one
+// asynchronous kernel on the node's own stream followed by a stream wait, so the
+// consumer may touch the buffer as soon as it receives it.
+class BatchFirNodeDev : public DeriveNode<BatchFirNodeDev> {
+public:
+    NodeReceiver<DeviceBuf<Complex32>> input;
+    NodeSender<DeviceBuf<Complex32>> output;
+    BatchFirNodeDev(const std::vector<Complex32>& taps, const std::optional<std::vector<Complex32>>& state = std::nullopt,
+                    int device = 0)
+        : device_(device) {
+        throw_on(comms_fir_create(c32(taps.data()), taps.size(), state ? c32(state->data()) : nullptr,
+                                  state ? state->size() : 0, device, &h_),
+                 "BatchFirNodeDev::new");
+    }
+    BatchFirNodeDev(BatchFirNodeDev&& o) noexcept
+        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), device_(o.device_) { o.h_ = nullptr; }
+    ~BatchFirNodeDev() { comms_fir_destroy(h_); }
+    Result<DeviceBuf<Complex32>> run(const DeviceBuf<Complex32>& in) {
+        DeviceBuf<Complex32> out(in.size(), device_);
+        comms_status_t st = comms_fir_run_dev(h_, c32(in.ptr()), in.size(), c32(out.ptr()), nullptr);
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_fir_t* h_ = nullptr;
+    int device_;
+};
+
+class BatchMixerNodeDev : public DeriveNode<BatchMixerNodeDev> {
+public:
+    NodeReceiver<DeviceBuf<Complex32>> input;
+    NodeSender<DeviceBuf<Complex32>> output;
+    explicit BatchMixerNodeDev(double dphase, std::optional<double> phase = std::nullopt, int device = 0) : device_(device) {
+        throw_on(comms_mixer_create(dphase, phase.value_or(0.0), device, &h_), "BatchMixerNodeDev::new");
+    }
+    BatchMixerNodeDev(BatchMixerNodeDev&& o) noexcept
+        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), device_(o.device_) { o.h_ = nullptr; }
+    ~BatchMixerNodeDev() { comms_mixer_destroy(h_); }
+    Result<DeviceBuf<Complex32>> run(const DeviceBuf<Complex32>& in) {
+        DeviceBuf<Complex32> out(in.size(), device_);
+        comms_status_t st = comms_mixer_run_dev(h_, c32(in.ptr()), in.size(), c32(out.ptr()), nullptr);
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_mixer_t* h_ = nullptr;
+    int device_;
+};
+
+class DecimateNodeDev : public DeriveNode<DecimateNodeDev> {
+public:
+    NodeReceiver<DeviceBuf<Complex32>> input;
+    NodeSender<DeviceBuf<Complex32>> output;
+    explicit DecimateNodeDev(size_t dec_rate, int device = 0) : rate_(dec_rate), device_(device) {}
+    Result<DeviceBuf<Complex32>> run(const DeviceBuf<Complex32>& in) {
+        size_t n_out = 0;
+        comms_decimate_out_len(in.size(), rate_, &n_out);
+        DeviceBuf<Complex32> out(n_out, device_);
+        comms_status_t st = comms_decimate_run_dev(in.ptr(), in.size(), sizeof(Complex32), rate_, out.ptr(), nullptr,
+                                                   device_, nullptr);
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    size_t rate_;
+    int device_;
+};
+
+}  // namespace comms
