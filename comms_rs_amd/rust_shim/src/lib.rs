@@ -1,0 +1,211 @@
+//! comms-rs nodes whose `run()` executes on an MI355X through libcomms_hip.so.
+//!
+//! UNTESTED SOURCE (no Rust toolchain where this was written).  Each struct keeps
+//! the reference node's name, constructor signature and public `input` / `output`
+//! fields, and derives `Node` with the reference's own `node_derive` macro, so
+//! `connect_nodes!` / `start_nodes!` / `Graph` work unchanged:
+//!
+//! ```ignore
+//! use comms_rs::prelude::*;
+//! use comms_rs_hip::BatchFirNode;          // instead of comms_rs::filter::fir_node::BatchFirNode
+//! let mut filt: BatchFirNode = BatchFirNode::new(taps, None);
+//! connect_nodes!(src, output, filt, input);
+//! start_nodes!(src, filt);
+//! ```
+pub mod ffi;
+
+use comms_rs::prelude::*;
+use ffi::*;
+use num::Complex;
+use std::ptr;
+
+fn to_err(st: comms_status_t) -> NodeError {
+    // COMMS_ERR_ARG -> DataError, COMMS_ERR_DEVICE -> PermanentError (include/comms_hip.h)
+    if st == COMMS_ERR_ARG { NodeError::DataError } else { NodeError::PermanentError }
+}
+
+macro_rules! handle_node {
+    ($name:ident, $h:ty, $destroy:ident) => {
+        // a handle is used by one thread at a time but not its creator: Send, never Sync
+        unsafe impl Send for $name {}
+        impl Drop for $name {
+            fn drop(&mut self) { unsafe { $destroy(self.h); } }
+        }
+    };
+}
+
+/// fir_node.rs:148-221
+#[derive(Node)]
+#[pass_by_ref]
+pub struct BatchFirNode {
+    pub input: NodeReceiver<Vec<Complex<f32>>>,
+    h: *mut comms_fir_t,
+    pub output: NodeSender<Vec<Complex<f32>>>,
+}
+handle_node!(BatchFirNode, comms_fir_t, comms_fir_destroy);
+impl BatchFirNode {
+    pub fn new(taps: Vec<Complex<f32>>, state: Option<Vec<Complex<f32>>>) -> Self {
+        let mut h = ptr::null_mut();
+        let (sp, sn) = match &state { Some(s) => (s.as_ptr(), s.len()), None => (ptr::null(), 0) };
+        let st = unsafe { comms_fir_create(taps.as_ptr(), taps.len(), sp, sn, 0, &mut h) };
+        assert_eq!(st, COMMS_OK, "comms_fir_create failed");   // the reference panics on a bad state too
+        BatchFirNode { input: Default::default(), h, output: Default::default() }
+    }
+    pub fn run(&mut self, input: &[Complex<f32>]) -> Result<Vec<Complex<f32>>, NodeError> {
+        let mut out = vec![Complex::new(0.0f32, 0.0); input.len()];
+        let st = unsafe { comms_fir_run(self.h, input.as_ptr(), input.len(), out.as_mut_ptr()) };
+        if st == COMMS_OK { Ok(out) } else { Err(to_err(st)) }
+    }
+}
+
+/// fir_node.rs:45-114 (one sample per message)
+#[derive(Node)]
+#[pass_by_ref]
+pub struct FirNode {
+    pub input: NodeReceiver<Complex<f32>>,
+    h: *mut comms_fir_t,
+    pub output: NodeSender<Complex<f32>>,
+}
+handle_node!(FirNode, comms_fir_t, comms_fir_destroy);
+impl FirNode {
+    pub fn new(taps: Vec<Complex<f32>>, state: Option<Vec<Complex<f32>>>) -> Self {
+        let mut h = ptr::null_mut();
+        let (sp, sn) = match &state { Some(s) => (s.as_ptr(), s.len()), None => (ptr::null(), 0) };
+        let st = unsafe { comms_fir_create(taps.as_ptr(), taps.len(), sp, sn, 0, &mut h) };
+        assert_eq!(st, COMMS_OK, "comms_fir_create failed");
+        FirNode { input: Default::default(), h, output: Default::default() }
+    }
+    pub fn run(&mut self, input: &Complex<f32>) -> Result<Complex<f32>, NodeError> {
+        let mut out = Complex::new(0.0f32, 0.0);
+        let st = unsafe { comms_fir_run(self.h, input, 1, &mut out) };
+        if st == COMMS_OK { Ok(out) } else { Err(to_err(st)) }
+    }
+}
+
+/// mixer.rs:93-148 -- argument order (dphase, phase) as in MixerNode::new
+#[derive(Node)]
+#[pass_by_ref]
+pub struct MixerNode {
+    pub input: NodeReceiver<Complex<f32>>,
+    h: *mut comms_mixer_t,
+    pub output: NodeSender<Complex<f32>>,
+}
+handle_node!(MixerNode, comms_mixer_t, comms_mixer_destroy);
+impl MixerNode {
+    pub fn new(dphase: f64, phase: Option<f64>) -> Self {
+        let mut h = ptr::null_mut();
+        let st = unsafe { comms_mixer_create(dphase, phase.unwrap_or(0.0), 0, &mut h) };
+        assert_eq!(st, COMMS_OK, "comms_mixer_create failed");
+        MixerNode { input: Default::default(), h, output: Default::default() }
+    }
+    pub fn run(&mut self, input: &Complex<f32>) -> Result<Complex<f32>, NodeError> {
+        let mut out = Complex::new(0.0f32, 0.0);
+        let st = unsafe { comms_mixer_run(self.h, input, 1, &mut out) };
+        if st == COMMS_OK { Ok(out) } else { Err(to_err(st)) }
+    }
+}
+
+/// pulse.rs:38-93
+#[derive(Node)]
+#[pass_by_ref]
+pub struct PulseNode {
+    pub input: NodeReceiver<Complex<f32>>,
+    h: *mut comms_pulse_t,
+    sam_per_sym: usize,
+    pub output: NodeSender<Vec<Complex<f32>>>,
+}
+handle_node!(PulseNode, comms_pulse_t, comms_pulse_destroy);
+impl PulseNode {
+    pub fn new(taps: Vec<Complex<f32>>, sam_per_sym: usize) -> Self {
+        let mut h = ptr::null_mut();
+        let st = unsafe { comms_pulse_create(taps.as_ptr(), taps.len(), sam_per_sym, 0, &mut h) };
+        assert_eq!(st, COMMS_OK, "comms_pulse_create failed");
+        PulseNode { input: Default::default(), h, sam_per_sym, output: Default::default() }
+    }
+    pub fn run(&mut self, input: &Complex<f32>) -> Result<Vec<Complex<f32>>, NodeError> {
+        let mut out = vec![Complex::new(0.0f32, 0.0); self.sam_per_sym];
+        let st = unsafe { comms_pulse_run(self.h, input, 1, out.as_mut_ptr()) };
+        if st == COMMS_OK { Ok(out) } else { Err(to_err(st)) }
+    }
+}
+
+/// resample_node.rs:10-66 (T = Complex<f32>; any Copy T works through `elem`)
+#[derive(Node)]
+#[pass_by_ref]
+pub struct DecimateNode {
+    pub input: NodeReceiver<Vec<Complex<f32>>>,
+    dec_rate: usize,
+    pub output: NodeSender<Vec<Complex<f32>>>,
+}
+impl DecimateNode {
+    pub fn new(dec_rate: usize) -> Self {
+        DecimateNode { dec_rate, input: Default::default(), output: Default::default() }
+    }
+    pub fn run(&mut self, signal: &[Complex<f32>]) -> Result<Vec<Complex<f32>>, NodeError> {
+        let mut n_out = 0usize;
+        unsafe { comms_decimate_out_len(signal.len(), self.dec_rate, &mut n_out) };
+        let mut out = vec![Complex::new(0.0f32, 0.0); n_out];
+        let st = unsafe {
+            comms_decimate_run(signal.as_ptr() as *const _, signal.len(), 8, self.dec_rate,
+                               out.as_mut_ptr() as *mut _, ptr::null_mut(), 0)
+        };
+        if st == COMMS_OK { Ok(out) } else { Err(to_err(st)) }
+    }
+}
+
+/// analog_node.rs:20-52
+#[derive(Node)]
+#[pass_by_ref]
+pub struct FMDemodNode {
+    pub input: NodeReceiver<Vec<Complex<f32>>>,
+    h: *mut comms_fmdemod_t,
+    pub output: NodeSender<Vec<f32>>,
+}
+handle_node!(FMDemodNode, comms_fmdemod_t, comms_fmdemod_destroy);
+impl FMDemodNode {
+    pub fn new() -> Self {
+        let mut h = ptr::null_mut();
+        let st = unsafe { comms_fmdemod_create(0, &mut h) };
+        assert_eq!(st, COMMS_OK, "comms_fmdemod_create failed");
+        FMDemodNode { input: Default::default(), h, output: Default::default() }
+    }
+    pub fn run(&mut self, samples: &[Complex<f32>]) -> Result<Vec<f32>, NodeError> {
+        let mut out = vec![0.0f32; samples.len()];
+        let st = unsafe { comms_fmdemod_run(self.h, samples.as_ptr(), samples.len(), out.as_mut_ptr()) };
+        if st == COMMS_OK { Ok(out) } else { Err(to_err(st)) }
+    }
+}
+
+/// fft_node.rs:28-84
+#[derive(Node)]
+#[pass_by_ref]
+pub struct FFTBatchNode {
+    pub input: NodeReceiver<Vec<Complex<f32>>>,
+    h: *mut comms_fft_t,
+    pub output: NodeSender<Vec<Complex<f32>>>,
+}
+handle_node!(FFTBatchNode, comms_fft_t, comms_fft_destroy);
+impl FFTBatchNode {
+    pub fn new(fft_size: usize, ifft: bool) -> Self {
+        let mut h = ptr::null_mut();
+        let st = unsafe { comms_fft_create(fft_size, ifft as i32, 0, &mut h) };
+        assert_eq!(st, COMMS_OK, "comms_fft_create failed");
+        FFTBatchNode { input: Default::default(), h, output: Default::default() }
+    }
+    pub fn run(&mut self, data: &[Complex<f32>]) -> Result<Vec<Complex<f32>>, NodeError> {
+        let mut out = vec![Complex::new(0.0f32, 0.0); data.len()];
+        let st = unsafe { comms_fft_run(self.h, data.as_ptr(), data.len(), out.as_mut_ptr()) };
+        if st == COMMS_OK { Ok(out) } else { Err(to_err(st)) }   // rustfft would panic on a wrong length
+    }
+}
+
+/// Device-resident message: `Clone` bumps the library's refcount (the derive macro
+/// clones once per sender, node_derive/src/lib.rs:156).
+pub struct DeviceBuf { b: *mut comms_buf_t, pub len: usize }
+unsafe impl Send for DeviceBuf {}
+impl Clone for DeviceBuf {
+    fn clone(&self) -> Self { unsafe { comms_buf_retain(self.b) }; DeviceBuf { b: self.b, len: self.len } }
+}
+impl Drop for DeviceBuf {
+    fn drop(&mut self) { unsafe { comms_buf_release(self.b) }; }
+}
