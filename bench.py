@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--algo", choices=["auto", "direct", "os1024", "os4096"], default="auto")
+    # rehearsal aid: "gloo" runs the N>1 logic with CPU-side messages, ranks sharing the visible GPUs
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     args = ap.parse_args()
 
     import torch
@@ -92,17 +94,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    ndev = torch.cuda.device_count()
+    assert ndev >= 1, "no MI355X visible (no CPU fallback)"
+    if args.backend == "gloo":
+        local_rank = local_rank % ndev
+    assert local_rank < ndev, "LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, ndev)
+    torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+        if args.backend == "nccl":  # RCCL over xGMI
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
-    assert c.device_count() > local_rank, "no MI355X visible (no CPU fallback)"
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     n = N_SAMPLES
     taps = c.rrc_taps(N_TAPS, 8.0, 0.35)
@@ -123,7 +131,7 @@ def main():
     if world > 1:
         from comms_rs_amd.sharding import halo_exchange, state_from_halo
 
-        tail = torch.view_as_real(x[n - N_TAPS:].clone())
+        tail = torch.view_as_real(x[n - N_TAPS:].clone()).to(comm_dev)
         halo = halo_exchange(dist, tail, rank, world)
         torch.cuda.synchronize()
         if rank > 0:
@@ -163,7 +171,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kms = timer.read_ms()
