@@ -176,6 +176,26 @@ def main():
         elapsed = float(t.item())
     kms = timer.read_ms()
     timer.close()
+
+    # ---- the same chain as ONE fused node (comms_chain_*: additional node, same results)
+    chain = c.ChainNode(MIX_DPHASE, 0.0, taps, DEC_RATE, False, device=local_rank, mixer_after_fir=True)
+    zf = torch.empty_like(z)
+    for _ in range(max(args.warmup, 1)):
+        chain.run_dev(x.data_ptr(), n, zf.data_ptr(), stream)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    tf0 = time.perf_counter()
+    for _ in range(args.steps):
+        chain.run_dev(x.data_ptr(), n, zf.data_ptr(), stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    fused_elapsed = time.perf_counter() - tf0
+    if world > 1:
+        t = torch.tensor([fused_elapsed], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        fused_elapsed = float(t.item())
     kernel_ms = float(np.mean(kms)) if kms.size else float("nan")
     algo = {c.FIR_DIRECT: "fir_direct_kernel", c.FIR_OS1024: "fir_os1024_kernel",
             c.FIR_OS4096: "fir_os4096_kernel"}[fir.algo_for(n)]
@@ -207,6 +227,10 @@ def main():
                          "kernel_ms": round(kernel_ms, 5), "launches_timed": int(kms.size),
                          "algorithmic_bytes_per_launch": FIR_BYTES_PER_SAMPLE * n},
         }
+        out["fused_chain"] = {"value": round(total / fused_elapsed / 1e6, 1), "unit": "Msamples/s",
+                              "ms_per_step": round(fused_elapsed / args.steps * 1e3, 4), "fused": chain.fused,
+                              "note": "same FIR->mixer->decimate chain as one comms_chain_* launch "
+                                      "(8 B read + 1 B written per input sample); not the headline value"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n)
         print(json.dumps(out), flush=True)

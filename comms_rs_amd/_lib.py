@@ -94,6 +94,8 @@ _PROTOS = {
     "comms_gaussian_taps": [_u32, _f64, _f64, _vp],
     "comms_rect_taps": [_sz, _vp],
     "comms_chain_create": [_f64, _f64, _vp, _sz, _sz, _i32, _i32, _pp],
+    "comms_chain_create_ex": [_f64, _f64, _vp, _sz, _sz, _i32, _i32, _pp],
+    "comms_chain_is_fused": [_vp, C.POINTER(_i32)],
     "comms_chain_run_dev": [_vp, _vp, _sz, _vp, _vp],
     "comms_chain_run": [_vp, _vp, _sz, _vp],
     "comms_chain_destroy": [_vp],

@@ -1,21 +1,31 @@
-// chain.hip -- mixer -> FIR -> decimate-by-R [-> FM demod] as ONE node.
+// chain.hip -- mixer / FIR / decimate-by-R [/ FM demod] as ONE node.
 //
-// An ADDITIONAL node (the reference has no fused nodes): same results as
-// MixerNode -> BatchFirNode -> DecimateNode [-> FMDemodNode] in series
-// (examples/fm_radio.rs:146-148 order, mixer of BASELINE config 3 in front).
-// This first version chains the four device kernels through two handle-owned
-// HBM temporaries on one stream; state (mixer phase, FIR history, FM prev)
-// lives in the sub-handles.
+// An ADDITIONAL node (the reference has no fused nodes): same results as the
+// reference nodes in series -- MixerNode -> BatchFirNode -> DecimateNode
+// [-> FMDemodNode] (BASELINE config 3; examples/fm_radio.rs:146-148 order with a
+// mixer in front) or BatchFirNode -> MixerNode -> DecimateNode (the BASELINE
+// metric's chain).  Up to 257 taps it is one launch of the 1024-point
+// overlap-save kernel with the extra stages fused in registers
+// (fir_os1024_kernel<.., MODE>): 8 B read per input sample and 8/R (or 4/R) B
+// written, instead of 16 + 16 + 9 + 1.5 B for the four nodes.  Longer filters run
+// the four device kernels back to back through HBM temporaries.
 #include "common.hpp"
 
 using namespace comms;
 
 struct comms_chain : Handle {
-    comms_mixer_t* mixer = nullptr;
+    bool fused = false;
+    int mode = 0;
+    // fused path state
     comms_fir_t* fir = nullptr;
+    uint64_t turns = 0, frac = 0;
+    float2* d_prev[2] = {nullptr, nullptr};
+    int cur = 0;
+    // unfused path
+    comms_mixer_t* mixer = nullptr;
     comms_fmdemod_t* fm = nullptr;
     size_t rate = 1;
-    bool fm_demod = false;
+    bool fm_demod = false, mixer_after = false;
     Scratch t1, t2, t3;
 };
 
@@ -24,6 +34,8 @@ static void free_chain(comms_chain* h) {
     if (h->fir) comms_fir_destroy(h->fir);
     if (h->fm) comms_fmdemod_destroy(h->fm);
     (void)use_device(h->device);
+    if (h->d_prev[0]) (void)hipFree(h->d_prev[0]);
+    if (h->d_prev[1]) (void)hipFree(h->d_prev[1]);
     h->t1.release();
     h->t2.release();
     h->t3.release();
@@ -33,12 +45,12 @@ static void free_chain(comms_chain* h) {
 
 extern "C" {
 
-comms_status_t comms_chain_create(double dphase, double phase, const comms_c32* taps,
-                                  size_t n_taps, size_t rate, int32_t fm_demod, int32_t device,
-                                  comms_chain_t** out) {
+comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c32* taps, size_t n_taps,
+                                     size_t rate, int32_t flags, int32_t device, comms_chain_t** out) {
     COMMS_ARG(out != nullptr, "out is NULL");
     *out = nullptr;
     COMMS_ARG(rate >= 1, "rate must be >= 1");
+    COMMS_ARG(std::isfinite(dphase) && std::isfinite(phase), "dphase/phase must be finite");
     comms_chain* h = new (std::nothrow) comms_chain;
     COMMS_ARG(h != nullptr, "out of host memory");
     comms_status_t st = h->init(device);
@@ -47,15 +59,43 @@ comms_status_t comms_chain_create(double dphase, double phase, const comms_c32* 
         return st;
     }
     h->rate = rate;
-    h->fm_demod = fm_demod != 0;
-    st = comms_mixer_create(dphase, phase, device, &h->mixer);
-    if (st == COMMS_OK) st = comms_fir_create(taps, n_taps, nullptr, 0, device, &h->fir);
-    if (st == COMMS_OK && h->fm_demod) st = comms_fmdemod_create(device, &h->fm);
+    h->fm_demod = (flags & COMMS_CHAIN_FM_DEMOD) != 0;
+    h->mixer_after = (flags & COMMS_CHAIN_MIXER_AFTER_FIR) != 0;
+    st = comms_fir_create(taps, n_taps, nullptr, 0, device, &h->fir);
+    const bool can_fuse = !(flags & COMMS_CHAIN_UNFUSED) && n_taps <= 257 && rate <= (1u << 20) &&
+                          (!h->fm_demod || (rate <= 64 && n_taps + rate <= 257));
+    if (st == COMMS_OK && can_fuse) {
+        h->fused = true;
+        h->mode = (h->mixer_after ? COMMS_CHAIN_POST : COMMS_CHAIN_PRE) | COMMS_CHAIN_DEC |
+                  (h->fm_demod ? COMMS_CHAIN_FM : 0);
+        h->frac = mix_to_turns(mix_wrap_dphase(dphase));
+        h->turns = mix_to_turns(phase);
+        for (int i = 0; i < 2 && st == COMMS_OK; ++i) {
+            hipError_t e = hipMalloc(&h->d_prev[i], sizeof(float2));
+            if (e == hipSuccess) e = hipMemset(h->d_prev[i], 0, sizeof(float2));
+            if (e != hipSuccess) st = fail(COMMS_ERR_DEVICE, "chain state alloc: %s", hipGetErrorString(e));
+        }
+    } else if (st == COMMS_OK) {
+        st = comms_mixer_create(dphase, phase, device, &h->mixer);
+        if (st == COMMS_OK && h->fm_demod) st = comms_fmdemod_create(device, &h->fm);
+    }
     if (st != COMMS_OK) {
         free_chain(h);
         return st;
     }
     *out = h;
+    return COMMS_OK;
+}
+
+comms_status_t comms_chain_create(double dphase, double phase, const comms_c32* taps,
+                                  size_t n_taps, size_t rate, int32_t fm_demod, int32_t device,
+                                  comms_chain_t** out) {
+    return comms_chain_create_ex(dphase, phase, taps, n_taps, rate, fm_demod ? COMMS_CHAIN_FM_DEMOD : 0, device, out);
+}
+
+comms_status_t comms_chain_is_fused(const comms_chain_t* h, int32_t* out_fused) {
+    COMMS_ARG(h && out_fused, "NULL argument");
+    *out_fused = h->fused ? 1 : 0;
     return COMMS_OK;
 }
 
@@ -67,13 +107,26 @@ comms_status_t comms_chain_run_dev(comms_chain_t* h, const comms_c32* d_in, size
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
     void* s = stream == COMMS_STREAM_HANDLE ? static_cast<void*>(h->stream) : stream;
+    if (h->fused) {
+        COMMS_TRY(comms_fir_run_fused_dev(h->fir, d_in, n, d_out, h->mode, h->turns, h->frac,
+                                          static_cast<uint32_t>(h->rate), h->d_prev[h->cur],
+                                          h->d_prev[h->cur ^ 1], s));
+        h->turns += static_cast<uint64_t>(n) * h->frac;
+        if (h->fm_demod) h->cur ^= 1;
+        return COMMS_OK;
+    }
     const size_t n_dec = n / h->rate;
     COMMS_TRY(h->t1.reserve(n * sizeof(comms_c32)));
     COMMS_TRY(h->t2.reserve(n * sizeof(comms_c32)));
     comms_c32* a = static_cast<comms_c32*>(h->t1.p);
     comms_c32* b = static_cast<comms_c32*>(h->t2.p);
-    COMMS_TRY(comms_mixer_run_dev(h->mixer, d_in, n, a, s));
-    COMMS_TRY(comms_fir_run_dev(h->fir, a, n, b, s));
+    if (h->mixer_after) {
+        COMMS_TRY(comms_fir_run_dev(h->fir, d_in, n, a, s));
+        COMMS_TRY(comms_mixer_run_dev(h->mixer, a, n, b, s));
+    } else {
+        COMMS_TRY(comms_mixer_run_dev(h->mixer, d_in, n, a, s));
+        COMMS_TRY(comms_fir_run_dev(h->fir, a, n, b, s));
+    }
     if (!h->fm_demod)
         return comms_decimate_run_dev(b, n, sizeof(comms_c32), h->rate, d_out, nullptr, h->device, s);
     COMMS_TRY(h->t3.reserve(n_dec * sizeof(comms_c32)));

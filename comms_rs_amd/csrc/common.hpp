@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -10,6 +11,15 @@
 #include <new>
 
 #include "../../include/comms_hip.h"
+
+// fused-chain stage bits shared by fir.hip and chain.hip (internal)
+#define COMMS_CHAIN_PRE 1  /* mixer before the FIR */
+#define COMMS_CHAIN_POST 2 /* mixer after the FIR */
+#define COMMS_CHAIN_DEC 4
+#define COMMS_CHAIN_FM 8
+extern "C" comms_status_t comms_fir_run_fused_dev(comms_fir_t* h, const comms_c32* d_in, size_t n, void* d_out,
+                                                  int32_t mode, uint64_t turns0, uint64_t frac, uint32_t rate,
+                                                  const void* fm_prev, void* fm_prev_new, void* stream);
 
 namespace comms {
 
@@ -138,5 +148,29 @@ inline bool ranges_overlap(const void* a, size_t na, const void* b, size_t nb) {
 }
 
 constexpr int kNumCU = 256;  // MI355X: 8 XCD x 32 CU
+
+// Mixer phase bookkeeping shared by the mixer node and the fused chain: phases are
+// 64-bit fixed-point fractions ("turns") of T = fl(2*pi), the constant the reference
+// wraps with (src/mixer.rs:79-82).
+constexpr double kMixT = 2.0 * 3.14159265358979323846264338327950288;
+inline uint64_t mix_to_turns(double angle) {
+    long double r = fmodl(static_cast<long double>(angle), static_cast<long double>(kMixT));
+    if (r < 0) r += static_cast<long double>(kMixT);
+    long double t = r / static_cast<long double>(kMixT) * 18446744073709551616.0L;
+    if (t >= 18446744073709551616.0L) return 0;
+    return static_cast<uint64_t>(t);
+}
+inline void mix_host_rotor(uint64_t turns, double& c, double& s) {
+    double ang = static_cast<double>(turns >> 11) * (kMixT * 0x1.0p-53);
+    c = cos(ang);
+    s = sin(ang);
+}
+// Mixer::new (src/mixer.rs:43-51): dphase wrapped into [0, 2pi)
+inline double mix_wrap_dphase(double dphase) {
+    if (fabs(dphase) > 64.0 * kMixT) dphase = fmod(dphase, kMixT);
+    while (dphase >= kMixT) dphase -= kMixT;
+    while (dphase < 0.0) dphase += kMixT;
+    return dphase;
+}
 
 }  // namespace comms

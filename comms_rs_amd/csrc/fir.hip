@@ -319,6 +319,33 @@ struct WTables {
     const float2* hdev;  // [16][64]  H[k0 + 16 k1 + 256 k2]/1024 at [4j + k2][lane], k1 = lane&15, k0 = (lane>>4) + 4j
 };
 
+// Optional stages fused around the 1024-point overlap-save FIR (comms_chain_*):
+//   MODE bit 0: mixer BEFORE the FIR (on load)      bit 1: mixer AFTER the FIR
+//   MODE bit 2: keep every `rate`-th output          bit 3: FM demod of the kept outputs
+// The mixer rotor of sample i (relative to this call) is rot(turns0 + i*frac); a lane
+// evaluates it once per run with an f64 sincos, advances it per segment with one f64
+// rotor, and reaches the 16 rows of a segment with the wave-uniform f32 rotors
+// step_a[a] = e^{i*64a*dphi}.
+constexpr int CH_PRE = COMMS_CHAIN_PRE, CH_POST = COMMS_CHAIN_POST, CH_DEC = COMMS_CHAIN_DEC, CH_FM = COMMS_CHAIN_FM;
+struct ChainArgs {
+    uint64_t turns0, frac;
+    double seg_c, seg_s;      // e^{i*768*dphi}
+    float2 step_a[16];        // e^{i*64a*dphi}
+    unsigned rate;            // decimation rate (>= 1)
+    unsigned q_a[16], r_a[16];  // (64*(a-4)) / rate and % rate for a = 4..15
+    const float2* fm_prev;    // FM.prev before this call
+    float2* fm_prev_new;      //   ... and after it (ping-pong)
+};
+constexpr double kTwoPiF = 2.0 * 3.14159265358979323846264338327950288;
+
+// FM::demod step (reference src/modulation/analog.rs:27-28): arg(x * conj(p)), unfused
+__device__ __forceinline__ float fm_step(float2 x, float2 p) {
+    const float pcr = p.x, pci = -p.y;
+    const float re = x.x * pcr - x.y * pci;
+    const float im = x.x * pci + x.y * pcr;
+    return atan2f(im, re);
+}
+
 // Orders one wave's LDS traffic (other lanes' writes -> this lane's reads).  A
 // wavefront's DS instructions execute in issue order, so no s_waitcnt or
 // s_barrier is needed -- only a compiler-level fence.
@@ -331,14 +358,15 @@ __device__ __forceinline__ void wave_lds_sync() {
 // WPB waves per workgroup share the read-only tables in LDS (stage-1 twiddles,
 // filter spectrum, W64 table: 16.5 KiB); every wave has a private 8.5 KiB
 // exchange buffer and runs on its own -- no workgroup barrier after set-up.
-template <int WPB, int MINW>
+template <int WPB, int MINW, int MODE>
 __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2* __restrict__ in,
                                                                     const float2* __restrict__ hist,
                                                                     int hist_len,
                                                                     float2* __restrict__ out, size_t n,
                                                                     size_t nseg, size_t n_runs,
                                                                     WTables tb,
-                                                                    float2* __restrict__ new_hist) {
+                                                                    float2* __restrict__ new_hist,
+                                                                    ChainArgs ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     hist_advance(hist, in, n, new_hist, hist_len);
     float2* tw1 = reinterpret_cast<float2*>(smem);  // [16][64]
@@ -362,13 +390,29 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
     const size_t seg0 = run < n_runs ? run * nseg / n_runs : nseg;
     const size_t seg1 = run < n_runs ? (run + 1) * nseg / n_runs : nseg;
 
+    // mixer rotor of this lane's first row (sample seg*768 - 256 + l), f64
+    double rot_c = 1.0, rot_s = 0.0;
+    if ((MODE & (CH_PRE | CH_POST)) && seg0 < seg1) {
+        const long long i0 = static_cast<long long>(seg0 * WV) - 256 + l;
+        const uint64_t turns = ch.turns0 + static_cast<uint64_t>(i0) * ch.frac;
+        sincos(static_cast<double>(turns >> 11) * (kTwoPiF * 0x1.0p-53), &rot_s, &rot_c);
+    }
+
     float2 v[16], carry[4];
     for (size_t seg = seg0; seg < seg1; ++seg) {
         const size_t nb = seg * WV;  // first new sample of this segment
+        float2 rot = make_float2(static_cast<float>(rot_c), static_cast<float>(rot_s));
+        if (MODE & (CH_PRE | CH_POST)) {  // advance to the next segment's first row
+            const double nc = rot_c * ch.seg_c - rot_s * ch.seg_s;
+            rot_s = rot_c * ch.seg_s + rot_s * ch.seg_c;
+            rot_c = nc;
+        }
         if (seg == seg0) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < 4; ++a) {
                 v[a] = stream_at(in, hist, hist_len, static_cast<long long>(nb) - 256 + 64 * a + l, n);
+                if (MODE & CH_PRE) v[a] = cmulf(v[a], a ? cmulf(rot, ch.step_a[a]) : rot);
+            }
         } else {
 #pragma unroll
             for (int a = 0; a < 4; ++a) v[a] = carry[a];
@@ -382,6 +426,10 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
                 const size_t g = nb + 64 * (a - 4) + l;
                 v[a] = g < n ? in[g] : make_float2(0.f, 0.f);
             }
+        }
+        if (MODE & CH_PRE) {
+#pragma unroll
+            for (int a = 4; a < 16; ++a) v[a] = cmulf(v[a], cmulf(rot, ch.step_a[a]));
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a) carry[a] = v[12 + a];
@@ -441,14 +489,61 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
         }
         wave_lds_sync();
         radix16<1>(v);
-        if (nb + WV <= n) {
+        if (MODE == 0) {
+            if (nb + WV <= n) {
 #pragma unroll
-            for (int a = 4; a < 16; ++a) out[nb + 64 * (a - 4) + l] = v[R16_POS(a)];
+                for (int a = 4; a < 16; ++a) out[nb + 64 * (a - 4) + l] = v[R16_POS(a)];
+            } else {
+#pragma unroll
+                for (int a = 4; a < 16; ++a) {
+                    const size_t o = nb + 64 * (a - 4) + l;
+                    if (o < n) out[o] = v[R16_POS(a)];
+                }
+            }
         } else {
+            if (MODE & CH_POST) {
+#pragma unroll
+                for (int a = 4; a < 16; ++a)
+                    v[R16_POS(a)] = cmulf(v[R16_POS(a)], cmulf(rot, ch.step_a[a]));
+            }
+            // FM needs y[idx - rate]: lane l - rate of the same row, or the tail of row a-1
+            const int src = (l - static_cast<int>(ch.rate)) & 63;
+            float2 sh_prev = make_float2(0.f, 0.f);
+            if (MODE & CH_FM) {
+                const float2 y3 = v[R16_POS(3)];
+                sh_prev = make_float2(__shfl(y3.x, src), __shfl(y3.y, src));
+            }
+            // idx = nb + 64(a-4) + l; kept when idx % rate == 0, written at idx / rate
+            const size_t base = nb + l;
+            const size_t q0 = base / ch.rate;
+            const unsigned r0 = static_cast<unsigned>(base - q0 * ch.rate);
 #pragma unroll
             for (int a = 4; a < 16; ++a) {
-                const size_t o = nb + 64 * (a - 4) + l;
-                if (o < n) out[o] = v[R16_POS(a)];
+                unsigned r = r0 + ch.r_a[a];
+                size_t q = q0 + ch.q_a[a];
+                if (r >= ch.rate) {
+                    r -= ch.rate;
+                    ++q;
+                }
+                const size_t idx = nb + 64 * (a - 4) + l;
+                float2 sh_cur = make_float2(0.f, 0.f);
+                if (MODE & CH_FM) {
+                    const float2 ya = v[R16_POS(a)];
+                    sh_cur = make_float2(__shfl(ya.x, src), __shfl(ya.y, src));
+                }
+                const float2 p_row = l >= static_cast<int>(ch.rate) ? sh_cur : sh_prev;
+                sh_prev = sh_cur;
+                if (r == 0 && idx < n) {
+                    const float2 y = v[R16_POS(a)];
+                    if (MODE & CH_FM) {
+                        float2 p = p_row;
+                        if (idx == 0) p = ch.fm_prev[0];
+                        reinterpret_cast<float*>(out)[q] = fm_step(y, p);
+                        if (idx + ch.rate >= n) ch.fm_prev_new[0] = y;  // last kept sample of the call
+                    } else {
+                        out[q] = y;
+                    }
+                }
             }
         }
     }
@@ -802,16 +897,16 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
             const size_t lds = (2112 + 16 * W_LDS) * sizeof(float2);
             static bool attr16 = false;
             if (!attr16) {
-                COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os1024_kernel<16, 4>),
+                COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os1024_kernel<16, 4, 0>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
                 attr16 = true;
             }
-            fir_os1024_kernel<16, 4><<<dim3(static_cast<unsigned>((runs + 15) / 16)), dim3(1024), lds, s>>>(
-                in, hist, h->n_eff, o, n, nseg, runs, tb, nh);
+            fir_os1024_kernel<16, 4, 0><<<dim3(static_cast<unsigned>((runs + 15) / 16)), dim3(1024), lds, s>>>(
+                in, hist, h->n_eff, o, n, nseg, runs, tb, nh, ChainArgs{});
         } else {
             const size_t lds = (2112 + 4 * W_LDS) * sizeof(float2);
-            fir_os1024_kernel<4, 3><<<dim3(static_cast<unsigned>((runs + 3) / 4)), dim3(256), lds, s>>>(
-                in, hist, h->n_eff, o, n, nseg, runs, tb, nh);
+            fir_os1024_kernel<4, 3, 0><<<dim3(static_cast<unsigned>((runs + 3) / 4)), dim3(256), lds, s>>>(
+                in, hist, h->n_eff, o, n, nseg, runs, tb, nh, ChainArgs{});
         }
         h->toc(s);
         COMMS_TRY(launch_ok("fir_os1024_kernel"));
@@ -872,6 +967,68 @@ comms_status_t comms_fir_set_state(comms_fir_t* h, const comms_c32* state, size_
 comms_status_t comms_fir_set_timer(comms_fir_t* h, comms_timer_t* t) {
     COMMS_ARG(h != nullptr, "handle is NULL");
     h->timer = t;
+    return COMMS_OK;
+}
+
+// ---- fused chain entry (internal; used by chain.hip).  mode = CH_* bits.
+comms_status_t comms_fir_run_fused_dev(comms_fir_t* h, const comms_c32* d_in, size_t n, void* d_out,
+                                       int32_t mode, uint64_t turns0, uint64_t frac, uint32_t rate,
+                                       const void* fm_prev, void* fm_prev_new, void* stream) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG((d_in && d_out) || !n, "NULL device pointer");
+    COMMS_ARG(h->n_eff <= 257, "the fused chain kernel supports at most 257 taps");
+    COMMS_ARG(rate >= 1 && n % rate == 0, "n must be a multiple of the decimation rate");
+    COMMS_ARG(!(mode & CH_FM) || (rate <= 64 && h->n_eff + static_cast<int>(rate) <= 257),
+              "fused FM demod needs rate <= 64 and taps + rate <= 257");
+    COMMS_TRY(use_device(h->device));
+    if (!n) return COMMS_OK;
+    COMMS_TRY(fir_prepare_os1024(h));
+    hipStream_t s = h->pick(stream);
+    const float2* in = reinterpret_cast<const float2*>(d_in);
+    float2* o = reinterpret_cast<float2*>(d_out);
+    const float2* hist = h->d_hist[h->cur];
+    float2* nh = h->d_hist[h->cur ^ 1];
+    ChainArgs ch{};
+    ch.turns0 = turns0;
+    ch.frac = frac;
+    mix_host_rotor(static_cast<uint64_t>(WV) * frac, ch.seg_c, ch.seg_s);
+    for (int a = 0; a < 16; ++a) {
+        double c, sn;
+        mix_host_rotor(static_cast<uint64_t>(64 * a) * frac, c, sn);
+        ch.step_a[a] = make_float2(static_cast<float>(c), static_cast<float>(sn));
+        const unsigned off = a >= 4 ? 64u * (a - 4) : 0u;
+        ch.q_a[a] = off / rate;
+        ch.r_a[a] = off % rate;
+    }
+    ch.rate = rate;
+    ch.fm_prev = static_cast<const float2*>(fm_prev);
+    ch.fm_prev_new = static_cast<float2*>(fm_prev_new);
+    const size_t nseg = (n + WV - 1) / WV;
+    size_t runs = 12 * static_cast<size_t>(kNumCU);
+    if (runs * 4 > nseg) runs = (nseg + 3) / 4;
+    WTables tb{h->d_wtw1, h->d_wtw2, h->d_whdev};
+    const size_t lds = (2112 + 4 * W_LDS) * sizeof(float2);
+    const dim3 grid(static_cast<unsigned>((runs + 3) / 4)), block(256);
+    h->tic(s);
+    switch (mode) {
+        case CH_PRE | CH_DEC:
+            fir_os1024_kernel<4, 3, CH_PRE | CH_DEC><<<grid, block, lds, s>>>(in, hist, h->n_eff, o, n, nseg, runs, tb, nh, ch);
+            break;
+        case CH_PRE | CH_DEC | CH_FM:
+            fir_os1024_kernel<4, 3, CH_PRE | CH_DEC | CH_FM><<<grid, block, lds, s>>>(in, hist, h->n_eff, o, n, nseg, runs, tb, nh, ch);
+            break;
+        case CH_POST | CH_DEC:
+            fir_os1024_kernel<4, 3, CH_POST | CH_DEC><<<grid, block, lds, s>>>(in, hist, h->n_eff, o, n, nseg, runs, tb, nh, ch);
+            break;
+        case CH_POST | CH_DEC | CH_FM:
+            fir_os1024_kernel<4, 3, CH_POST | CH_DEC | CH_FM><<<grid, block, lds, s>>>(in, hist, h->n_eff, o, n, nseg, runs, tb, nh, ch);
+            break;
+        default:
+            return fail(COMMS_ERR_ARG, "unsupported fused mode %d", mode);
+    }
+    h->toc(s);
+    COMMS_TRY(launch_ok("fir_os1024_kernel (fused)"));
+    h->cur ^= 1;
     return COMMS_OK;
 }
 

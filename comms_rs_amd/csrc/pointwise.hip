@@ -160,18 +160,8 @@ struct comms_mixer : Handle {
     uint64_t frac;       // dphase as a fraction of T
 };
 
-static uint64_t to_turns(double angle) {
-    long double r = fmodl(static_cast<long double>(angle), static_cast<long double>(kT));
-    if (r < 0) r += static_cast<long double>(kT);
-    long double t = r / static_cast<long double>(kT) * 18446744073709551616.0L;
-    if (t >= 18446744073709551616.0L) return 0;
-    return static_cast<uint64_t>(t);
-}
-static void host_rotor(uint64_t turns, double& c, double& s) {
-    double ang = static_cast<double>(turns >> 11) * (kT * 0x1.0p-53);
-    c = std::cos(ang);
-    s = std::sin(ang);
-}
+static uint64_t to_turns(double angle) { return mix_to_turns(angle); }
+static void host_rotor(uint64_t turns, double& c, double& s) { mix_host_rotor(turns, c, s); }
 
 extern "C" {
 
@@ -187,12 +177,7 @@ comms_status_t comms_mixer_create(double dphase, double phase, int32_t device,
         delete h;
         return st;
     }
-    // Mixer::new (src/mixer.rs:43-51): wrap dphase into [0, 2pi).  The
-    // reference loops; beyond a few turns fmod gives the same value without
-    // the loop's O(|dphase|) trip count.
-    if (std::fabs(dphase) > 64.0 * kT) dphase = std::fmod(dphase, kT);
-    while (dphase >= kT) dphase -= kT;
-    while (dphase < 0.0) dphase += kT;
+    dphase = mix_wrap_dphase(dphase);  // Mixer::new (src/mixer.rs:43-51)
     h->dphase = dphase;
     h->frac = to_turns(dphase);
     h->turns = to_turns(phase);

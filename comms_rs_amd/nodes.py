@@ -309,15 +309,23 @@ class FFTSampleNode(FFTBatchNode):
 
 # ------------------------------------------------------------------ fused chain
 class ChainNode(_Handle):
-    """mixer -> FIR -> decimate [-> FM demod] (additional node, comms_chain_*)."""
+    """mixer / FIR / decimate [/ FM demod] as one node (comms_chain_*), an additional node.
+    mixer_after_fir=False: mixer -> FIR -> decimate [-> FM]; True: FIR -> mixer -> decimate."""
     _destroy = "comms_chain_destroy"
 
-    def __init__(self, dphase, phase, taps, rate, fm_demod, device=0):
+    def __init__(self, dphase, phase, taps, rate, fm_demod, device=0, mixer_after_fir=False, unfused=False):
         super().__init__()
         taps = _as_c64(taps)
         self.rate, self.fm_demod = int(rate), bool(fm_demod)
-        check(lib().comms_chain_create(float(dphase), float(phase), _ptr(taps), taps.size, self.rate,
-                                       1 if fm_demod else 0, device, C.byref(self._h)))
+        flags = (1 if fm_demod else 0) | (2 if mixer_after_fir else 0) | (4 if unfused else 0)
+        check(lib().comms_chain_create_ex(float(dphase), float(phase), _ptr(taps), taps.size, self.rate,
+                                          flags, device, C.byref(self._h)))
+
+    @property
+    def fused(self):
+        f = C.c_int32()
+        check(lib().comms_chain_is_fused(self._h, C.byref(f)))
+        return bool(f.value)
 
     def run(self, x):
         x = _as_c64(x)

@@ -451,21 +451,24 @@ def fm_stream(n, first=0):
 
 @pytest.mark.parametrize("fm", [False, True])
 def test_config3_mixer_fir_decimate_fm_chain(c, fm):
-    """BASELINE config 3 (mixer -> 127-tap LPF -> /8 -> FM demod), node by node and
-    through the chain node, in two batches (state carry-over)."""
+    """BASELINE config 3 (mixer -> 127-tap LPF -> /8 -> FM demod): node by node, through the
+    fused chain node and through the unfused chain node, in three batches (state carry-over)."""
     n = 1 << 18
     x = fm_stream(n)
     taps = lowpass_taps(127, 1 / 16)
     dphase = 2 * np.pi * 0.05
     om, ost, ofm = oracle.Mixer(0.0, dphase), oracle.default_state(taps), oracle.FM()
-    node = c.ChainNode(dphase, 0.0, taps, 8, fm)
+    fused = c.ChainNode(dphase, 0.0, taps, 8, fm)
+    plain = c.ChainNode(dphase, 0.0, taps, 8, fm, unfused=True)
+    assert fused.fused and not plain.fused
     gm, gf, gd, gfm = c.MixerNode(dphase), c.BatchFirNode(taps), c.DecimateNode(8), c.FMDemodNode()
-    for a, b in [(0, 8 * 1000), (8 * 1000, n)]:
+    for a, b in [(0, 8 * 1000), (8 * 1000, 8 * 1001), (8 * 1001, n)]:
         w = oracle.decimate(oracle.batch_fir(om.mix(x[a:b]), taps, ost, norotate=True), 8)
         g = gd.run(gf.run(gm.run(x[a:b])))
         if fm:
             w, g = ofm.demod(w), gfm.run(g)
-        got = node.run(x[a:b])
+        got, got_plain = fused.run(x[a:b]), plain.run(x[a:b])
+        assert np.array_equal(got_plain, g)  # the unfused chain IS the four nodes
         if fm:
             # angle error = FIR error / |y|: compare where the LPF output has settled
             # (|y| ~ 1); the first taps/8 outputs of the stream are the filter's
@@ -473,10 +476,50 @@ def test_config3_mixer_fir_decimate_fm_chain(c, fm):
             settled = slice(32, None) if a == 0 else slice(None)
             assert np.max(circ(g.astype(np.float64) - w)[settled]) <= 5e-5
             assert np.max(circ(got.astype(np.float64) - w)[settled]) <= 5e-5
-            assert np.max(circ(g.astype(np.float64) - got)) == 0.0  # chain node == the four nodes
         else:
             fir_close(g, w, taps, x)
             fir_close(got, w, taps, x)
+
+
+@pytest.mark.parametrize("rate", [1, 2, 5, 8, 64, 100])
+def test_metric_chain_fir_mixer_decimate_fused(c, rate):
+    """The BASELINE metric's chain (255-tap FIR -> mixer -> decimate) as one fused node."""
+    rng = np.random.default_rng(rate)
+    n = 40 * 768 * rate // np.gcd(768, rate)
+    n -= n % rate
+    x = rand_c(rng, n)
+    taps = oracle.rrc_taps(255, 8.0, 0.35)
+    dphase = 2 * np.pi * 0.1
+    node = c.ChainNode(dphase, 0.3, taps, rate, False, mixer_after_fir=True)
+    assert node.fused
+    ost, om = oracle.default_state(taps), oracle.Mixer(0.3, dphase)
+    cut = (n // 3) - (n // 3) % rate
+    for a, b in [(0, cut), (cut, n)]:
+        w = oracle.decimate(om.mix(oracle.batch_fir(x[a:b], taps, ost, norotate=True)), rate)
+        fir_close(node.run(x[a:b]), w, taps, x)
+
+
+@pytest.mark.parametrize("rate", [3, 5, 8, 64])
+def test_fused_fm_chain_rates_and_fallbacks(c, rate):
+    n = 768 * rate * 6
+    x = fm_stream(n)
+    taps = lowpass_taps(63, 1 / (2.5 * rate))
+    node = c.ChainNode(0.3, 0.1, taps, rate, True)
+    assert node.fused
+    ost, om, ofm = oracle.default_state(taps), oracle.Mixer(0.1, 0.3), oracle.FM()
+    for a, b in [(0, 768 * rate), (768 * rate, n)]:
+        w = ofm.demod(oracle.decimate(oracle.batch_fir(om.mix(x[a:b]), taps, ost, norotate=True), rate))
+        got = node.run(x[a:b])
+        y = oracle.decimate(oracle.batch_fir(oracle.Mixer(0.1, 0.3).mix(x[:b]), taps, oracle.default_state(taps), norotate=True), rate)[a // rate:]
+        mag = np.minimum(np.abs(y), np.abs(np.concatenate([[1.0], y[:-1]])))
+        ok = mag > 0.05  # the angle is ill-conditioned where the filtered signal is ~0
+        assert np.max(circ(got.astype(np.float64) - w)[ok]) <= 1e-4
+    # combinations the fused kernel does not cover fall back to the four-kernel path
+    assert not c.ChainNode(0.3, 0.1, lowpass_taps(255, 0.1), 8, True).fused      # taps + rate > 257
+    assert not c.ChainNode(0.3, 0.1, lowpass_taps(63, 0.1), 128, True).fused     # rate > 64
+    assert not c.ChainNode(0.3, 0.1, lowpass_taps(300, 0.1), 8, False).fused     # > 257 taps
+    with pytest.raises(c.CommsError):
+        c.ChainNode(0.3, 0.1, taps, 8, True).run(x[:12])  # n not a multiple of rate
 
 
 def test_fm_radio_example_chain(c):
