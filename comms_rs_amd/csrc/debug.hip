@@ -66,3 +66,61 @@ extern "C" comms_status_t comms_debug_copy(const void* d_in, void* d_out, size_t
     }
     return launch_ok("probe kernel");
 }
+
+// ---- VALU issue-rate probe: ITER x 16 independent ops per lane
+namespace comms {
+template <int KIND>
+__global__ __launch_bounds__(256) void probe_valu_kernel(float* out, int iters, float a, float b) {
+    float r[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = threadIdx.x * 0.001f + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (KIND == 0) r[i] = __builtin_fmaf(r[i], a, b);
+            if (KIND == 1) r[i] = r[i] + a;
+            if (KIND == 2) r[i] = r[i] * a;
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += r[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+// KIND 3: v_pk_fma_f32; KIND 4: complex multiply as 2 packed ops with op_sel/neg modifiers
+template <int KIND>
+__global__ __launch_bounds__(256) void probe_pk_kernel(float* out, int iters, float a, float b) {
+    v2f r[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = v2f{threadIdx.x * 0.001f + i, 1.0f + i};
+    const v2f va{a, a * 0.5f}, vb{b, -b};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (KIND == 3) {
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r[i]) : "v"(r[i]), "v"(va), "v"(vb));
+            } else {
+                v2f p;
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(p) : "v"(r[i]), "v"(va));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+                             : "=v"(r[i]) : "v"(r[i]), "v"(va), "v"(p));
+            }
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += r[i].x + r[i].y;
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+}  // namespace comms
+extern "C" comms_status_t comms_debug_valu(float* d_out, int kind, int iters, int blocks, void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (kind == 0) comms::probe_valu_kernel<0><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 1.0001f, 0.5f);
+    else if (kind == 1) comms::probe_valu_kernel<1><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 1.0001f, 0.5f);
+    else if (kind == 2) comms::probe_valu_kernel<2><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 1.0001f, 0.5f);
+    else if (kind == 3) comms::probe_pk_kernel<3><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 0.9999f, 0.01f);
+    else comms::probe_pk_kernel<4><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 0.9999f, 0.01f);
+    return comms::launch_ok("probe_valu");
+}

@@ -39,22 +39,40 @@ struct FftTileParams {
     size_t tile_step_in, tile_step_out;
     size_t N;                        // distance between transforms of the batch
     size_t n_tiles;                  // total (batch * tiles_per_xform)
-    const float2* twL;               // W_L^m, m < L (forward sign)
+    const cf* twL;               // W_L^m, m < L (forward sign)
     int apply_tw;                    // four-step pass 1: times W_N^{(tile*C + c) * k}
-    const float2* tw_lo;             // W_N^e, e < 4096
-    const float2* tw_hi;             // W_N^{4096 e}
+    const cf* tw_lo;             // W_N^e, e < 4096
+    const cf* tw_hi;             // W_N^{4096 e}
 };
 
+// The generic tile kernel keeps plain C++ complex arithmetic (the compiler schedules
+// it freely across its guarded, partially unrolled passes); the hand-packed butterflies
+// of fft_radix.hpp are for the fully unrolled radix-16 kernels.
+__device__ __forceinline__ cf g_mul(cf a, cf b) {
+    return cf{__builtin_fmaf(-a.y, b.y, a.x * b.x), __builtin_fmaf(a.y, b.x, a.x * b.y)};
+}
+__device__ __forceinline__ cf g_mulc(cf a, cf b) {
+    return cf{__builtin_fmaf(a.y, b.y, a.x * b.x), __builtin_fmaf(a.y, b.x, -(a.x * b.y))};
+}
 template <int DIR>
-__device__ __forceinline__ float2 tw_apply(float2 x, float2 w) {
-    return DIR < 0 ? cmulf(x, w) : cmulcf(x, w);
+__device__ __forceinline__ cf tw_apply(cf x, cf w) {
+    return DIR < 0 ? g_mul(x, w) : g_mulc(x, w);
+}
+template <int DIR>
+__device__ __forceinline__ void g_radix4(cf& a, cf& b, cf& c, cf& d) {
+    const cf t0 = a + c, t1 = a - c, t2 = b + d, u = b - d;
+    const cf t3 = DIR < 0 ? cf{u.y, -u.x} : cf{-u.y, u.x};
+    a = t0 + t2;
+    c = t0 - t2;
+    b = t1 + t3;
+    d = t1 - t3;
 }
 
 template <int DIR>
-__global__ __launch_bounds__(1024) void fft_tile_kernel(const float2* in, float2* out,
+__global__ __launch_bounds__(1024) void fft_tile_kernel(const cf* in, cf* out,
                                                         FftTileParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* tile = reinterpret_cast<float2*>(smem);  // [c][l], row stride L
+    cf* tile = reinterpret_cast<cf*>(smem);  // [c][l], row stride L
     const int T = blockDim.x;
     const int tid = threadIdx.x;
     const int L = p.L, C = p.C;
@@ -63,8 +81,8 @@ __global__ __launch_bounds__(1024) void fft_tile_kernel(const float2* in, float2
     for (size_t tix = blockIdx.x; tix < p.n_tiles; tix += gridDim.x) {
         const size_t b = tix / p.tiles_per_xform;
         const size_t tl = tix - b * p.tiles_per_xform;
-        const float2* src = in + b * p.N + tl * p.tile_step_in;
-        float2* dst = out + b * p.N + tl * p.tile_step_out;
+        const cf* src = in + b * p.N + tl * p.tile_step_in;
+        cf* dst = out + b * p.N + tl * p.tile_step_out;
 
         // ---- load tile
         for (int i = tid; i < npts; i += T) {
@@ -84,7 +102,7 @@ __global__ __launch_bounds__(1024) void fft_tile_kernel(const float2* in, float2
         int Ns = 1;
         int logNs = 0;
         for (; (Ns << 2) <= L; Ns <<= 2, logNs += 2) {
-            float2 v[FT_PTS];
+            cf v[FT_PTS];
             const int nb = npts >> 2;  // radix-4 butterflies in the tile
             const int q = L >> 2;
 #pragma unroll
@@ -92,7 +110,7 @@ __global__ __launch_bounds__(1024) void fft_tile_kernel(const float2* in, float2
                 const int w = tid + u * T;
                 if (w < nb) {
                     const int c = w / q, j = w - c * q;
-                    const float2* row = tile + c * L;
+                    const cf* row = tile + c * L;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[4 * u + r] = row[j + r * q];
                 }
@@ -110,9 +128,9 @@ __global__ __launch_bounds__(1024) void fft_tile_kernel(const float2* in, float2
                         v[4 * u + 2] = tw_apply<DIR>(v[4 * u + 2], p.twL[2 * estep]);
                         v[4 * u + 3] = tw_apply<DIR>(v[4 * u + 3], p.twL[3 * estep]);
                     }
-                    radix4<DIR>(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
+                    g_radix4<DIR>(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
                     const int j0 = ((j >> logNs) << (logNs + 2)) + k;
-                    float2* row = tile + c * L;
+                    cf* row = tile + c * L;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) row[j0 + r * Ns] = v[4 * u + r];
                 }
@@ -120,7 +138,7 @@ __global__ __launch_bounds__(1024) void fft_tile_kernel(const float2* in, float2
             __syncthreads();
         }
         if (Ns < L) {  // one radix-2 pass left (Ns == L/2)
-            float2 v[FT_PTS];
+            cf v[FT_PTS];
             const int nb = npts >> 1;
             const int q = L >> 1;
 #pragma unroll
@@ -139,10 +157,10 @@ __global__ __launch_bounds__(1024) void fft_tile_kernel(const float2* in, float2
                 if (w < nb) {
                     const int c = w / q, j = w - c * q;
                     // Ns == q here, so k == j and the twiddle is W_L^j
-                    float2 a = v[2 * u];
-                    float2 bb = j ? tw_apply<DIR>(v[2 * u + 1], p.twL[j]) : v[2 * u + 1];
-                    tile[c * L + j] = cadd(a, bb);
-                    tile[c * L + j + q] = csub(a, bb);
+                    cf a = v[2 * u];
+                    cf bb = j ? tw_apply<DIR>(v[2 * u + 1], p.twL[j]) : v[2 * u + 1];
+                    tile[c * L + j] = a + bb;
+                    tile[c * L + j + q] = a - bb;
                 }
             }
             __syncthreads();
@@ -158,10 +176,10 @@ __global__ __launch_bounds__(1024) void fft_tile_kernel(const float2* in, float2
                 k = i & (L - 1);
                 c = i >> p.logL;
             }
-            float2 x = tile[c * L + k];
+            cf x = tile[c * L + k];
             if (p.apply_tw) {
                 const size_t e = (tl * static_cast<size_t>(C) + c) * static_cast<size_t>(k);  // < N
-                const float2 w = cmulf(p.tw_hi[e >> 12], p.tw_lo[e & 4095]);
+                const cf w = g_mul(p.tw_hi[e >> 12], p.tw_lo[e & 4095]);
                 x = tw_apply<DIR>(x, w);
             }
             dst[c * p.out_cs + k * p.out_ks] = x;
@@ -171,17 +189,17 @@ __global__ __launch_bounds__(1024) void fft_tile_kernel(const float2* in, float2
 }
 
 // Exact-index O(N^2) DFT, one transform per workgroup, f64 accumulation.
-__global__ __launch_bounds__(256) void dft_direct_kernel(const float2* __restrict__ in,
-                                                         float2* __restrict__ out, int N,
+__global__ __launch_bounds__(256) void dft_direct_kernel(const cf* __restrict__ in,
+                                                         cf* __restrict__ out, int N,
                                                          size_t batch,
-                                                         const float2* __restrict__ twN,
+                                                         const cf* __restrict__ twN,
                                                          int inverse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* x = reinterpret_cast<float2*>(smem);
-    float2* w = x + N;
+    cf* x = reinterpret_cast<cf*>(smem);
+    cf* w = x + N;
     for (int i = threadIdx.x; i < N; i += 256) {
-        float2 t = twN[i];
-        w[i] = inverse ? make_float2(t.x, -t.y) : t;
+        cf t = twN[i];
+        w[i] = inverse ? cf{t.x, -t.y} : t;
     }
     for (size_t b = blockIdx.x; b < batch; b += gridDim.x) {
         __syncthreads();
@@ -199,35 +217,35 @@ __global__ __launch_bounds__(256) void dft_direct_kernel(const float2* __restric
                 e += k;
                 if (e >= N) e -= N;
             }
-            out[b * N + k] = make_float2(static_cast<float>(sr), static_cast<float>(si));
+            out[b * N + k] = cf{static_cast<float>(sr), static_cast<float>(si)};
         }
     }
 }
 
 // Bluestein helpers: a[n] = x[n] * chirp[n] zero-padded to M;  y[k] = c[k] * chirp[k]
-__global__ void blu_pre_kernel(const float2* __restrict__ in, const float2* __restrict__ chirp,
-                               float2* __restrict__ a, size_t N, size_t M, size_t batch) {
+__global__ void blu_pre_kernel(const cf* __restrict__ in, const cf* __restrict__ chirp,
+                               cf* __restrict__ a, size_t N, size_t M, size_t batch) {
     const size_t total = batch * M;
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
         const size_t b = i / M, n = i - b * M;
-        a[i] = n < N ? cmulf(in[b * N + n], chirp[n]) : make_float2(0.f, 0.f);
+        a[i] = n < N ? g_mul(in[b * N + n], chirp[n]) : cf{0.f, 0.f};
     }
 }
-__global__ void blu_mul_kernel(float2* __restrict__ a, const float2* __restrict__ bspec, size_t M,
+__global__ void blu_mul_kernel(cf* __restrict__ a, const cf* __restrict__ bspec, size_t M,
                                size_t batch) {
     const size_t total = batch * M;
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride)
-        a[i] = cmulf(a[i], bspec[i % M]);
+        a[i] = g_mul(a[i], bspec[i % M]);
 }
-__global__ void blu_post_kernel(const float2* __restrict__ a, const float2* __restrict__ chirp,
-                                float2* __restrict__ out, size_t N, size_t M, size_t batch) {
+__global__ void blu_post_kernel(const cf* __restrict__ a, const cf* __restrict__ chirp,
+                                cf* __restrict__ out, size_t N, size_t M, size_t batch) {
     const size_t total = batch * N;
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
         const size_t b = i / N, k = i - b * N;
-        out[i] = cmulf(a[b * M + k], chirp[k]);
+        out[i] = g_mul(a[b * M + k], chirp[k]);
     }
 }
 
@@ -305,7 +323,7 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
         p.tile_step_in = p.tile_step_out = 0;
         p.N = static_cast<size_t>(p.C) * N;
         COMMS_TRY(upload_tw(N, N, 1, &pl.d_tw[0]));
-        p.twL = pl.d_tw[0];
+        p.twL = reinterpret_cast<const cf*>(pl.d_tw[0]);
     } else {
         pl.n_pass = 2;
         const int log1 = logN / 2, log2v = logN - log1;
@@ -327,9 +345,9 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
         COMMS_TRY(upload_tw(N1, N1, 1, &pl.d_tw[0]));
         COMMS_TRY(upload_tw(4096, N, 1, &pl.d_tw[2]));
         COMMS_TRY(upload_tw(N / 4096, N, 4096, &pl.d_tw[3]));
-        a.twL = pl.d_tw[0];
-        a.tw_lo = pl.d_tw[2];
-        a.tw_hi = pl.d_tw[3];
+        a.twL = reinterpret_cast<const cf*>(pl.d_tw[0]);
+        a.tw_lo = reinterpret_cast<const cf*>(pl.d_tw[2]);
+        a.tw_hi = reinterpret_cast<const cf*>(pl.d_tw[3]);
         // pass 2: rows k1, FFT over n2, transposed store -> X[k1 + N1*k2]
         FftTileParams& b = pl.pass[1];
         memset(&b, 0, sizeof(b));
@@ -345,7 +363,7 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
         b.tile_step_out = b.C;
         b.N = N;
         COMMS_TRY(upload_tw(N2, N2, 1, &pl.d_tw[1]));
-        b.twL = pl.d_tw[1];
+        b.twL = reinterpret_cast<const cf*>(pl.d_tw[1]);
     }
     for (int i = 0; i < pl.n_pass; ++i) {
         const int npts = pl.pass[i].L * pl.pass[i].C;
@@ -381,9 +399,9 @@ static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size
             if (full) {
                 unsigned blocks = static_cast<unsigned>(full < 4u * kNumCU ? full : 4u * kNumCU);
                 if (inverse)
-                    fft_tile_kernel<1><<<dim3(blocks), dim3(pl.threads[i]), pl.lds[i], s>>>(src, dst, p);
+                    fft_tile_kernel<1><<<dim3(blocks), dim3(pl.threads[i]), pl.lds[i], s>>>(reinterpret_cast<const cf*>(src), reinterpret_cast<cf*>(dst), p);
                 else
-                    fft_tile_kernel<-1><<<dim3(blocks), dim3(pl.threads[i]), pl.lds[i], s>>>(src, dst, p);
+                    fft_tile_kernel<-1><<<dim3(blocks), dim3(pl.threads[i]), pl.lds[i], s>>>(reinterpret_cast<const cf*>(src), reinterpret_cast<cf*>(dst), p);
                 COMMS_TRY(launch_ok("fft_tile_kernel"));
             }
             const size_t rem = batch - full * p.C;
@@ -398,9 +416,9 @@ static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size
                 if (T < 64) T = 64;
                 unsigned blocks = static_cast<unsigned>(rem < 4u * kNumCU ? rem : 4u * kNumCU);
                 if (inverse)
-                    fft_tile_kernel<1><<<dim3(blocks), dim3(T), pl.N * sizeof(float2), s>>>(src + off, dst + off, q);
+                    fft_tile_kernel<1><<<dim3(blocks), dim3(T), pl.N * sizeof(float2), s>>>(reinterpret_cast<const cf*>(src + off), reinterpret_cast<cf*>(dst + off), q);
                 else
-                    fft_tile_kernel<-1><<<dim3(blocks), dim3(T), pl.N * sizeof(float2), s>>>(src + off, dst + off, q);
+                    fft_tile_kernel<-1><<<dim3(blocks), dim3(T), pl.N * sizeof(float2), s>>>(reinterpret_cast<const cf*>(src + off), reinterpret_cast<cf*>(dst + off), q);
                 COMMS_TRY(launch_ok("fft_tile_kernel"));
             }
         } else {
@@ -414,9 +432,9 @@ static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size
             p.n_tiles = batch * p.tiles_per_xform;
             unsigned blocks = static_cast<unsigned>(p.n_tiles < 4u * kNumCU ? p.n_tiles : 4u * kNumCU);
             if (inverse)
-                fft_tile_kernel<1><<<dim3(blocks), dim3(pl.threads[i]), pl.lds[i], s>>>(src, dst, p);
+                fft_tile_kernel<1><<<dim3(blocks), dim3(pl.threads[i]), pl.lds[i], s>>>(reinterpret_cast<const cf*>(src), reinterpret_cast<cf*>(dst), p);
             else
-                fft_tile_kernel<-1><<<dim3(blocks), dim3(pl.threads[i]), pl.lds[i], s>>>(src, dst, p);
+                fft_tile_kernel<-1><<<dim3(blocks), dim3(pl.threads[i]), pl.lds[i], s>>>(reinterpret_cast<const cf*>(src), reinterpret_cast<cf*>(dst), p);
             COMMS_TRY(launch_ok("fft_tile_kernel"));
         }
     }
@@ -559,7 +577,8 @@ comms_status_t comms_fft_run_dev(comms_fft_t* h, const comms_c32* d_in, size_t n
         COMMS_ARG(!ranges_overlap(d_in, n * 8, d_out, n * 8) , "this fft_size cannot run in place");
         unsigned blocks = static_cast<unsigned>(batch < 4u * kNumCU ? batch : 4u * kNumCU);
         dft_direct_kernel<<<dim3(blocks), dim3(256), 2 * h->N * sizeof(float2), s>>>(
-            in, o, static_cast<int>(h->N), batch, h->d_twN, h->inverse ? 1 : 0);
+            reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(o), static_cast<int>(h->N), batch,
+            reinterpret_cast<const cf*>(h->d_twN), h->inverse ? 1 : 0);
         return launch_ok("dft_direct_kernel");
     }
     // Bluestein, in chunks that bound the work buffer
@@ -573,13 +592,13 @@ comms_status_t comms_fft_run_dev(comms_fft_t* h, const comms_c32* d_in, size_t n
     float2* sc = static_cast<float2*>(h->work2.p);
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = batch - b0 < chunk ? batch - b0 : chunk;
-        blu_pre_kernel<<<dim3(4 * kNumCU), dim3(256), 0, s>>>(in + b0 * h->N, h->d_chirp, a, h->N, M, nb);
+        blu_pre_kernel<<<dim3(4 * kNumCU), dim3(256), 0, s>>>(reinterpret_cast<const cf*>(in + b0 * h->N), reinterpret_cast<const cf*>(h->d_chirp), reinterpret_cast<cf*>(a), h->N, M, nb);
         COMMS_TRY(launch_ok("blu_pre_kernel"));
         COMMS_TRY(pow2_run(h->plan, a, a, nb, false, s, sc));
-        blu_mul_kernel<<<dim3(4 * kNumCU), dim3(256), 0, s>>>(a, h->d_bspec, M, nb);
+        blu_mul_kernel<<<dim3(4 * kNumCU), dim3(256), 0, s>>>(reinterpret_cast<cf*>(a), reinterpret_cast<const cf*>(h->d_bspec), M, nb);
         COMMS_TRY(launch_ok("blu_mul_kernel"));
         COMMS_TRY(pow2_run(h->plan, a, a, nb, true, s, sc));
-        blu_post_kernel<<<dim3(4 * kNumCU), dim3(256), 0, s>>>(a, h->d_chirp, o + b0 * h->N, h->N, M, nb);
+        blu_post_kernel<<<dim3(4 * kNumCU), dim3(256), 0, s>>>(reinterpret_cast<const cf*>(a), reinterpret_cast<const cf*>(h->d_chirp), reinterpret_cast<cf*>(o + b0 * h->N), h->N, M, nb);
         COMMS_TRY(launch_ok("blu_post_kernel"));
     }
     return COMMS_OK;

@@ -178,18 +178,19 @@ constexpr int OS_S2 = 18;   // [row][16 + 2]: 144-B rows, conflict-free ds_read_
 constexpr int OS_LDS = 4608;
 
 struct OsTables {
-    const float2* tw1;   // [16][256]  W4096^{t*k0}
-    const float2* tw2;   // [16][16]   W256^{lo*j}, index [j][lo]
-    const float2* hdev;  // [16][256]  H[k0 + 16*k1 + 256*k2] / 4096 at [k2][16*k0 + k1]
+    const cf* tw1;   // [16][256]  W4096^{t*k0}
+    const cf* tw2;   // [16][16]   W256^{lo*j}, index [j][lo]
+    const cf* hdev;  // [16][256]  H[k0 + 16*k1 + 256*k2] / 4096 at [k2][16*k0 + k1]
 };
 
-__device__ __forceinline__ void lds_read16_contig(const float2* __restrict__ p, float2 (&v)[16]) {
-    const float4* r = reinterpret_cast<const float4*>(p);
+typedef float cf2 __attribute__((ext_vector_type(4)));  // two packed complex values (16 B)
+__device__ __forceinline__ void lds_read16_contig(const cf* __restrict__ p, cf (&v)[16]) {
+    const cf2* r = reinterpret_cast<const cf2*>(p);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        float4 x = r[j];
-        v[2 * j] = make_float2(x.x, x.y);
-        v[2 * j + 1] = make_float2(x.z, x.w);
+        const cf2 x = r[j];
+        v[2 * j] = cf{x.x, x.y};
+        v[2 * j + 1] = cf{x.z, x.w};
     }
 }
 
@@ -198,25 +199,25 @@ __global__ __launch_bounds__(256, 2) void fir_os4096_kernel(const float2* __rest
                                                             int hist_len, float2* __restrict__ out,
                                                             size_t n, int hblk, size_t nseg,
                                                             OsTables tb, float2* __restrict__ new_hist) {
-    __shared__ __attribute__((aligned(16))) float2 lds[OS_LDS + 256];
+    __shared__ __attribute__((aligned(16))) cf lds[OS_LDS + 256];
     const int t = threadIdx.x;
     hist_advance(hist, in, n, new_hist, hist_len);
     const int hi = t >> 4, lo = t & 15;
 
     // persistent per-lane constants: stage-1 twiddles and the filter spectrum in
     // VGPRs, the 16x16 stage-2 twiddle table in LDS (read as tw2[j*16 + lo])
-    float2 tw1r[16], hr[16];
+    cf tw1r[16], hr[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         tw1r[j] = tb.tw1[j * 256 + t];
         hr[j] = tb.hdev[j * 256 + t];
     }
-    float2* tw2 = lds + OS_LDS;
+    cf* tw2 = lds + OS_LDS;
     tw2[t] = tb.tw2[t];
 
     const int H = 256 * hblk;
     const int V = OSF - H;
-    float2 v[16];
+    cf v[16];
 
     // workgroup b of the persistent grid owns segments [b*nseg/G, (b+1)*nseg/G)
     const size_t seg_lo = static_cast<size_t>(blockIdx.x) * nseg / gridDim.x;
@@ -227,16 +228,16 @@ __global__ __launch_bounds__(256, 2) void fir_os4096_kernel(const float2* __rest
         const bool interior = base >= 0 && static_cast<size_t>(base) + OSF <= n;
         if (interior) {
 #pragma unroll
-            for (int a = 0; a < 16; ++a) v[a] = in[base + 256 * a + t];
+            for (int a = 0; a < 16; ++a) v[a] = to_cf(in[base + 256 * a + t]);
         } else {
 #pragma unroll
-            for (int a = 0; a < 16; ++a) v[a] = stream_at(in, hist, hist_len, base + 256 * a + t, n);
+            for (int a = 0; a < 16; ++a) v[a] = to_cf(stream_at(in, hist, hist_len, base + 256 * a + t, n));
         }
         radix16<-1>(v);
         __syncthreads();  // previous segment's last LDS reads are done
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            float2 x = v[R16_POS(k)];
+            cf x = v[R16_POS(k)];
             if (k) x = cmulf(x, tw1r[k]);
             lds[k * OS_S1 + t] = x;
         }
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void fir_os4096_kernel(const float2* __rest
         radix16<-1>(v);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            float2 x = v[R16_POS(k)];
+            cf x = v[R16_POS(k)];
             if (k) x = cmulf(x, tw2[k * 16 + lo]);
             lds[(hi * 16 + k) * OS_S2 + lo] = x;
         }
@@ -258,13 +259,13 @@ __global__ __launch_bounds__(256, 2) void fir_os4096_kernel(const float2* __rest
         __syncthreads();
         radix16<-1>(v);
         // ---- spectrum multiply (1/4096 folded into hr) and inverse stage 3': over k2 -> c
-        float2 w[16];
+        cf w[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) w[k] = cmulf(v[R16_POS(k)], hr[k]);
         radix16<1>(w);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            float2 x = w[R16_POS(c)];
+            cf x = w[R16_POS(c)];
             if (c) x = cmulcf(x, tw2[c * 16 + lo]);
             lds[hi * 288 + c * OS_S2 + lo] = x;  // [k0][c][k1]
         }
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void fir_os4096_kernel(const float2* __rest
         // ---- inverse stage 1': lane (b,c) = t: over k0 -> a
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            float2 x = lds[k * OS_S1 + t];
+            cf x = lds[k * OS_S1 + t];
             v[k] = k ? cmulcf(x, tw1r[k]) : x;
         }
         radix16<1>(v);
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void fir_os4096_kernel(const float2* __rest
         for (int a = 1; a < 16; ++a) {
             if (a >= hblk) {
                 size_t o = obase + static_cast<size_t>(256 * (a - hblk));
-                if (o < n) out[o] = v[R16_POS(a)];
+                if (o < n) out[o] = to_f2(v[R16_POS(a)]);
             }
         }
     }
@@ -314,9 +315,9 @@ constexpr int W_P = 272;
 constexpr int W_LDS = 4 * W_P;  // 1088 >= 16*66
 
 struct WTables {
-    const float2* tw1;   // [16][64]  W1024^{lane*k0}
-    const float2* tw2;   // [16][4]   W64^{c*k1}, index [k1][c]
-    const float2* hdev;  // [16][64]  H[k0 + 16 k1 + 256 k2]/1024 at [4j + k2][lane], k1 = lane&15, k0 = (lane>>4) + 4j
+    const cf* tw1;   // [16][64]  W1024^{lane*k0}
+    const cf* tw2;   // [16][4]   W64^{c*k1}, index [k1][c]
+    const cf* hdev;  // [16][64]  H[k0 + 16 k1 + 256 k2]/1024 at [4j + k2][lane], k1 = lane&15, k0 = (lane>>4) + 4j
 };
 
 // Optional stages fused around the 1024-point overlap-save FIR (comms_chain_*):
@@ -326,6 +327,7 @@ struct WTables {
 // evaluates it once per run with an f64 sincos, advances it per segment with one f64
 // rotor, and reaches the 16 rows of a segment with the wave-uniform f32 rotors
 // step_a[a] = e^{i*64a*dphi}.
+constexpr int CH_STAMP = 16;  // diagnostic: per-phase cycle stamps into fm_prev_new (scripts/stamp_fir.py)
 constexpr int CH_PRE = COMMS_CHAIN_PRE, CH_POST = COMMS_CHAIN_POST, CH_DEC = COMMS_CHAIN_DEC, CH_FM = COMMS_CHAIN_FM;
 struct ChainArgs {
     uint64_t turns0, frac;
@@ -333,6 +335,7 @@ struct ChainArgs {
     float2 step_a[16];        // e^{i*64a*dphi}
     unsigned rate;            // decimation rate (>= 1)
     unsigned q_a[16], r_a[16];  // (64*(a-4)) / rate and % rate for a = 4..15
+    unsigned q_seg, r_seg;      // 768 / rate and 768 % rate
     const float2* fm_prev;    // FM.prev before this call
     float2* fm_prev_new;      //   ... and after it (ping-pong)
 };
@@ -355,6 +358,21 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The 12 new 64-sample rows of the segment that starts at sample nb (zeros past the end)
+__device__ __forceinline__ void load_rows(const float2* __restrict__ in, size_t nb, int l, size_t n,
+                                          cf (&r)[12]) {
+    if (nb + WV <= n) {
+#pragma unroll
+        for (int a = 0; a < 12; ++a) r[a] = to_cf(in[nb + 64 * a + l]);
+    } else {
+#pragma unroll
+        for (int a = 0; a < 12; ++a) {
+            const size_t g = nb + 64 * a + l;
+            r[a] = g < n ? to_cf(in[g]) : cf{0.f, 0.f};
+        }
+    }
+}
+
 // WPB waves per workgroup share the read-only tables in LDS (stage-1 twiddles,
 // filter spectrum, W64 table: 16.5 KiB); every wave has a private 8.5 KiB
 // exchange buffer and runs on its own -- no workgroup barrier after set-up.
@@ -369,12 +387,12 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
                                                                     ChainArgs ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     hist_advance(hist, in, n, new_hist, hist_len);
-    float2* tw1 = reinterpret_cast<float2*>(smem);  // [16][64]
-    float2* hsp = tw1 + 1024;                       // [16][64]
-    float2* tw2 = hsp + 1024;                       // [16][4]
+    cf* tw1 = reinterpret_cast<cf*>(smem);  // [16][64]
+    cf* hsp = tw1 + 1024;                       // [16][64]
+    cf* tw2 = hsp + 1024;                       // [16][4]
     const int l = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    float2* lds = tw2 + 64 + wave * W_LDS;          // this wave's exchange buffer
+    cf* lds = tw2 + 64 + wave * W_LDS;          // this wave's exchange buffer
     const int q0 = l & 15, q1 = l >> 4;  // stage 2: (k0, c) = (q0, q1); stage 3: k1 = q0, k0 = q1 + 4j
 
     for (int i = threadIdx.x; i < 1024; i += 64 * WPB) {
@@ -398,10 +416,24 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
         sincos(static_cast<double>(turns >> 11) * (kTwoPiF * 0x1.0p-53), &rot_s, &rot_c);
     }
 
-    float2 v[16], carry[4];
+    // diagnostic build only (MODE bit 4): cycle stamps per phase, summed per wave
+    unsigned long long st_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_prev = 0;
+#define OS_STAMP(i)                                                        \
+    if (MODE & CH_STAMP) {                                                 \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        \
+        const unsigned long long st_now = __builtin_amdgcn_s_memtime();    \
+        st_acc[i] += st_now - st_prev;                                     \
+        st_prev = st_now;                                                  \
+    }
+    if (MODE & CH_STAMP) st_prev = __builtin_amdgcn_s_memtime();
+
+    cf v[16], carry[4], nxt[12];
+    size_t dec_q = 0;
+    unsigned dec_r = 0;
     for (size_t seg = seg0; seg < seg1; ++seg) {
         const size_t nb = seg * WV;  // first new sample of this segment
-        float2 rot = make_float2(static_cast<float>(rot_c), static_cast<float>(rot_s));
+        cf rot = cf{static_cast<float>(rot_c), static_cast<float>(rot_s)};
         if (MODE & (CH_PRE | CH_POST)) {  // advance to the next segment's first row
             const double nc = rot_c * ch.seg_c - rot_s * ch.seg_s;
             rot_s = rot_c * ch.seg_s + rot_s * ch.seg_c;
@@ -410,55 +442,56 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
         if (seg == seg0) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                v[a] = stream_at(in, hist, hist_len, static_cast<long long>(nb) - 256 + 64 * a + l, n);
-                if (MODE & CH_PRE) v[a] = cmulf(v[a], a ? cmulf(rot, ch.step_a[a]) : rot);
+                v[a] = to_cf(stream_at(in, hist, hist_len, static_cast<long long>(nb) - 256 + 64 * a + l, n));
+                if (MODE & CH_PRE) v[a] = cmulf(v[a], a ? cmulf(rot, to_cf(ch.step_a[a])) : rot);
             }
         } else {
 #pragma unroll
             for (int a = 0; a < 4; ++a) v[a] = carry[a];
         }
-        if (nb + WV <= n) {
+        // (A register prefetch of the next segment's rows was tried and lost: vmcnt is one
+        // in-order counter for loads and stores, so the wait for prefetched rows also
+        // drains the previous segment's 12 stores -- 57.6 -> 65 us.)
+        load_rows(in, nb, l, n, nxt);
 #pragma unroll
-            for (int a = 4; a < 16; ++a) v[a] = in[nb + 64 * (a - 4) + l];
-        } else {
-#pragma unroll
-            for (int a = 4; a < 16; ++a) {
-                const size_t g = nb + 64 * (a - 4) + l;
-                v[a] = g < n ? in[g] : make_float2(0.f, 0.f);
-            }
-        }
+        for (int a = 4; a < 16; ++a) v[a] = nxt[a - 4];
         if (MODE & CH_PRE) {
 #pragma unroll
-            for (int a = 4; a < 16; ++a) v[a] = cmulf(v[a], cmulf(rot, ch.step_a[a]));
+            for (int a = 4; a < 16; ++a) v[a] = cmulf(v[a], cmulf(rot, to_cf(ch.step_a[a])));
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a) carry[a] = v[12 + a];
+        OS_STAMP(0)  // global loads landed
 
         // ---- forward
         radix16<-1>(v);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            float2 x = v[R16_POS(k)];
+            cf x = v[R16_POS(k)];
             if (k) x = cmulf(x, tw1[k * 64 + l]);
             lds[k * W_S1 + l] = x;
         }
         wave_lds_sync();
+        OS_STAMP(1)  // R16 + twiddle + exchange-1 writes
 #pragma unroll
         for (int b = 0; b < 16; ++b) v[b] = lds[q0 * W_S1 + 4 * b + q1];
         wave_lds_sync();
+        OS_STAMP(2)  // exchange-1 reads
         radix16<-1>(v);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            float2 x = v[R16_POS(k)];
+            cf x = v[R16_POS(k)];
             if (k) x = cmulf(x, tw2[k * 4 + q1]);
             lds[q1 * W_P + 17 * q0 + k] = x;
         }
         wave_lds_sync();
+        OS_STAMP(3)  // R16 + twiddle + exchange-2 writes
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[4 * j + c] = lds[c * W_P + 17 * (q1 + 4 * j) + q0];
         wave_lds_sync();
+        OS_STAMP(4)  // exchange-2 reads
         // ---- R4 over c -> k2, spectrum multiply, inverse R4 over k2 -> c
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -470,53 +503,67 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
             for (int c = 0; c < 4; ++c) lds[c * W_P + 17 * (q1 + 4 * j) + q0] = v[4 * j + c];
         }
         wave_lds_sync();
+        OS_STAMP(5)  // R4 + spectrum + R4 + exchange-3 writes
         // ---- inverse: lane (k0,c) = (q0,q1): conj W64^{c*k1}, R16 over k1 -> b
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            float2 x = lds[q1 * W_P + 17 * q0 + k];
+            cf x = lds[q1 * W_P + 17 * q0 + k];
             v[k] = k ? cmulcf(x, tw2[k * 4 + q1]) : x;
         }
         wave_lds_sync();
+        OS_STAMP(6)  // exchange-3 reads + twiddle
         radix16<1>(v);
 #pragma unroll
         for (int b = 0; b < 16; ++b) lds[q0 * W_S1 + 4 * b + q1] = v[R16_POS(b)];
         wave_lds_sync();
+        OS_STAMP(7)  // R16 + exchange-4 writes
         // ---- inverse: lane t: conj W1024^{t*k0}, R16 over k0 -> a
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            float2 x = lds[k * W_S1 + l];
+            cf x = lds[k * W_S1 + l];
             v[k] = k ? cmulcf(x, tw1[k * 64 + l]) : x;
         }
         wave_lds_sync();
+        OS_STAMP(8)  // exchange-4 reads + twiddle
         radix16<1>(v);
-        if (MODE == 0) {
+        if ((MODE & ~CH_STAMP) == 0) {
             if (nb + WV <= n) {
 #pragma unroll
-                for (int a = 4; a < 16; ++a) out[nb + 64 * (a - 4) + l] = v[R16_POS(a)];
+                for (int a = 4; a < 16; ++a) out[nb + 64 * (a - 4) + l] = to_f2(v[R16_POS(a)]);
             } else {
 #pragma unroll
                 for (int a = 4; a < 16; ++a) {
                     const size_t o = nb + 64 * (a - 4) + l;
-                    if (o < n) out[o] = v[R16_POS(a)];
+                    if (o < n) out[o] = to_f2(v[R16_POS(a)]);
                 }
             }
         } else {
             if (MODE & CH_POST) {
 #pragma unroll
                 for (int a = 4; a < 16; ++a)
-                    v[R16_POS(a)] = cmulf(v[R16_POS(a)], cmulf(rot, ch.step_a[a]));
+                    v[R16_POS(a)] = cmulf(v[R16_POS(a)], cmulf(rot, to_cf(ch.step_a[a])));
             }
             // FM needs y[idx - rate]: lane l - rate of the same row, or the tail of row a-1
             const int src = (l - static_cast<int>(ch.rate)) & 63;
             float2 sh_prev = make_float2(0.f, 0.f);
             if (MODE & CH_FM) {
-                const float2 y3 = v[R16_POS(3)];
+                const float2 y3 = to_f2(v[R16_POS(3)]);
                 sh_prev = make_float2(__shfl(y3.x, src), __shfl(y3.y, src));
             }
             // idx = nb + 64(a-4) + l; kept when idx % rate == 0, written at idx / rate
-            const size_t base = nb + l;
-            const size_t q0 = base / ch.rate;
-            const unsigned r0 = static_cast<unsigned>(base - q0 * ch.rate);
+            // (nb + l) / rate and % rate: one 64-bit division per run, then per-segment increments
+            if (seg == seg0) {
+                dec_q = (nb + l) / ch.rate;
+                dec_r = static_cast<unsigned>((nb + l) - dec_q * ch.rate);
+            }
+            const size_t q0 = dec_q;
+            const unsigned r0 = dec_r;
+            dec_q += ch.q_seg;
+            dec_r += ch.r_seg;
+            if (dec_r >= ch.rate) {
+                dec_r -= ch.rate;
+                ++dec_q;
+            }
 #pragma unroll
             for (int a = 4; a < 16; ++a) {
                 unsigned r = r0 + ch.r_a[a];
@@ -528,13 +575,13 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
                 const size_t idx = nb + 64 * (a - 4) + l;
                 float2 sh_cur = make_float2(0.f, 0.f);
                 if (MODE & CH_FM) {
-                    const float2 ya = v[R16_POS(a)];
+                    const float2 ya = to_f2(v[R16_POS(a)]);
                     sh_cur = make_float2(__shfl(ya.x, src), __shfl(ya.y, src));
                 }
                 const float2 p_row = l >= static_cast<int>(ch.rate) ? sh_cur : sh_prev;
                 sh_prev = sh_cur;
                 if (r == 0 && idx < n) {
-                    const float2 y = v[R16_POS(a)];
+                    const float2 y = to_f2(v[R16_POS(a)]);
                     if (MODE & CH_FM) {
                         float2 p = p_row;
                         if (idx == 0) p = ch.fm_prev[0];
@@ -546,7 +593,13 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
                 }
             }
         }
+        OS_STAMP(9)  // R16 + stores retired
     }
+    if (MODE & CH_STAMP) {
+        if (l == 0 && run < n_runs)
+            for (int i = 0; i < 10; ++i) reinterpret_cast<unsigned long long*>(ch.fm_prev_new)[run * 10 + i] = st_acc[i];
+    }
+#undef OS_STAMP
 }
 
 // ---------------------------------------------------------------- pulse shaping (polyphase)
@@ -623,6 +676,39 @@ static void free_fir(comms_fir* h) {
     if (h->d_hist[1]) (void)hipFree(h->d_hist[1]);
     h->fini();
     delete h;
+}
+
+// One launch of fir_os1024_kernel<.., MODE>: 16-wave workgroups (one per CU, 156 KiB of
+// LDS: shared tables + 16 private exchange buffers) by default, 4-wave workgroups
+// (three per CU) with COMMS_OS1024_WPB=4.
+template <int MODE>
+static comms_status_t launch_os1024(int wpb, size_t runs, hipStream_t s, const float2* in, const float2* hist,
+                                    int n_eff, float2* o, size_t n, size_t nseg, const comms::WTables& tb,
+                                    float2* nh, const comms::ChainArgs& ch) {
+    using namespace comms;
+    if (wpb == 16) {
+        const size_t lds = (2112 + 16 * W_LDS) * sizeof(float2);
+        static bool attr_set = false;
+        if (!attr_set) {
+            COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os1024_kernel<16, 4, MODE>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+            attr_set = true;
+        }
+        fir_os1024_kernel<16, 4, MODE><<<dim3(static_cast<unsigned>((runs + 15) / 16)), dim3(1024), lds, s>>>(
+            in, hist, n_eff, o, n, nseg, runs, tb, nh, ch);
+    } else {
+        const size_t lds = (2112 + 4 * W_LDS) * sizeof(float2);
+        fir_os1024_kernel<4, 3, MODE><<<dim3(static_cast<unsigned>((runs + 3) / 4)), dim3(256), lds, s>>>(
+            in, hist, n_eff, o, n, nseg, runs, tb, nh, ch);
+    }
+    return COMMS_OK;
+}
+static size_t os1024_runs(int wpb, size_t nseg, size_t min_run) {
+    // persistent: every wave slot of the chip gets one run (fewer for short inputs, where a
+    // run is at least min_run segments to amortise its halo load)
+    size_t runs = static_cast<size_t>(wpb == 16 ? 16 : 12) * comms::kNumCU;
+    if (runs * min_run > nseg) runs = (nseg + min_run - 1) / min_run;
+    return runs;
 }
 
 static const double kPi = 3.14159265358979323846264338327950288;
@@ -882,32 +968,12 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
         COMMS_TRY(fir_prepare_os1024(h));
         const size_t nseg = (n + WV - 1) / WV;
         // one wave per run of consecutive segments
-        static const int wpb = tune_int("COMMS_OS1024_WPB", 4);  // waves per workgroup: 4 or 16
+        static const int wpb = tune_int("COMMS_OS1024_WPB", 16);
         static const int min_run = tune_int("COMMS_OS1024_MINRUN", 4);
-        // persistent: every wave slot of the chip gets one run (fewer for short inputs,
-        // where a run is at least min_run segments to amortise its halo load)
-        const size_t waves_per_cu = wpb == 16 ? 16 : 12;
-        size_t runs = waves_per_cu * kNumCU;
-        if (runs * min_run > nseg) runs = (nseg + min_run - 1) / min_run;
-        const size_t per = 0;
-        (void)per;
-        WTables tb{h->d_wtw1, h->d_wtw2, h->d_whdev};
+        const size_t runs = os1024_runs(wpb, nseg, min_run);
+        WTables tb{reinterpret_cast<const cf*>(h->d_wtw1), reinterpret_cast<const cf*>(h->d_wtw2), reinterpret_cast<const cf*>(h->d_whdev)};
         h->tic(s);
-        if (wpb == 16) {
-            const size_t lds = (2112 + 16 * W_LDS) * sizeof(float2);
-            static bool attr16 = false;
-            if (!attr16) {
-                COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os1024_kernel<16, 4, 0>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-                attr16 = true;
-            }
-            fir_os1024_kernel<16, 4, 0><<<dim3(static_cast<unsigned>((runs + 15) / 16)), dim3(1024), lds, s>>>(
-                in, hist, h->n_eff, o, n, nseg, runs, tb, nh, ChainArgs{});
-        } else {
-            const size_t lds = (2112 + 4 * W_LDS) * sizeof(float2);
-            fir_os1024_kernel<4, 3, 0><<<dim3(static_cast<unsigned>((runs + 3) / 4)), dim3(256), lds, s>>>(
-                in, hist, h->n_eff, o, n, nseg, runs, tb, nh, ChainArgs{});
-        }
+        COMMS_TRY(launch_os1024<0>(wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}));
         h->toc(s);
         COMMS_TRY(launch_ok("fir_os1024_kernel"));
     } else {
@@ -917,7 +983,7 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
         // persistent grid: 2 workgroups per CU, segments split evenly
         const size_t slots = 2 * kNumCU;
         const unsigned blocks = static_cast<unsigned>(nseg < slots ? nseg : slots);
-        OsTables tb{h->d_tw1, h->d_tw2, h->d_hdev};
+        OsTables tb{reinterpret_cast<const cf*>(h->d_tw1), reinterpret_cast<const cf*>(h->d_tw2), reinterpret_cast<const cf*>(h->d_hdev)};
         h->tic(s);
         fir_os4096_kernel<<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh);
         h->toc(s);
@@ -1001,27 +1067,30 @@ comms_status_t comms_fir_run_fused_dev(comms_fir_t* h, const comms_c32* d_in, si
         ch.r_a[a] = off % rate;
     }
     ch.rate = rate;
+    ch.q_seg = WV / rate;
+    ch.r_seg = WV % rate;
     ch.fm_prev = static_cast<const float2*>(fm_prev);
     ch.fm_prev_new = static_cast<float2*>(fm_prev_new);
     const size_t nseg = (n + WV - 1) / WV;
-    size_t runs = 12 * static_cast<size_t>(kNumCU);
-    if (runs * 4 > nseg) runs = (nseg + 3) / 4;
-    WTables tb{h->d_wtw1, h->d_wtw2, h->d_whdev};
-    const size_t lds = (2112 + 4 * W_LDS) * sizeof(float2);
-    const dim3 grid(static_cast<unsigned>((runs + 3) / 4)), block(256);
+    static const int wpb = tune_int("COMMS_OS1024_WPB", 16);
+    const size_t runs = os1024_runs(wpb, nseg, 4);
+    WTables tb{reinterpret_cast<const cf*>(h->d_wtw1), reinterpret_cast<const cf*>(h->d_wtw2), reinterpret_cast<const cf*>(h->d_whdev)};
     h->tic(s);
     switch (mode) {
         case CH_PRE | CH_DEC:
-            fir_os1024_kernel<4, 3, CH_PRE | CH_DEC><<<grid, block, lds, s>>>(in, hist, h->n_eff, o, n, nseg, runs, tb, nh, ch);
+            COMMS_TRY(launch_os1024<CH_PRE | CH_DEC>(wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ch));
             break;
         case CH_PRE | CH_DEC | CH_FM:
-            fir_os1024_kernel<4, 3, CH_PRE | CH_DEC | CH_FM><<<grid, block, lds, s>>>(in, hist, h->n_eff, o, n, nseg, runs, tb, nh, ch);
+            COMMS_TRY(launch_os1024<CH_PRE | CH_DEC | CH_FM>(wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ch));
             break;
         case CH_POST | CH_DEC:
-            fir_os1024_kernel<4, 3, CH_POST | CH_DEC><<<grid, block, lds, s>>>(in, hist, h->n_eff, o, n, nseg, runs, tb, nh, ch);
+            COMMS_TRY(launch_os1024<CH_POST | CH_DEC>(wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ch));
             break;
         case CH_POST | CH_DEC | CH_FM:
-            fir_os1024_kernel<4, 3, CH_POST | CH_DEC | CH_FM><<<grid, block, lds, s>>>(in, hist, h->n_eff, o, n, nseg, runs, tb, nh, ch);
+            COMMS_TRY(launch_os1024<CH_POST | CH_DEC | CH_FM>(wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ch));
+            break;
+        case CH_STAMP:  // diagnostic build: 4-wave workgroups, stamps into fm_prev_new
+            COMMS_TRY(launch_os1024<CH_STAMP>(4, os1024_runs(4, nseg, 4), s, in, hist, h->n_eff, o, n, nseg, tb, nh, ch));
             break;
         default:
             return fail(COMMS_ERR_ARG, "unsupported fused mode %d", mode);
