@@ -198,10 +198,11 @@ __global__ __launch_bounds__(256, 2) void fir_os4096_kernel(const float2* __rest
                                                             const float2* __restrict__ hist,
                                                             int hist_len, float2* __restrict__ out,
                                                             size_t n, int hblk, size_t nseg,
-                                                            OsTables tb, float2* __restrict__ new_hist) {
+                                                            OsTables tb, float2* __restrict__ new_hist,
+                                                            int delay, int accumulate) {
     __shared__ __attribute__((aligned(16))) cf lds[OS_LDS + 256];
     const int t = threadIdx.x;
-    hist_advance(hist, in, n, new_hist, hist_len);
+    if (!accumulate) hist_advance(hist, in, n, new_hist, hist_len);  // once per call (first partition)
     const int hi = t >> 4, lo = t & 15;
 
     // persistent per-lane constants: stage-1 twiddles and the filter spectrum in
@@ -223,7 +224,8 @@ __global__ __launch_bounds__(256, 2) void fir_os4096_kernel(const float2* __rest
     const size_t seg_lo = static_cast<size_t>(blockIdx.x) * nseg / gridDim.x;
     const size_t seg_hi = static_cast<size_t>(blockIdx.x + 1) * nseg / gridDim.x;
     for (size_t seg = seg_lo; seg < seg_hi; ++seg) {
-        const long long base = static_cast<long long>(seg) * V - H;
+        // partition p of a long filter sees the stream delayed by p*2049 samples
+        const long long base = static_cast<long long>(seg) * V - H - delay;
         // ---- forward stage 1: lane (b,c) = t holds x[256a + t]; DFT over a -> k0
         const bool interior = base >= 0 && static_cast<size_t>(base) + OSF <= n;
         if (interior) {
@@ -290,7 +292,11 @@ __global__ __launch_bounds__(256, 2) void fir_os4096_kernel(const float2* __rest
         for (int a = 1; a < 16; ++a) {
             if (a >= hblk) {
                 size_t o = obase + static_cast<size_t>(256 * (a - hblk));
-                if (o < n) out[o] = to_f2(v[R16_POS(a)]);
+                if (o < n) {
+                    cf y = v[R16_POS(a)];
+                    if (accumulate) y = y + to_cf(out[o]);
+                    out[o] = to_f2(y);
+                }
             }
         }
     }
@@ -653,7 +659,9 @@ struct comms_fir : Handle {
     float2* d_whdev = nullptr;
     // overlap-save, F = 4096 (workgroup per segment)
     bool os_ready = false;
-    int hblk = 0;        // halo = 256*hblk >= n_eff-1
+    int hblk = 0;        // halo = 256*hblk >= (taps per partition) - 1
+    int n_part = 1;      // > 3841 taps: partitions of OS_PART taps, each one pass of the 4096-pt kernel
+    std::vector<float2*> d_hparts;  // filter spectrum per partition (d_hdev = partition 0)
     float2* d_tw1 = nullptr;
     float2* d_tw2 = nullptr;
     float2* d_hdev = nullptr;
@@ -671,7 +679,8 @@ static void free_fir(comms_fir* h) {
     if (h->d_whdev) (void)hipFree(h->d_whdev);
     if (h->d_tw1) (void)hipFree(h->d_tw1);
     if (h->d_tw2) (void)hipFree(h->d_tw2);
-    if (h->d_hdev) (void)hipFree(h->d_hdev);
+    for (float2* q : h->d_hparts)
+        if (q) (void)hipFree(q);
     if (h->d_hist[0]) (void)hipFree(h->d_hist[0]);
     if (h->d_hist[1]) (void)hipFree(h->d_hist[1]);
     h->fini();
@@ -713,6 +722,12 @@ static size_t os1024_runs(int wpb, size_t nseg, size_t min_run) {
 
 static const double kPi = 3.14159265358979323846264338327950288;
 
+static float2 unit_root_os(long long e, int denom) {
+    e %= denom;
+    const double a = -2.0 * kPi * static_cast<double>(e) / denom;
+    return make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
+}
+
 // Tuning knobs read once from the environment (scripts/bench_fir.py sweeps them).
 static int tune_int(const char* name, int dflt) {
     const char* v = getenv(name);
@@ -721,59 +736,54 @@ static int tune_int(const char* name, int dflt) {
 
 // Filter spectrum + twiddle tables for the 4096-point overlap-save kernel (f64 on
 // the host, rounded once to f32).
+constexpr int OS_PART = 2049;  // taps per partition of a long filter: halo 2048, 2048 outputs per segment
+
+static void tap_spectrum_range(const comms_fir* h, int first, int count, int F, std::vector<double>& re,
+                               std::vector<double>& im);
+
 static comms_status_t fir_prepare_os(comms_fir* h) {
     if (h->os_ready) return COMMS_OK;
     const int N = h->n_eff;
-    COMMS_ARG(N - 1 <= 15 * 256, "overlap-save (F=4096) supports at most 3841 taps, got %d", N);
-    h->hblk = (N - 1 + 255) / 256;
+    int per = N;
+    h->n_part = 1;
+    if (N > 3841) {  // partitioned convolution: y = sum_p FIR(taps[p*P .. ), x delayed by p*P)
+        per = OS_PART;
+        h->n_part = (N + OS_PART - 1) / OS_PART;
+    }
+    h->hblk = (per - 1 + 255) / 256;
     if (h->hblk < 1) h->hblk = 1;
     std::vector<float2> tw1(16 * 256), tw2(16 * 16), hdev(16 * 256);
     for (int k0 = 0; k0 < 16; ++k0)
-        for (int t = 0; t < 256; ++t) {
-            int e = (t * k0) % OSF;
-            double a = -2.0 * kPi * static_cast<double>(e) / OSF;
-            tw1[k0 * 256 + t] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
-        }
+        for (int t = 0; t < 256; ++t) tw1[k0 * 256 + t] = unit_root_os(static_cast<long long>(t) * k0, OSF);
     for (int j = 0; j < 16; ++j)
-        for (int lo = 0; lo < 16; ++lo) {
-            int e = (lo * j) % 256;
-            double a = -2.0 * kPi * static_cast<double>(e) / 256.0;
-            tw2[j * 16 + lo] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
-        }
-    // H[k] = sum_j taps[j] e^{-2 pi i jk/4096}, exact-index twiddles
-    std::vector<double> cs(OSF), sn(OSF);
-    for (int e = 0; e < OSF; ++e) {
-        double a = -2.0 * kPi * static_cast<double>(e) / OSF;
-        cs[e] = std::cos(a);
-        sn[e] = std::sin(a);
-    }
-    for (int k = 0; k < OSF; ++k) {
-        double re = 0, im = 0;
-        int e = 0;
-        for (int j = 0; j < N; ++j) {
-            double tr = h->taps[j].re, ti = h->taps[j].im;
-            re += tr * cs[e] - ti * sn[e];
-            im += tr * sn[e] + ti * cs[e];
-            e += k;
-            if (e >= OSF) e -= OSF;
-        }
-        int k0 = k & 15, k1 = (k >> 4) & 15, k2 = k >> 8;
-        hdev[k2 * 256 + 16 * k0 + k1] =
-            make_float2(static_cast<float>(re / OSF), static_cast<float>(im / OSF));
-    }
+        for (int lo = 0; lo < 16; ++lo) tw2[j * 16 + lo] = unit_root_os(lo * j, 256);
     COMMS_HIP_TRY(hipMalloc(&h->d_tw1, tw1.size() * sizeof(float2)));
     COMMS_HIP_TRY(hipMalloc(&h->d_tw2, tw2.size() * sizeof(float2)));
-    COMMS_HIP_TRY(hipMalloc(&h->d_hdev, hdev.size() * sizeof(float2)));
     COMMS_HIP_TRY(hipMemcpy(h->d_tw1, tw1.data(), tw1.size() * sizeof(float2), hipMemcpyHostToDevice));
     COMMS_HIP_TRY(hipMemcpy(h->d_tw2, tw2.data(), tw2.size() * sizeof(float2), hipMemcpyHostToDevice));
-    COMMS_HIP_TRY(hipMemcpy(h->d_hdev, hdev.data(), hdev.size() * sizeof(float2), hipMemcpyHostToDevice));
+    std::vector<double> re, im;
+    for (int pt = 0; pt < h->n_part; ++pt) {
+        const int first = pt * per;
+        const int count = N - first < per ? N - first : per;
+        tap_spectrum_range(h, first, count, OSF, re, im);
+        for (int k = 0; k < OSF; ++k) {
+            const int k0 = k & 15, k1 = (k >> 4) & 15, k2 = k >> 8;
+            hdev[k2 * 256 + 16 * k0 + k1] =
+                make_float2(static_cast<float>(re[k] / OSF), static_cast<float>(im[k] / OSF));
+        }
+        float2* d = nullptr;
+        COMMS_HIP_TRY(hipMalloc(&d, hdev.size() * sizeof(float2)));
+        h->d_hparts.push_back(d);
+        COMMS_HIP_TRY(hipMemcpy(d, hdev.data(), hdev.size() * sizeof(float2), hipMemcpyHostToDevice));
+    }
+    h->d_hdev = h->d_hparts[0];
     h->os_ready = true;
     return COMMS_OK;
 }
 
-
 // Spectrum of the effective taps zero-padded to F points (f64, exact-index twiddles).
-static void tap_spectrum(const comms_fir* h, int F, std::vector<double>& re, std::vector<double>& im) {
+static void tap_spectrum_range(const comms_fir* h, int first, int count, int F, std::vector<double>& re,
+                               std::vector<double>& im) {
     std::vector<double> cs(F), sn(F);
     for (int e = 0; e < F; ++e) {
         double a = -2.0 * kPi * static_cast<double>(e) / F;
@@ -785,8 +795,8 @@ static void tap_spectrum(const comms_fir* h, int F, std::vector<double>& re, std
     for (int k = 0; k < F; ++k) {
         double r = 0, i = 0;
         int e = 0;
-        for (int j = 0; j < h->n_eff; ++j) {
-            double tr = h->taps[j].re, ti = h->taps[j].im;
+        for (int j = 0; j < count; ++j) {
+            double tr = h->taps[first + j].re, ti = h->taps[first + j].im;
             r += tr * cs[e] - ti * sn[e];
             i += tr * sn[e] + ti * cs[e];
             e += k;
@@ -795,6 +805,10 @@ static void tap_spectrum(const comms_fir* h, int F, std::vector<double>& re, std
         re[k] = r;
         im[k] = i;
     }
+}
+
+static void tap_spectrum(const comms_fir* h, int F, std::vector<double>& re, std::vector<double>& im) {
+    tap_spectrum_range(h, 0, h->n_eff, F, re, im);
 }
 
 static comms_status_t upload_f2(const std::vector<float2>& v, float2** d) {
@@ -924,8 +938,7 @@ comms_status_t comms_fir_set_algo(comms_fir_t* h, int32_t algo) {
               "the 1024-point overlap-save kernel supports at most 257 taps");
     COMMS_ARG(algo != COMMS_FIR_DIRECT || h->n_eff <= DIRECT_MAX_TAPS,
               "direct-form FIR supports at most %d taps", DIRECT_MAX_TAPS);
-    COMMS_ARG((algo != COMMS_FIR_OVERLAP_SAVE && algo != COMMS_FIR_OS4096) || h->n_eff <= 3841,
-              "overlap-save (F=4096) supports at most 3841 taps");
+
     h->algo = algo;
     return COMMS_OK;
 }
@@ -983,9 +996,13 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
         // persistent grid: 2 workgroups per CU, segments split evenly
         const size_t slots = 2 * kNumCU;
         const unsigned blocks = static_cast<unsigned>(nseg < slots ? nseg : slots);
-        OsTables tb{reinterpret_cast<const cf*>(h->d_tw1), reinterpret_cast<const cf*>(h->d_tw2), reinterpret_cast<const cf*>(h->d_hdev)};
         h->tic(s);
-        fir_os4096_kernel<<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh);
+        for (int pt = 0; pt < h->n_part; ++pt) {
+            OsTables tb{reinterpret_cast<const cf*>(h->d_tw1), reinterpret_cast<const cf*>(h->d_tw2),
+                        reinterpret_cast<const cf*>(h->d_hparts[pt])};
+            fir_os4096_kernel<<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh,
+                                                                 pt * OS_PART, pt ? 1 : 0);
+        }
         h->toc(s);
         COMMS_TRY(launch_ok("fir_os4096_kernel"));
     }

@@ -128,6 +128,41 @@ def test_fir_short_and_long_user_state(c):
         fir_close(got, want, taps, x)
 
 
+@pytest.mark.parametrize("n_taps", [3842, 4097, 4098, 9000])
+def test_fir_long_filters_partitioned(c, n_taps):
+    # > 3841 taps: partitions of 2049 taps, one pass of the 4096-point kernel each (config 5's 4097 taps)
+    rng = np.random.default_rng(n_taps)
+    taps = (rand_c(rng, n_taps) / np.sqrt(n_taps)).astype(np.complex64)
+    x = rand_c(rng, 30000)
+    node = c.BatchFirNode(taps)
+    assert node.algo_for(x.size) == c.FIR_OS4096
+    st = oracle.default_state(taps)
+    for a, b in [(0, 5000), (5000, 5001), (5001, 30000)]:
+        want = oracle.batch_fir(x[a:b], taps, st, norotate=True)
+        fir_close(node.run(x[a:b]), want, taps, x)
+    assert np.array_equal(node.state(n_taps), st)
+
+
+def test_config5_4097_taps_windowed_sinc_long_stream(c):
+    """BASELINE config 5's filter (4097-tap windowed sinc) on one GPU's shard-sized slice
+    (2^22 here; the sharding itself is test_cpu_host's gloo test): oracle on windows."""
+    import torch
+
+    n = 1 << 22
+    k = np.arange(4097) - 2048
+    taps = (0.25 * np.sinc(0.25 * k) * np.hamming(4097)).astype(np.float32).astype(np.complex64)
+    x = torch.empty(n, dtype=torch.complex64, device="cuda:0")
+    y = torch.empty_like(x)
+    c.synth_iq_dev(x.data_ptr(), n, 0, 5)
+    c.BatchFirNode(taps).run_dev(x.data_ptr(), n, y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for a in (0, 2048, 100000, n - 3000):
+        lo = max(0, a - 4096)
+        xs = c.synth_iq(a + 3000 - lo, lo, 5)
+        want = oracle.batch_fir(xs, taps, oracle.default_state(taps), norotate=True)[a - lo:]
+        fir_close(y[a:a + 3000].cpu().numpy(), want, taps, xs)
+
+
 def test_fir_auto_selection_and_errors(c):
     taps = np.ones(255, np.complex64)
     node = c.BatchFirNode(taps)
