@@ -194,7 +194,8 @@ __device__ __forceinline__ void lds_read16_contig(const cf* __restrict__ p, cf (
     }
 }
 
-__global__ __launch_bounds__(256, 2) void fir_os4096_kernel(const float2* __restrict__ in,
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void fir_os4096_kernel(const float2* __restrict__ in,
                                                             const float2* __restrict__ hist,
                                                             int hist_len, float2* __restrict__ out,
                                                             size_t n, int hblk, size_t nseg,
@@ -993,15 +994,20 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
         COMMS_TRY(fir_prepare_os(h));
         const size_t V = OSF - 256 * static_cast<size_t>(h->hblk);
         const size_t nseg = (n + V - 1) / V;
-        // persistent grid: 2 workgroups per CU, segments split evenly
-        const size_t slots = 2 * kNumCU;
+        // persistent grid: WPS workgroups per CU (one wave of each per SIMD), segments split evenly
+        static const int wps = tune_int("COMMS_OS4096_WPS", 3);
+        const size_t slots = static_cast<size_t>(wps) * kNumCU;
         const unsigned blocks = static_cast<unsigned>(nseg < slots ? nseg : slots);
         h->tic(s);
         for (int pt = 0; pt < h->n_part; ++pt) {
             OsTables tb{reinterpret_cast<const cf*>(h->d_tw1), reinterpret_cast<const cf*>(h->d_tw2),
                         reinterpret_cast<const cf*>(h->d_hparts[pt])};
-            fir_os4096_kernel<<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh,
-                                                                 pt * OS_PART, pt ? 1 : 0);
+            if (wps == 4)
+                fir_os4096_kernel<4><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, pt * OS_PART, pt ? 1 : 0);
+            else if (wps == 3)
+                fir_os4096_kernel<3><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, pt * OS_PART, pt ? 1 : 0);
+            else
+                fir_os4096_kernel<2><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, pt * OS_PART, pt ? 1 : 0);
         }
         h->toc(s);
         COMMS_TRY(launch_ok("fir_os4096_kernel"));

@@ -1,0 +1,33 @@
+#!/bin/bash
+# HBM traffic of the bench's FIR kernel from rocprofv3 PMC counters: separate passes for
+# FETCH_SIZE and WRITE_SIZE (they do not fit one pass on gfx950), per-launch means.
+export TMPDIR=/tmp
+OUT=gpurun_out/traffic; mkdir -p $OUT
+for cnt in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 400 rocprofv3 --pmc $cnt --output-format csv -d $OUT/$cnt -o pmc -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/$cnt.log 2>&1 || { echo "$cnt pass failed"; tail -3 $OUT/$cnt.log; }
+done
+python3 - <<PY
+import csv, glob, json, collections
+vals = {}
+for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
+    acc = collections.defaultdict(list)
+    for f in glob.glob("$OUT/%s/*counter_collection.csv" % cnt):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == cnt:
+                acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    vals[cnt] = {k: sum(v) / len(v) for k, v in acc.items()}
+    for k, v in vals[cnt].items():
+        print("%-11s %-60s %.4g KiB/launch" % (cnt, k[:60], v))
+key = [k for k in vals["FETCH_SIZE"] if "fir_os1024_kernel<16, 4, 0>" in k or "fir_os1024_kernel<4, 3, 0>" in k]
+if key:
+    k = key[0]
+    fetch, write = vals["FETCH_SIZE"][k] * 1024.0, vals["WRITE_SIZE"][k] * 1024.0
+    d = {"kernel": "fir_os1024_kernel", "n_samples": 1 << 24,
+         "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
+         "hbm_bytes_per_launch": 2.0 * fetch + write,
+         "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 50`; "
+                 "counters are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of a "
+                 "wide coalesced streaming read); algorithmic bytes per launch = 268435456"}
+    json.dump(d, open("$OUT/pmc_traffic.json", "w"), indent=1)
+    print(json.dumps(d))
+PY
