@@ -68,6 +68,21 @@ constexpr int DTILE = 256 * DT;   // outputs per workgroup
 constexpr int DROW = 10;          // LDS row: 8 samples + 2 pad (80 B): conflict-free ds_read_b128
 constexpr int DIRECT_MAX_TAPS = 1024;
 
+// acc += h * x as packed-f32 FMAs on {re, im} pairs (see fft_radix.hpp for why by hand):
+//   real tap h: one v_pk_fma_f32, the tap picked from the lo / hi half of a register pair;
+//   complex tap: two, with the swizzle and the sign of -h.im*x.im in the modifiers.
+__device__ __forceinline__ void mac_real_lo(cf& acc, cf x, cf hp) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "v"(hp));
+}
+__device__ __forceinline__ void mac_real_hi(cf& acc, cf x, cf hp) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "v"(hp));
+}
+__device__ __forceinline__ void mac_cplx(cf& acc, cf h, cf x) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(h), "v"(x));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(acc) : "v"(h), "v"(x));
+}
+typedef float cf2 __attribute__((ext_vector_type(4)));  // two packed complex values (16 B)
+
 template <bool REAL_TAPS>
 __global__ __launch_bounds__(256) void fir_direct_kernel(const float2* __restrict__ in,
                                                          const float2* __restrict__ hist,
@@ -80,77 +95,75 @@ __global__ __launch_bounds__(256) void fir_direct_kernel(const float2* __restric
     const int t = threadIdx.x;
     hist_advance(hist, in, n, new_hist, hist_len);
     const int nrows = (DTILE + NP) / 8;
-    float2* xt = reinterpret_cast<float2*>(smem);
-    float2* tp = xt + nrows * DROW;  // taps (complex) or, if REAL_TAPS, NP floats
+    cf* xt = reinterpret_cast<cf*>(smem);
+    cf* tp = xt + nrows * DROW;  // taps (complex) or, if REAL_TAPS, NP floats
 
     const size_t o0 = static_cast<size_t>(blockIdx.x) * DTILE;
     if (REAL_TAPS) {
         float* tr = reinterpret_cast<float*>(tp);
         for (int k = t; k < NP; k += 256) tr[k] = taps_pad[k].x;
     } else {
-        for (int k = t; k < NP; k += 256) tp[k] = taps_pad[k];
+        for (int k = t; k < NP; k += 256) tp[k] = to_cf(taps_pad[k]);
     }
     const long long g0 = static_cast<long long>(o0) - NP;
     for (int q = t; q < DTILE + NP; q += 256)
-        xt[(q >> 3) * DROW + (q & 7)] = stream_at(in, hist, hist_len, g0 + q, n);
+        xt[(q >> 3) * DROW + (q & 7)] = to_cf(stream_at(in, hist, hist_len, g0 + q, n));
     __syncthreads();
 
-    float2 acc[DT];
+    cf acc[DT];
 #pragma unroll
-    for (int i = 0; i < DT; ++i) acc[i] = make_float2(0.f, 0.f);
+    for (int i = 0; i < DT; ++i) acc[i] = cf{0.f, 0.f};
 
-    float2 wh[8], wl[8];
+    cf wh[8], wl[8];
     {
-        const float4* r = reinterpret_cast<const float4*>(xt + (NP / 8 + t) * DROW);
+        const cf2* r = reinterpret_cast<const cf2*>(xt + (NP / 8 + t) * DROW);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float4 v = r[j];
-            wh[2 * j] = make_float2(v.x, v.y);
-            wh[2 * j + 1] = make_float2(v.z, v.w);
+            const cf2 v = r[j];
+            wh[2 * j] = cf{v.x, v.y};
+            wh[2 * j + 1] = cf{v.z, v.w};
         }
     }
     const int nchunks = NP / 8;
     for (int c = 0; c < nchunks; ++c) {
-        const float4* r = reinterpret_cast<const float4*>(xt + (NP / 8 + t - c - 1) * DROW);
+        const cf2* r = reinterpret_cast<const cf2*>(xt + (NP / 8 + t - c - 1) * DROW);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float4 v = r[j];
-            wl[2 * j] = make_float2(v.x, v.y);
-            wl[2 * j + 1] = make_float2(v.z, v.w);
+            const cf2 v = r[j];
+            wl[2 * j] = cf{v.x, v.y};
+            wl[2 * j + 1] = cf{v.z, v.w};
         }
         if (REAL_TAPS) {
-            const float4* hp = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(tp) + 8 * c);
-            float4 ha = hp[0], hb = hp[1];
-            const float h[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+            const cf2* hp = reinterpret_cast<const cf2*>(reinterpret_cast<const float*>(tp) + 8 * c);
+            const cf2 ha = hp[0], hb = hp[1];
+            const cf h[4] = {cf{ha.x, ha.y}, cf{ha.z, ha.w}, cf{hb.x, hb.y}, cf{hb.z, hb.w}};  // (h0,h1) (h2,h3) ...
 #pragma unroll
             for (int o = 0; o < DT; ++o) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int idx = 8 + o - j;
-                    const float2 x = idx >= 8 ? wh[idx - 8] : wl[idx];
-                    acc[o].x = __builtin_fmaf(h[j], x.x, acc[o].x);
-                    acc[o].y = __builtin_fmaf(h[j], x.y, acc[o].y);
+                    const cf x = idx >= 8 ? wh[idx - 8] : wl[idx];
+                    if (j & 1)
+                        mac_real_hi(acc[o], x, h[j >> 1]);
+                    else
+                        mac_real_lo(acc[o], x, h[j >> 1]);
                 }
             }
         } else {
-            const float4* hp = reinterpret_cast<const float4*>(tp + 8 * c);
-            float2 h[8];
+            const cf2* hp = reinterpret_cast<const cf2*>(tp + 8 * c);
+            cf h[8];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float4 v = hp[j];
-                h[2 * j] = make_float2(v.x, v.y);
-                h[2 * j + 1] = make_float2(v.z, v.w);
+                const cf2 v = hp[j];
+                h[2 * j] = cf{v.x, v.y};
+                h[2 * j + 1] = cf{v.z, v.w};
             }
 #pragma unroll
             for (int o = 0; o < DT; ++o) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int idx = 8 + o - j;
-                    const float2 x = idx >= 8 ? wh[idx - 8] : wl[idx];
-                    acc[o].x = __builtin_fmaf(h[j].x, x.x, acc[o].x);
-                    acc[o].x = __builtin_fmaf(-h[j].y, x.y, acc[o].x);
-                    acc[o].y = __builtin_fmaf(h[j].x, x.y, acc[o].y);
-                    acc[o].y = __builtin_fmaf(h[j].y, x.x, acc[o].y);
+                    mac_cplx(acc[o], h[j], idx >= 8 ? wh[idx - 8] : wl[idx]);
                 }
             }
         }
@@ -160,14 +173,13 @@ __global__ __launch_bounds__(256) void fir_direct_kernel(const float2* __restric
 
     const size_t ob = o0 + static_cast<size_t>(t) * DT;
     if (out_vec4 && ob + DT <= n) {
-        float4* o4 = reinterpret_cast<float4*>(out + ob);
+        cf2* o4 = reinterpret_cast<cf2*>(out + ob);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            o4[j] = make_float4(acc[2 * j].x, acc[2 * j].y, acc[2 * j + 1].x, acc[2 * j + 1].y);
+        for (int j = 0; j < 4; ++j) o4[j] = cf2{acc[2 * j].x, acc[2 * j].y, acc[2 * j + 1].x, acc[2 * j + 1].y};
     } else {
 #pragma unroll
         for (int j = 0; j < DT; ++j)
-            if (ob + j < n) out[ob + j] = acc[j];
+            if (ob + j < n) out[ob + j] = to_f2(acc[j]);
     }
 }
 
@@ -183,7 +195,6 @@ struct OsTables {
     const cf* hdev;  // [16][256]  H[k0 + 16*k1 + 256*k2] / 4096 at [k2][16*k0 + k1]
 };
 
-typedef float cf2 __attribute__((ext_vector_type(4)));  // two packed complex values (16 B)
 __device__ __forceinline__ void lds_read16_contig(const cf* __restrict__ p, cf (&v)[16]) {
     const cf2* r = reinterpret_cast<const cf2*>(p);
 #pragma unroll
@@ -867,13 +878,15 @@ static comms_status_t fir_prepare_direct(comms_fir* h) {
 static int fir_pick(const comms_fir* h, size_t n) {
     int algo = h->algo;
     if (algo == COMMS_FIR_AUTO) {
-        const int direct_limit = h->real_taps ? 48 : 24;
+        // measured on MI355X (2^24 samples): the 1024-point overlap-save kernel takes ~62 us for
+        // any tap count up to 257, the direct kernel 70 us at 16 taps and 88 us at 63 -- so the
+        // direct form is kept for very short filters and for calls too short to fill segments
         if (h->n_eff > DIRECT_MAX_TAPS)
             algo = COMMS_FIR_OVERLAP_SAVE;
-        else if (h->n_eff <= direct_limit)
+        else if (h->n_eff <= 8)
             algo = COMMS_FIR_DIRECT;
-        else if (n * static_cast<size_t>(h->n_eff) < (1u << 18))
-            algo = COMMS_FIR_DIRECT;  // a short call does not amortise FFT segments
+        else if (n * static_cast<size_t>(h->n_eff) < (1u << 18) || n < (1u << 14))
+            algo = COMMS_FIR_DIRECT;
         else
             algo = COMMS_FIR_OVERLAP_SAVE;
     }

@@ -1,2 +1,3 @@
 #!/bin/bash
-for w in 2 3 4; do echo "== WPS=$w"; COMMS_OS4096_WPS=$w ALGOS=os4096 timeout -k 5 120 python scripts/bench_fir.py 255 24 100 2>&1 | grep -v amdgpu.ids;  COMMS_OS4096_WPS=$w ALGOS=os4096 timeout -k 5 120 python scripts/bench_fir.py 1025 26 20 2>&1 | grep -v amdgpu.ids; done
+python -m pytest tests -m gpu -x -q -k "fir or pulse or config1 or golden" 2>&1 | tail -3
+for t in 16 32 63 64 127 255; do ALGOS=direct,os1024 timeout -k 5 120 python scripts/bench_fir.py $t 24 100 2>&1 | grep -v amdgpu.ids; done
