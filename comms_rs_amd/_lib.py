@@ -99,6 +99,12 @@ _PROTOS = {
     "comms_chain_run_dev": [_vp, _vp, _sz, _vp, _vp],
     "comms_chain_run": [_vp, _vp, _sz, _vp],
     "comms_chain_destroy": [_vp],
+    "comms_iq_i16_to_c32": [_vp, _sz, C.c_float, _vp, _i32],
+    "comms_iq_c32_to_i16": [_vp, _sz, C.c_float, _vp, _i32],
+    "comms_iq_u8_to_c32": [_vp, _sz, _vp, _i32],
+    "comms_iq_i16_to_c32_dev": [_vp, _sz, C.c_float, _vp, _i32, _vp],
+    "comms_iq_c32_to_i16_dev": [_vp, _sz, C.c_float, _vp, _i32, _vp],
+    "comms_iq_u8_to_c32_dev": [_vp, _sz, _vp, _i32, _vp],
     "comms_synth_iq_dev": [_vp, _sz, _u64, _u64, _i32, _vp],
 }
 _OTHER = {

@@ -328,7 +328,8 @@ __global__ __launch_bounds__(256, WPS) void fir_os4096_kernel(const float2* __re
 // 64-entry W64 table: 9.2 KiB.
 constexpr int WF = 1024;
 constexpr int WV = 768;        // new samples per segment
-constexpr int W_S1 = 66;
+constexpr int W_S1 = 66;   // exchange 1: [k0][64+2] -- conflict-free ds_read_b64 by lanes (k0,c)
+constexpr int W_S4 = 65;   // exchange 4: [k0][64+1] -- conflict-free ds_write_b64 by lanes (k0,c)
 constexpr int W_P = 272;
 constexpr int W_LDS = 4 * W_P;  // 1088 >= 16*66
 
@@ -532,13 +533,13 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
         OS_STAMP(6)  // exchange-3 reads + twiddle
         radix16<1>(v);
 #pragma unroll
-        for (int b = 0; b < 16; ++b) lds[q0 * W_S1 + 4 * b + q1] = v[R16_POS(b)];
+        for (int b = 0; b < 16; ++b) lds[q0 * W_S4 + 4 * b + q1] = v[R16_POS(b)];
         wave_lds_sync();
         OS_STAMP(7)  // R16 + exchange-4 writes
         // ---- inverse: lane t: conj W1024^{t*k0}, R16 over k0 -> a
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            cf x = lds[k * W_S1 + l];
+            cf x = lds[k * W_S4 + l];
             v[k] = k ? cmulcf(x, tw1[k * 64 + l]) : x;
         }
         wave_lds_sync();

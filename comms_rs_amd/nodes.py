@@ -361,6 +361,31 @@ def rect_taps(n_taps):
     return _taps(lib().comms_rect_taps, n_taps)
 
 
+# ------------------------------------------------------------------ raw IQ wire formats
+def iq_i16_to_c32(x, scale=1.0, device=0):
+    """int16 array of shape (n, 2) (re, im) -> complex64 (cast_complex, times scale)."""
+    x = np.ascontiguousarray(x, dtype=np.int16).reshape(-1, 2)
+    out = np.empty(x.shape[0], np.complex64)
+    check(lib().comms_iq_i16_to_c32(_ptr(x), x.shape[0], float(scale), _ptr(out), device))
+    return out
+
+
+def iq_c32_to_i16(x, scale=1.0, device=0):
+    """complex64 -> int16 (n, 2): `(scale * x) as i16` per component (Rust `as` semantics)."""
+    x = _as_c64(x)
+    out = np.empty((x.size, 2), np.int16)
+    check(lib().comms_iq_c32_to_i16(_ptr(x), x.size, float(scale), _ptr(out), device))
+    return out
+
+
+def iq_u8_to_c32(x, device=0):
+    """uint8 (n, 2) RTL-SDR bytes -> complex64: (x - 127.5) / 127.5."""
+    x = np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 2)
+    out = np.empty(x.shape[0], np.complex64)
+    check(lib().comms_iq_u8_to_c32(_ptr(x), x.shape[0], _ptr(out), device))
+    return out
+
+
 # ------------------------------------------------------------------ synthetic IQ
 def synth_iq(n, first_index=0, seed=0xC0FFEE):
     out = np.empty(int(n), np.complex64)

@@ -430,6 +430,29 @@ int orc_rrc_taps(uint32_t n_taps, double sam_per_sym, double beta, double* out_r
     return 0;
 }
 
+// ---------------------------------------------------------------- raw IQ wire formats
+// src/io/raw_iq.rs:16,50-51 (Complex<i16>, re then im) + src/util/math.rs:20-28 cast_complex
+void orc_iq_i16_to_f32(const int16_t* in, size_t n, float scale, float* out) {
+    for (size_t i = 0; i < 2 * n; ++i) out[i] = static_cast<float>(in[i]) * scale;
+}
+// examples/single_thread_bpsk.rs:40-44: `(8192.0 * x.re) as i16` -- Rust float->int `as`:
+// truncate toward zero, saturate at the type's range, NaN -> 0
+void orc_iq_f32_to_i16(const float* in, size_t n, float scale, int16_t* out) {
+    for (size_t i = 0; i < 2 * n; ++i) {
+        float v = scale * in[i];
+        int16_t r;
+        if (v != v) r = 0;
+        else if (v >= 32767.0f) r = 32767;
+        else if (v <= -32768.0f) r = -32768;
+        else r = static_cast<int16_t>(static_cast<int32_t>(v));
+        out[i] = r;
+    }
+}
+// examples/fm_radio.rs:82-90: (x as f32 - 127.5) / 127.5
+void orc_iq_u8_to_f32(const uint8_t* in, size_t n, float* out) {
+    for (size_t i = 0; i < 2 * n; ++i) out[i] = (static_cast<float>(in[i]) - 127.5f) / 127.5f;
+}
+
 // ---------------------------------------------------------------- PRBS source (config C1 input)
 // src/prns.rs:64-71 -- PrnGen<u8>::next_byte(): Fibonacci LFSR, left shift,
 // output = MSB before the shift, feedback = parity(state & poly_mask).

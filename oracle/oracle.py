@@ -224,6 +224,31 @@ def sinc(x):
     return lib().orc_sinc(float(x))
 
 
+# ------------------------------------------------------------------ raw IQ wire formats
+def iq_i16_to_c32(x, scale=1.0):
+    """raw_iq.rs:16,50-51 + math.rs:20-28 (cast_complex), times scale."""
+    x = np.ascontiguousarray(x, dtype=np.int16).reshape(-1, 2)
+    out = np.zeros(x.shape[0], np.complex64)
+    lib().orc_iq_i16_to_f32(_p(x), _sz(x.shape[0]), C.c_float(scale), _p(out))
+    return out
+
+
+def iq_c32_to_i16(x, scale=1.0):
+    """examples/single_thread_bpsk.rs:40-44: `(scale * x) as i16` per component."""
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    out = np.zeros((x.size, 2), np.int16)
+    lib().orc_iq_f32_to_i16(_p(x), _sz(x.size), C.c_float(scale), _p(out))
+    return out
+
+
+def iq_u8_to_c32(x):
+    """examples/fm_radio.rs:82-90."""
+    x = np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 2)
+    out = np.zeros(x.shape[0], np.complex64)
+    lib().orc_iq_u8_to_f32(_p(x), _sz(x.shape[0]), _p(out))
+    return out
+
+
 # ------------------------------------------------------------------ PRBS source
 def prns_u8(poly_mask, state, n):
     """prns.rs:64-71 on an 8-bit register.  Returns (bits, new_state)."""

@@ -576,6 +576,27 @@ def test_fm_radio_example_chain(c):
     assert np.max(np.abs(g2 - w2)) <= 1e-4 * np.sum(np.abs(taps))
 
 
+# ------------------------------------------------------------------ raw IQ wire formats
+def test_iq_wire_formats_bit_exact(c):
+    rng = np.random.default_rng(21)
+    for n in (0, 1, 7, 100003):
+        i16 = rng.integers(-32768, 32768, (n, 2), dtype=np.int16)
+        u8 = rng.integers(0, 256, (n, 2), dtype=np.uint8)
+        assert np.array_equal(c.iq_i16_to_c32(i16), oracle.iq_i16_to_c32(i16))
+        assert np.array_equal(c.iq_i16_to_c32(i16, 1.0 / 8192), oracle.iq_i16_to_c32(i16, 1.0 / 8192))
+        assert np.array_equal(c.iq_u8_to_c32(u8), oracle.iq_u8_to_c32(u8))
+        x = (rng.uniform(-6, 6, n) + 1j * rng.uniform(-6, 6, n)).astype(np.complex64)  # 8192 * 6 saturates
+        assert np.array_equal(c.iq_c32_to_i16(x, 8192.0), oracle.iq_c32_to_i16(x, 8192.0))
+    edge = np.array([np.nan + 0j, np.inf - np.inf * 1j, 3.99 - 3.99j, -0.9 + 0.9j, 4.0 - 4.0001j], np.complex64)
+    got = c.iq_c32_to_i16(edge, 8192.0)
+    assert np.array_equal(got, oracle.iq_c32_to_i16(edge, 8192.0))
+    assert got[0, 0] == 0 and got[1].tolist() == [32767, -32768] and got[3].tolist() == [-7372, 7372]
+    # the example's round trip: f32 -> i16 file format -> f32
+    y = c.synth_iq(5000)
+    back = c.iq_i16_to_c32(c.iq_c32_to_i16(y, 8192.0), 1.0 / 8192)
+    assert np.max(np.abs(back - y)) <= 1.0 / 8192
+
+
 # ------------------------------------------------------------------ device buffers
 def test_device_buf_refcount_and_roundtrip(c):
     x = c.synth_iq(1000)

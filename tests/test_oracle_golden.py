@@ -221,3 +221,14 @@ def test_prbs7_golden(kats):
         seen.add(st)
         _, st = oracle.prns_u8(0xB8, st, 1)
     assert st == 1
+
+
+def test_iq_wire_formats():
+    # raw_iq.rs:16,50-51 / single_thread_bpsk.rs:40-44 / fm_radio.rs:82-90
+    i16 = np.array([[3, -4], [32767, -32768], [0, 1]], np.int16)
+    assert np.array_equal(oracle.iq_i16_to_c32(i16), np.array([3 - 4j, 32767 - 32768j, 1j], np.complex64))
+    x = np.array([0.5 - 0.25j, 100 - 100j, np.nan + 0.9999j, -0.00013 + 0.00013j], np.complex64)
+    assert oracle.iq_c32_to_i16(x, 8192.0).tolist() == [[4096, -2048], [32767, -32768], [0, 8191], [-1, 1]]
+    u8 = np.array([[0, 255], [127, 128]], np.uint8)
+    got = oracle.iq_u8_to_c32(u8)
+    assert got[0] == np.complex64(-1 + 1j) and abs(got[1].real + 0.5 / 127.5) < 1e-7
