@@ -587,7 +587,9 @@ def test_iq_wire_formats_bit_exact(c):
         assert np.array_equal(c.iq_u8_to_c32(u8), oracle.iq_u8_to_c32(u8))
         x = (rng.uniform(-6, 6, n) + 1j * rng.uniform(-6, 6, n)).astype(np.complex64)  # 8192 * 6 saturates
         assert np.array_equal(c.iq_c32_to_i16(x, 8192.0), oracle.iq_c32_to_i16(x, 8192.0))
-    edge = np.array([np.nan + 0j, np.inf - np.inf * 1j, 3.99 - 3.99j, -0.9 + 0.9j, 4.0 - 4.0001j], np.complex64)
+    edge = np.empty(5, np.complex64)
+    edge.real = [np.nan, np.inf, 3.99, -0.9, 4.0]
+    edge.imag = [0.0, -np.inf, -3.99, 0.9, -4.0001]
     got = c.iq_c32_to_i16(edge, 8192.0)
     assert np.array_equal(got, oracle.iq_c32_to_i16(edge, 8192.0))
     assert got[0, 0] == 0 and got[1].tolist() == [32767, -32768] and got[3].tolist() == [-7372, 7372]
