@@ -223,33 +223,58 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void fft1024x16_kernel(c
     for (int i = tid; i < 1024; i += 64 * NW) tw1[i] = tw1g[i];
     if (tid < 64) tw2[tid] = tw2g[tid];
 
+    // A tile's 16 elements per lane: global element u of this lane and where it goes in LDS.
+    constexpr int LOG = NW == 16 ? 4 : 3;
+    auto tile_src = [&](size_t tix) {
+        const size_t b = tix / p.tiles_per_xform;
+        return in + b * p.N + (tix - b * p.tiles_per_xform) * p.tile_step_in;
+    };
+    // element offsets inside one transform fit 32 bits (N <= 2^24): uniform 64-bit base in
+    // SGPRs + one 32-bit VGPR offset per load keeps the 16 in-flight loads cheap in registers
+    const unsigned in_cs = static_cast<unsigned>(p.in_cs), in_ls = static_cast<unsigned>(p.in_ls);
+    auto fetch = [&](const cf* src, cf (&r)[16]) {
+        if (p.in_c_fast) {  // lane holds (c = tid % NW, rows tid / NW + 64u)
+            const unsigned o0 = (tid & (NW - 1)) * in_cs + (tid >> LOG) * in_ls, step = 64u * in_ls;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) r[u] = src[o0 + u * step];
+        } else if (NW == 16) {  // element i = tid + 1024u -> (c = u, r = tid)
+            const unsigned o0 = tid * in_ls;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) r[u] = src[o0 + u * in_cs];
+        } else {  // element i = tid + 512u -> (c = u/2, r = tid + 512 (u&1))
+            const unsigned o0 = tid * in_ls, o1 = o0 + 512u * in_ls;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) r[u] = src[((u & 1) ? o1 : o0) + (u >> 1) * in_cs];
+        }
+    };
+    // software pipeline: the next tile's elements are requested into VGPRs before this
+    // tile's transform and land in LDS at the top of the next iteration -- with one
+    // workgroup per CU nothing else would cover their HBM latency
+    // (two 8-wave workgroups per CU already cover each other, and there the extra 32
+    // VGPRs spill -- so only the 16-wave form prefetches)
+    constexpr bool PREFETCH = NW == 16;
+    cf pre[16];
+    if (PREFETCH && blockIdx.x < p.n_tiles) fetch(tile_src(blockIdx.x), pre);
+
     for (size_t tix = blockIdx.x; tix < p.n_tiles; tix += gridDim.x) {
         const size_t b = tix / p.tiles_per_xform;
         const size_t tl = tix - b * p.tiles_per_xform;
-        const cf* src = in + b * p.N + tl * p.tile_step_in;
         cf* dst = out + b * p.N + tl * p.tile_step_out;
         __syncthreads();  // previous tile fully stored (and the tables are in place)
-        // ---- coalesced tile load: 16 elements per lane, element u at base + u*step
-        {
-            // c-fast: lane holds (c = tid&15, rows tid>>4 + 64u);  l-fast: (row tid, c = u)
-            // c-fast: lane holds (c = tid % NW, rows tid / NW + 64u);  l-fast: rows (tid + 64 NW u) % 1024 of c = .. / 1024
-            constexpr int LOG = NW == 16 ? 4 : 3;
-            if (p.in_c_fast) {
-                const cf* g = src + (tid & (NW - 1)) * p.in_cs + (tid >> LOG) * p.in_ls;
-                const size_t gstep = 64 * p.in_ls;
-                cf* d = bufs + (tid & (NW - 1)) * FW_BUF + (tid >> LOG);
-#pragma unroll 8
-                for (int u = 0; u < 16; ++u) d[u * 64] = g[u * gstep];
-            } else {
-                // 64*NW lanes sweep the tile row-major: element i = tid + 64*NW*u -> (c = i / 1024, r = i % 1024)
-#pragma unroll 8
-                for (int u = 0; u < 16; ++u) {
-                    const int i = tid + 64 * NW * u;
-                    bufs[(i >> 10) * FW_BUF + (i & 1023)] = src[(i >> 10) * p.in_cs + (i & 1023) * p.in_ls];
-                }
+        if (!PREFETCH) fetch(tile_src(tix), pre);
+        if (p.in_c_fast) {
+            cf* d = bufs + (tid & (NW - 1)) * FW_BUF + (tid >> LOG);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) d[u * 64] = pre[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int i = tid + 64 * NW * u;
+                bufs[(i >> 10) * FW_BUF + (i & 1023)] = pre[u];
             }
         }
         __syncthreads();
+        if (PREFETCH && tix + gridDim.x < p.n_tiles) fetch(tile_src(tix + gridDim.x), pre);
         // ---- this wave's 1024-point transform, in its own buffer
         cf v[16];
 #pragma unroll
@@ -287,26 +312,27 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void fft1024x16_kernel(c
             for (int k2 = 0; k2 < 4; ++k2) buf[q1 + 4 * j + 17 * q0 + 272 * k2] = v[4 * j + k2];
         }
         __syncthreads();
-        // ---- coalesced tile store (optionally times the four-step twiddle)
+        // ---- coalesced tile store (optionally times the four-step twiddle); 32-bit offsets
         {
-            constexpr int LOG = NW == 16 ? 4 : 3;
+            const unsigned out_cs = static_cast<unsigned>(p.out_cs), out_ks = static_cast<unsigned>(p.out_ks);
+            const unsigned col0 = static_cast<unsigned>(tl) * NW;
 #pragma unroll 8
             for (int u = 0; u < 16; ++u) {
-                int c, k;
+                unsigned c, k;
                 if (p.out_c_fast) {
                     c = tid & (NW - 1);
                     k = (tid >> LOG) + 64 * u;
                 } else {
-                    const int i = tid + 64 * NW * u;
+                    const unsigned i = tid + 64 * NW * u;
                     c = i >> 10;
                     k = i & 1023;
                 }
                 cf x = bufs[c * FW_BUF + k + (k >> 4)];
                 if (p.apply_tw) {
-                    const size_t e = (tl * NW + c) * static_cast<size_t>(k);  // < N
+                    const unsigned e = (col0 + c) * k;  // < N <= 2^24
                     x = tw_apply<DIR>(x, g_mul(p.tw_hi[e >> 12], p.tw_lo[e & 4095]));
                 }
-                dst[c * p.out_cs + k * p.out_ks] = x;
+                dst[c * out_cs + k * out_ks] = x;
             }
         }
     }
