@@ -778,15 +778,31 @@ comms_status_t comms_fft_run_dev(comms_fft_t* h, const comms_c32* d_in, size_t n
         return COMMS_OK;
     }
     if (h->kind == 0) {
-        float2* scratch = nullptr;
-        if (h->plan.n_pass == 2) {
-            COMMS_TRY(h->work.reserve(n * sizeof(float2)));
-            scratch = static_cast<float2*>(h->work.p);
+        if (h->plan.n_pass == 1) {
+            h->tic(s);
+            comms_status_t st = pow2_run(h->plan, in, o, batch, h->inverse, s, nullptr);
+            h->toc(s);
+            return st;
         }
+        // four-step: pass 1 -> scratch -> pass 2, in groups that bound the scratch buffer.
+        // (Small groups, sized so the intermediate stays in the 256 MiB Infinity Cache, were
+        // measured and lose: 2^20 x 64 runs 0.56 ms ungrouped, 0.66 ms at 64 MiB, 2.3 ms at 8 MiB.)
+        static const size_t group_bytes = [] {
+            const char* v = getenv("COMMS_FFT_GROUP_MB");
+            return static_cast<size_t>(v && *v ? atoi(v) : 2048) << 20;
+        }();
+        size_t group = group_bytes / (h->N * sizeof(float2));
+        if (group < 1) group = 1;
+        if (group > batch) group = batch;
+        COMMS_TRY(h->work.reserve(group * h->N * sizeof(float2)));
+        float2* scratch = static_cast<float2*>(h->work.p);
         h->tic(s);
-        comms_status_t st = pow2_run(h->plan, in, o, batch, h->inverse, s, scratch);
+        for (size_t b0 = 0; b0 < batch; b0 += group) {
+            const size_t nb = batch - b0 < group ? batch - b0 : group;
+            COMMS_TRY(pow2_run(h->plan, in + b0 * h->N, o + b0 * h->N, nb, h->inverse, s, scratch));
+        }
         h->toc(s);
-        return st;
+        return COMMS_OK;
     }
     if (h->kind == 1) {
         COMMS_ARG(!ranges_overlap(d_in, n * 8, d_out, n * 8) , "this fft_size cannot run in place");
