@@ -559,6 +559,46 @@ def test_fused_fm_chain_rates_and_fallbacks(c, rate):
         c.ChainNode(0.3, 0.1, taps, 8, True).run(x[:12])  # n not a multiple of rate
 
 
+def test_config3_full_size_2p26_fused_vs_nodes(c):
+    """BASELINE config 3 at its full size (2^26 samples, mixer -> 127-tap LPF -> /8 [-> FM]),
+    device-resident: the fused launch against the four kernels in series, plus the oracle on
+    windows of the decimated FIR output."""
+    import torch
+
+    n = 1 << 26
+    taps = lowpass_taps(127, 1 / 16)
+    dphase = 2 * np.pi * 0.05
+    x = torch.empty(n, dtype=torch.complex64, device="cuda:0")
+    c.synth_iq_dev(x.data_ptr(), n, 0, 3)
+    s = torch.cuda.current_stream().cuda_stream
+    a = torch.empty(n // 8, dtype=torch.complex64, device="cuda:0")
+    b = torch.empty_like(a)
+    c.ChainNode(dphase, 0.0, taps, 8, False).run_dev(x.data_ptr(), n, a.data_ptr(), s)
+    c.ChainNode(dphase, 0.0, taps, 8, False, unfused=True).run_dev(x.data_ptr(), n, b.data_ptr(), s)
+    torch.cuda.synchronize()
+    scale = float(np.sum(np.abs(taps)))
+    assert float((a - b).abs().max()) <= TOL * scale
+    for start in (0, 1 << 20, n - 65536):  # multiples of 8
+        lo = max(0, start - 126)
+        xs = c.synth_iq(start + 16384 - lo, lo, 3)
+        # phase of sample lo, wrapped in extended precision (an unwrapped 1e7-rad start would make
+        # the reference's own `phase += dphase; phase -= 2pi` lose ~2e-9 rad per step)
+        ph = float(np.fmod(np.longdouble(dphase) * lo, np.longdouble(2.0) * np.longdouble(np.pi)))
+        mx = oracle.Mixer(ph, dphase).mix(xs)
+        w = oracle.batch_fir(mx, taps, oracle.default_state(taps), norotate=True)[start - lo:][::8]
+        fir_close(a[start // 8:start // 8 + w.size].cpu().numpy(), w, taps, xs)
+    # FM demod variant: fused vs unfused on the circle, where the signal is not ~0
+    fa = torch.empty(n // 8, dtype=torch.float32, device="cuda:0")
+    fb = torch.empty_like(fa)
+    c.ChainNode(dphase, 0.0, taps, 8, True).run_dev(x.data_ptr(), n, fa.data_ptr(), s)
+    c.ChainNode(dphase, 0.0, taps, 8, True, unfused=True).run_dev(x.data_ptr(), n, fb.data_ptr(), s)
+    torch.cuda.synchronize()
+    mag = torch.minimum(b.abs(), torch.roll(b.abs(), 1))
+    d = (fa - fb).abs()
+    d = torch.minimum(d, 2 * np.pi - d)
+    assert float((d * mag).max()) <= 4 * TOL * scale  # angle error x magnitude ~ FIR error
+
+
 def test_fm_radio_example_chain(c):
     # the literal example chain (examples/fm_radio.rs:144-152): 63-tap FIR -> /5 -> FM demod
     # -> (re,0) -> 63-tap FIR -> .re -> /5, on a synthetic FM stream
