@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcomms_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 COMMS_OK, COMMS_ERR_ARG, COMMS_ERR_DEVICE = 0, 1, 2
-FIR_AUTO, FIR_DIRECT, FIR_OVERLAP_SAVE, FIR_OS1024, FIR_OS4096 = 0, 1, 2, 3, 4
+FIR_AUTO, FIR_DIRECT, FIR_OVERLAP_SAVE, FIR_OS1024, FIR_OS4096, FIR_OS16K = 0, 1, 2, 3, 4, 5
 STREAM_HANDLE = C.c_void_p(-1).value  # COMMS_STREAM_HANDLE: the handle's own stream
 
 

@@ -24,6 +24,7 @@
 // the same data newest-first.
 #include <cmath>
 #include <cstdlib>
+#include <utility>
 #include <vector>
 
 #include "common.hpp"
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(256) void fir_direct_kernel(const float2* __restric
 
 // ---------------------------------------------------------------- overlap-save, F = 4096
 constexpr int OSF = 4096;
+constexpr int XF = 16384;
 constexpr int OS_S1 = 272;  // [k0][256 + 16]: odd k0 rows land 32 banks away (ds_read_b64)
 constexpr int OS_S2 = 18;   // [row][16 + 2]: 144-B rows, conflict-free ds_read_b128
 constexpr int OS_LDS = 4608;
@@ -621,6 +623,165 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
 #undef OS_STAMP
 }
 
+// ---------------------------------------------------------------- overlap-save, F = 16384 (long filters)
+// 2050..4097 taps (config 5).  16384 = 16 x 1024: one 16-wave workgroup owns a segment
+// (12288 new samples + 4096 of halo carried in VGPRs): every lane does a radix-16 over
+// the 1024-strided rows (twiddle W16384^{t*k0}), the 16 k0-slices are exchanged through
+// LDS so that wave k0 holds slice k0, each wave then runs the same barrier-free
+// 1024-point transform as fir_os1024_kernel on its slice, multiplies by its part of the
+// filter spectrum, and the mirror image brings the samples back.  Three workgroup
+// barriers per segment.  LDS: 16 x 1090 slice buffers + W1024 / W64 / W256 / W16384
+// tables = 158 KiB, one workgroup per CU.
+constexpr int XV = 12288;      // new samples per segment (halo 4096)
+constexpr int X_BUF = 1090;    // per-wave slice buffer (>= 1088; 2180 dwords = 4 mod 64 banks)
+
+struct XTables {
+    const cf* tw1;   // [16][64]   W1024^{lane*k}          (per-wave 1024-point transform)
+    const cf* tw2;   // [16][4]    W64^{c*k1}
+    const cf* ta;    // [16][16]   W256^{wave*k0}           (stage-1 twiddle, high part)
+    const cf* tb;    // [16][64]   W16384^{lane*k0}         (stage-1 twiddle, low part), index [k0][lane]
+    const cf* hdev;  // [16][1024] H[k0 + 16 k']/16384 at [4j + k2][tid], k0 = tid>>6, k' = (q1+4j) + 16 q0 + 256 k2
+};
+
+// in: v[a] = z[64a + l];  out: v[4j + k2] = Z[(q1 + 4j) + 16 q0 + 256 k2]   (forward)
+__device__ __forceinline__ void wave_fft1024_fwd(cf (&v)[16], cf* lds, const cf* tw1, const cf* tw2, int l, int q0,
+                                                 int q1) {
+    radix16<-1>(v);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        cf x = v[R16_POS(k)];
+        if (k) x = cmulf(x, tw1[k * 64 + l]);
+        lds[k * W_S1 + l] = x;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int b = 0; b < 16; ++b) v[b] = lds[q0 * W_S1 + 4 * b + q1];
+    wave_lds_sync();
+    radix16<-1>(v);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        cf x = v[R16_POS(k)];
+        if (k) x = cmulf(x, tw2[k * 4 + q1]);
+        lds[q1 * W_P + 17 * q0 + k] = x;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[4 * j + c] = lds[c * W_P + 17 * (q1 + 4 * j) + q0];
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) radix4<-1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+}
+// in: v[4j + k2] = Z[...] as above;  out: v[R16_POS(a)] = z[64a + l]   (unnormalised inverse)
+__device__ __forceinline__ void wave_fft1024_inv(cf (&v)[16], cf* lds, const cf* tw1, const cf* tw2, int l, int q0,
+                                                 int q1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        radix4<1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lds[c * W_P + 17 * (q1 + 4 * j) + q0] = v[4 * j + c];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        cf x = lds[q1 * W_P + 17 * q0 + k];
+        v[k] = k ? cmulcf(x, tw2[k * 4 + q1]) : x;
+    }
+    wave_lds_sync();
+    radix16<1>(v);
+#pragma unroll
+    for (int b = 0; b < 16; ++b) lds[q0 * W_S4 + 4 * b + q1] = v[R16_POS(b)];
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        cf x = lds[k * W_S4 + l];
+        v[k] = k ? cmulcf(x, tw1[k * 64 + l]) : x;
+    }
+    wave_lds_sync();
+    radix16<1>(v);
+}
+
+__global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(const float2* __restrict__ in,
+                                                            const float2* __restrict__ hist, int hist_len,
+                                                            float2* __restrict__ out, size_t n, size_t nseg,
+                                                            XTables tb, float2* __restrict__ new_hist, int delay,
+                                                            int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* tw1 = reinterpret_cast<cf*>(smem);  // [16][64]
+    cf* tw2 = tw1 + 1024;                   // [16][4]
+    cf* ta = tw2 + 64;                      // [16][16]
+    cf* tbl = ta + 256;                     // [16][64]
+    cf* bufs = tbl + 1024;                  // [16][X_BUF]
+    const int tid = threadIdx.x;
+    const int l = tid & 63, wave = tid >> 6;
+    const int q0 = l & 15, q1 = l >> 4;
+    cf* buf = bufs + wave * X_BUF;
+    if (!accumulate) hist_advance(hist, in, n, new_hist, hist_len);
+    tw1[tid] = tb.tw1[tid];
+    tbl[tid] = tb.tb[tid];
+    if (tid < 64) tw2[tid] = tb.tw2[tid];
+    if (tid < 256) ta[tid] = tb.ta[tid];
+
+    // workgroup g of the persistent grid owns segments [g*nseg/G, (g+1)*nseg/G)
+    const size_t seg_lo = static_cast<size_t>(blockIdx.x) * nseg / gridDim.x;
+    const size_t seg_hi = static_cast<size_t>(blockIdx.x + 1) * nseg / gridDim.x;
+    cf v[16], carry[4];
+    for (size_t seg = seg_lo; seg < seg_hi; ++seg) {
+        const size_t nb = seg * XV;
+        const long long base = static_cast<long long>(nb) - 4096 - delay;
+        if (seg == seg_lo) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) v[a] = to_cf(stream_at(in, hist, hist_len, base + 1024 * a + tid, n));
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) v[a] = carry[a];
+        }
+#pragma unroll
+        for (int a = 4; a < 16; ++a) v[a] = to_cf(stream_at(in, hist, hist_len, base + 1024 * a + tid, n));
+#pragma unroll
+        for (int a = 0; a < 4; ++a) carry[a] = v[12 + a];
+
+        // ---- stage 1: radix-16 over the rows, x W16384^{tid*k0}, slice k0 -> wave k0
+        radix16<-1>(v);
+        __syncthreads();  // the previous segment's last LDS reads are done
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            cf x = v[R16_POS(k)];
+            if (k) x = cmulf(x, cmulf(ta[wave * 16 + k], tbl[k * 64 + l]));
+            bufs[k * X_BUF + tid] = x;
+        }
+        __syncthreads();
+        // ---- this wave's slice: 1024-point transform, spectrum multiply, inverse
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = buf[64 * a + l];
+        wave_lds_sync();
+        wave_fft1024_fwd(v, buf, tw1, tw2, l, q0, q1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = cmulf(v[r], tb.hdev[r * 1024 + tid]);
+        wave_fft1024_inv(v, buf, tw1, tw2, l, q0, q1);
+#pragma unroll
+        for (int a = 0; a < 16; ++a) buf[64 * a + l] = v[R16_POS(a)];
+        __syncthreads();
+        // ---- inverse stage 1: lane tid gathers slice values k0 = 0..15, conj twiddle, radix-16
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            cf x = bufs[k * X_BUF + tid];
+            v[k] = k ? cmulcf(x, cmulf(ta[wave * 16 + k], tbl[k * 64 + l])) : x;
+        }
+        radix16<1>(v);
+#pragma unroll
+        for (int a = 4; a < 16; ++a) {
+            const size_t o = nb + 1024 * (a - 4) + tid;
+            if (o < n) {
+                cf y = v[R16_POS(a)];
+                if (accumulate) y = y + to_cf(out[o]);
+                out[o] = to_f2(y);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- pulse shaping (polyphase)
 // Reference: PulseNode::run (src/pulse.rs:82-92) = zero-stuff by sps, then FIR.
 //   out[m*sps + p] = sum_j taps[p + j*sps] * sym[m - j]
@@ -673,7 +834,12 @@ struct comms_fir : Handle {
     // overlap-save, F = 4096 (workgroup per segment)
     bool os_ready = false;
     int hblk = 0;        // halo = 256*hblk >= (taps per partition) - 1
-    int n_part = 1;      // > 3841 taps: partitions of OS_PART taps, each one pass of the 4096-pt kernel
+    // overlap-save, F = 16384 (workgroup per segment), > 2049 taps; partitions of 4097 taps
+    bool x_ready = false;
+    int x_part = 1;
+    float2* d_xt[4] = {nullptr, nullptr, nullptr, nullptr};  // tw1, tw2, ta, tb
+    std::vector<float2*> d_xh;                                // spectrum per partition
+    int n_part = 1;      // (4096-pt kernel, forced) > 3841 taps: partitions of OS_PART taps
     std::vector<float2*> d_hparts;  // filter spectrum per partition (d_hdev = partition 0)
     float2* d_tw1 = nullptr;
     float2* d_tw2 = nullptr;
@@ -693,6 +859,10 @@ static void free_fir(comms_fir* h) {
     if (h->d_tw1) (void)hipFree(h->d_tw1);
     if (h->d_tw2) (void)hipFree(h->d_tw2);
     for (float2* q : h->d_hparts)
+        if (q) (void)hipFree(q);
+    for (float2* q : h->d_xh)
+        if (q) (void)hipFree(q);
+    for (float2* q : h->d_xt)
         if (q) (void)hipFree(q);
     if (h->d_hist[0]) (void)hipFree(h->d_hist[0]);
     if (h->d_hist[1]) (void)hipFree(h->d_hist[1]);
@@ -794,29 +964,43 @@ static comms_status_t fir_prepare_os(comms_fir* h) {
     return COMMS_OK;
 }
 
-// Spectrum of the effective taps zero-padded to F points (f64, exact-index twiddles).
+// Spectrum of taps[first, first+count) zero-padded to F points (F a power of two), f64:
+// iterative radix-2 FFT with twiddles taken straight from cos/sin per index.
 static void tap_spectrum_range(const comms_fir* h, int first, int count, int F, std::vector<double>& re,
                                std::vector<double>& im) {
-    std::vector<double> cs(F), sn(F);
-    for (int e = 0; e < F; ++e) {
-        double a = -2.0 * kPi * static_cast<double>(e) / F;
+    re.assign(F, 0.0);
+    im.assign(F, 0.0);
+    for (int j = 0; j < count; ++j) {
+        re[j] = h->taps[first + j].re;
+        im[j] = h->taps[first + j].im;
+    }
+    for (int i = 1, j = 0; i < F; ++i) {  // bit reversal
+        int bit = F >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            std::swap(re[i], re[j]);
+            std::swap(im[i], im[j]);
+        }
+    }
+    std::vector<double> cs(F / 2), sn(F / 2);
+    for (int e = 0; e < F / 2; ++e) {
+        const double a = -2.0 * kPi * static_cast<double>(e) / F;
         cs[e] = std::cos(a);
         sn[e] = std::sin(a);
     }
-    re.assign(F, 0.0);
-    im.assign(F, 0.0);
-    for (int k = 0; k < F; ++k) {
-        double r = 0, i = 0;
-        int e = 0;
-        for (int j = 0; j < count; ++j) {
-            double tr = h->taps[first + j].re, ti = h->taps[first + j].im;
-            r += tr * cs[e] - ti * sn[e];
-            i += tr * sn[e] + ti * cs[e];
-            e += k;
-            if (e >= F) e -= F;
-        }
-        re[k] = r;
-        im[k] = i;
+    for (int len = 2; len <= F; len <<= 1) {
+        const int half = len / 2, step = F / len;
+        for (int i = 0; i < F; i += len)
+            for (int k = 0; k < half; ++k) {
+                const double wr = cs[k * step], wi = sn[k * step];
+                const double xr = re[i + k + half], xi = im[i + k + half];
+                const double vr = xr * wr - xi * wi, vi = xr * wi + xi * wr;
+                re[i + k + half] = re[i + k] - vr;
+                im[i + k + half] = im[i + k] - vi;
+                re[i + k] += vr;
+                im[i + k] += vi;
+            }
     }
 }
 
@@ -861,6 +1045,52 @@ static comms_status_t fir_prepare_os1024(comms_fir* h) {
     return COMMS_OK;
 }
 
+constexpr int X_PART = 4097;  // taps per pass of the 16384-point kernel (halo 4096)
+
+static comms_status_t fir_prepare_os16k(comms_fir* h) {
+    if (h->x_ready) return COMMS_OK;
+    const int N = h->n_eff;
+    h->x_part = (N + X_PART - 1) / X_PART;
+    std::vector<float2> tw1(16 * 64), tw2(16 * 4), ta(16 * 16), tb(16 * 64), hdev(16 * 1024);
+    for (int k = 0; k < 16; ++k)
+        for (int t = 0; t < 64; ++t) {
+            tw1[k * 64 + t] = unit_root(static_cast<long long>(t) * k, 1024);
+            tb[k * 64 + t] = unit_root(static_cast<long long>(t) * k, XF);
+        }
+    for (int k1 = 0; k1 < 16; ++k1)
+        for (int c = 0; c < 4; ++c) tw2[k1 * 4 + c] = unit_root(c * k1, 64);
+    for (int w = 0; w < 16; ++w)
+        for (int k = 0; k < 16; ++k) ta[w * 16 + k] = unit_root(w * k, 256);
+    COMMS_TRY(upload_f2(tw1, &h->d_xt[0]));
+    COMMS_TRY(upload_f2(tw2, &h->d_xt[1]));
+    COMMS_TRY(upload_f2(ta, &h->d_xt[2]));
+    COMMS_TRY(upload_f2(tb, &h->d_xt[3]));
+    std::vector<double> re, im;
+    for (int pt = 0; pt < h->x_part; ++pt) {
+        const int first = pt * X_PART;
+        const int count = N - first < X_PART ? N - first : X_PART;
+        tap_spectrum_range(h, first, count, XF, re, im);
+        for (int tid = 0; tid < 1024; ++tid) {
+            const int k0 = tid >> 6, l = tid & 63, q0 = l & 15, q1 = l >> 4;
+            for (int j = 0; j < 4; ++j)
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    const int kp = (q1 + 4 * j) + 16 * q0 + 256 * k2;  // index inside the slice transform
+                    const int k = k0 + 16 * kp;
+                    hdev[(4 * j + k2) * 1024 + tid] =
+                        make_float2(static_cast<float>(re[k] / XF), static_cast<float>(im[k] / XF));
+                }
+        }
+        float2* d = nullptr;
+        COMMS_TRY(upload_f2(hdev, &d));
+        h->d_xh.push_back(d);
+    }
+    const int lds = (1024 + 64 + 256 + 1024 + 16 * X_BUF) * static_cast<int>(sizeof(float2));
+    COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os16k_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    h->x_ready = true;
+    return COMMS_OK;
+}
+
 static comms_status_t fir_prepare_direct(comms_fir* h) {
     if (h->d_taps_pad) return COMMS_OK;
     COMMS_ARG(h->n_eff <= DIRECT_MAX_TAPS, "direct-form FIR supports at most %d taps, got %d",
@@ -891,7 +1121,8 @@ static int fir_pick(const comms_fir* h, size_t n) {
         else
             algo = COMMS_FIR_OVERLAP_SAVE;
     }
-    if (algo == COMMS_FIR_OVERLAP_SAVE) algo = h->n_eff <= 257 ? COMMS_FIR_OS1024 : COMMS_FIR_OS4096;
+    if (algo == COMMS_FIR_OVERLAP_SAVE)
+        algo = h->n_eff <= 257 ? COMMS_FIR_OS1024 : h->n_eff <= 2049 ? COMMS_FIR_OS4096 : COMMS_FIR_OS16K;
     return algo;
 }
 
@@ -948,7 +1179,7 @@ comms_status_t comms_fir_create(const comms_c32* taps, size_t n_taps, const comm
 
 comms_status_t comms_fir_set_algo(comms_fir_t* h, int32_t algo) {
     COMMS_ARG(h != nullptr, "handle is NULL");
-    COMMS_ARG(algo >= COMMS_FIR_AUTO && algo <= COMMS_FIR_OS4096, "unknown algo %d", algo);
+    COMMS_ARG(algo >= COMMS_FIR_AUTO && algo <= COMMS_FIR_OS16K, "unknown algo %d", algo);
     COMMS_ARG(algo != COMMS_FIR_OS1024 || h->n_eff <= 257,
               "the 1024-point overlap-save kernel supports at most 257 taps");
     COMMS_ARG(algo != COMMS_FIR_DIRECT || h->n_eff <= DIRECT_MAX_TAPS,
@@ -1004,6 +1235,21 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
         COMMS_TRY(launch_os1024<0>(wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}));
         h->toc(s);
         COMMS_TRY(launch_ok("fir_os1024_kernel"));
+    } else if (algo == COMMS_FIR_OS16K) {
+        COMMS_TRY(fir_prepare_os16k(h));
+        const size_t nseg = (n + XV - 1) / XV;
+        const unsigned blocks = static_cast<unsigned>(nseg < static_cast<size_t>(kNumCU) ? nseg : kNumCU);
+        const size_t lds = (1024 + 64 + 256 + 1024 + 16 * X_BUF) * sizeof(float2);
+        h->tic(s);
+        for (int pt = 0; pt < h->x_part; ++pt) {
+            XTables tb{reinterpret_cast<const cf*>(h->d_xt[0]), reinterpret_cast<const cf*>(h->d_xt[1]),
+                       reinterpret_cast<const cf*>(h->d_xt[2]), reinterpret_cast<const cf*>(h->d_xt[3]),
+                       reinterpret_cast<const cf*>(h->d_xh[pt])};
+            fir_os16k_kernel<<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, h->n_eff, o, n, nseg, tb, nh,
+                                                                   pt * X_PART, pt ? 1 : 0);
+        }
+        h->toc(s);
+        COMMS_TRY(launch_ok("fir_os16k_kernel"));
     } else {
         COMMS_TRY(fir_prepare_os(h));
         const size_t V = OSF - 256 * static_cast<size_t>(h->hblk);

@@ -14,7 +14,7 @@ import comms_rs_amd as c
 n_taps = int(sys.argv[1]) if len(sys.argv) > 1 else 255
 n = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 24)
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
-algos = {"direct": c.FIR_DIRECT, "os1024": c.FIR_OS1024, "os4096": c.FIR_OS4096}
+algos = {"direct": c.FIR_DIRECT, "os1024": c.FIR_OS1024, "os4096": c.FIR_OS4096, "os16k": c.FIR_OS16K}
 x = torch.empty(n, dtype=torch.complex64, device="cuda:0")
 y = torch.empty_like(x)
 c.synth_iq_dev(x.data_ptr(), n, 0)

@@ -84,7 +84,7 @@ def test_fir_direct_vs_oracle(c, n_taps, real, n):
 
 
 @pytest.mark.parametrize("n_taps,real", [(2, False), (25, False), (255, True), (255, False), (257, False),
-                                         (513, True), (2049, False), (3841, True)])
+                                         (513, True), (2049, False), (3841, True)])  # 3841: forced, default is os16k
 @pytest.mark.parametrize("n", [1, 767, 768, 769, 3839, 3840, 3841, 20000])
 def test_fir_overlap_save_vs_oracle(c, n_taps, real, n):
     rng = np.random.default_rng(n_taps * 11 + n)
@@ -134,13 +134,26 @@ def test_fir_long_filters_partitioned(c, n_taps):
     rng = np.random.default_rng(n_taps)
     taps = (rand_c(rng, n_taps) / np.sqrt(n_taps)).astype(np.complex64)
     x = rand_c(rng, 30000)
-    node = c.BatchFirNode(taps)
-    assert node.algo_for(x.size) == c.FIR_OS4096
-    st = oracle.default_state(taps)
-    for a, b in [(0, 5000), (5000, 5001), (5001, 30000)]:
-        want = oracle.batch_fir(x[a:b], taps, st, norotate=True)
-        fir_close(node.run(x[a:b]), want, taps, x)
-    assert np.array_equal(node.state(n_taps), st)
+    # default: the 16384-point kernel (4097-tap partitions); forced: 2049-tap partitions of the 4096-point one
+    for algo in (c.FIR_AUTO, c.FIR_OS4096):
+        node = c.BatchFirNode(taps).set_algo(algo)
+        assert node.algo_for(x.size) == (c.FIR_OS16K if algo == c.FIR_AUTO else c.FIR_OS4096)
+        st = oracle.default_state(taps)
+        for a, b in [(0, 5000), (5000, 5001), (5001, 30000)]:
+            want = oracle.batch_fir(x[a:b], taps, st, norotate=True)
+            fir_close(node.run(x[a:b]), want, taps, x)
+        assert np.array_equal(node.state(n_taps), st)
+
+
+@pytest.mark.parametrize("n_taps", [2050, 3000, 4097])
+@pytest.mark.parametrize("n", [1, 12287, 12288, 12289, 40000])
+def test_fir_os16k_vs_oracle(c, n_taps, n):
+    rng = np.random.default_rng(n_taps + n)
+    taps = (rand_c(rng, n_taps) / np.sqrt(n_taps)).astype(np.complex64)
+    x = rand_c(rng, n)
+    node = c.BatchFirNode(taps).set_algo(c.FIR_OS16K)
+    want = oracle.batch_fir(x, taps, oracle.default_state(taps), norotate=True)
+    fir_close(node.run(x), want, taps, x)
 
 
 def test_config5_4097_taps_windowed_sinc_long_stream(c):
@@ -168,6 +181,7 @@ def test_fir_auto_selection_and_errors(c):
     node = c.BatchFirNode(taps)
     assert node.algo_for(1 << 24) == c.FIR_OS1024
     assert c.BatchFirNode(np.ones(258, np.complex64)).algo_for(1 << 24) == c.FIR_OS4096
+    assert c.BatchFirNode(np.ones(2050, np.complex64)).algo_for(1 << 24) == c.FIR_OS16K
     assert node.algo_for(4) == c.FIR_DIRECT
     assert c.BatchFirNode(np.ones(8, np.complex64)).algo_for(1 << 24) == c.FIR_DIRECT
     assert c.BatchFirNode(np.ones(63, np.complex64)).algo_for(1 << 24) == c.FIR_OS1024
