@@ -105,6 +105,12 @@ _PROTOS = {
     "comms_iq_i16_to_c32_dev": [_vp, _sz, C.c_float, _vp, _i32, _vp],
     "comms_iq_c32_to_i16_dev": [_vp, _sz, C.c_float, _vp, _i32, _vp],
     "comms_iq_u8_to_c32_dev": [_vp, _sz, _vp, _i32, _vp],
+    "comms_frequency_offset_estimate": [_vp, _sz, C.POINTER(_f64), _i32],
+    "comms_psk_phase_estimate": [_vp, _sz, _u32, C.POINTER(_f64), _i32],
+    "comms_qam_phase_estimate": [_vp, _sz, C.POINTER(_f64), _i32],
+    "comms_frequency_offset_estimate_dev": [_vp, _sz, C.POINTER(_f64), _i32, _vp],
+    "comms_psk_phase_estimate_dev": [_vp, _sz, _u32, C.POINTER(_f64), _i32, _vp],
+    "comms_qam_phase_estimate_dev": [_vp, _sz, C.POINTER(_f64), _i32, _vp],
     "comms_synth_iq_dev": [_vp, _sz, _u64, _u64, _i32, _vp],
 }
 _OTHER = {

@@ -386,6 +386,31 @@ def iq_u8_to_c32(x, device=0):
     return out
 
 
+# ------------------------------------------------------------------ block estimators
+def frequency_offset_estimate(samples, device=0):
+    """frequency_estimator.rs:27-42 on Complex<f64> samples."""
+    x = np.ascontiguousarray(samples, dtype=np.complex128)
+    out = C.c_double()
+    check(lib().comms_frequency_offset_estimate(_ptr(x), x.size, C.byref(out), device))
+    return out.value
+
+
+def psk_phase_estimate(symbols, m, device=0):
+    """phase_estimator.rs:26-33."""
+    x = np.ascontiguousarray(symbols, dtype=np.complex128)
+    out = C.c_double()
+    check(lib().comms_psk_phase_estimate(_ptr(x), x.size, int(m), C.byref(out), device))
+    return out.value
+
+
+def qam_phase_estimate(symbols, device=0):
+    """phase_estimator.rs:58-65."""
+    x = np.ascontiguousarray(symbols, dtype=np.complex128)
+    out = C.c_double()
+    check(lib().comms_qam_phase_estimate(_ptr(x), x.size, C.byref(out), device))
+    return out.value
+
+
 # ------------------------------------------------------------------ synthetic IQ
 def synth_iq(n, first_index=0, seed=0xC0FFEE):
     out = np.empty(int(n), np.complex64)

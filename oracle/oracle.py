@@ -249,6 +249,28 @@ def iq_u8_to_c32(x):
     return out
 
 
+# ------------------------------------------------------------------ block estimators (f64)
+def frequency_offset_estimate(samples):
+    """frequency_estimator.rs:27-42."""
+    x = np.ascontiguousarray(samples, dtype=np.complex128)
+    lib().orc_frequency_offset_estimate.restype = C.c_double
+    return lib().orc_frequency_offset_estimate(_p(x), _sz(x.size))
+
+
+def psk_phase_estimate(symbols, m):
+    """phase_estimator.rs:26-33."""
+    x = np.ascontiguousarray(symbols, dtype=np.complex128)
+    lib().orc_psk_phase_estimate.restype = C.c_double
+    return lib().orc_psk_phase_estimate(_p(x), _sz(x.size), C.c_uint32(int(m)))
+
+
+def qam_phase_estimate(symbols):
+    """phase_estimator.rs:58-65."""
+    x = np.ascontiguousarray(symbols, dtype=np.complex128)
+    lib().orc_qam_phase_estimate.restype = C.c_double
+    return lib().orc_qam_phase_estimate(_p(x), _sz(x.size))
+
+
 # ------------------------------------------------------------------ PRBS source
 def prns_u8(poly_mask, state, n):
     """prns.rs:64-71 on an 8-bit register.  Returns (bits, new_state)."""
