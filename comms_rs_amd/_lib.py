@@ -111,6 +111,16 @@ _PROTOS = {
     "comms_frequency_offset_estimate_dev": [_vp, _sz, C.POINTER(_f64), _i32, _vp],
     "comms_psk_phase_estimate_dev": [_vp, _sz, _u32, C.POINTER(_f64), _i32, _vp],
     "comms_qam_phase_estimate_dev": [_vp, _sz, C.POINTER(_f64), _i32, _vp],
+    "comms_timing_create": [_u32, _u32, _f64, _i32, _pp],
+    "comms_timing_push": [_vp, _vp, _sz, C.POINTER(_f64)],
+    "comms_timing_push_dev": [_vp, _vp, _sz, C.POINTER(_f64), _vp],
+    "comms_timing_destroy": [_vp],
+    "comms_qfilt_taps": [_u32, _f64, _u32, _vp],
+    "comms_nco_create": [_f64, _f64, _i32, _pp],
+    "comms_nco_run": [_vp, _vp, _sz, _vp],
+    "comms_nco_run_dev": [_vp, _vp, _sz, _vp, _vp],
+    "comms_nco_get_phase": [_vp, C.POINTER(_f64)],
+    "comms_nco_destroy": [_vp],
     "comms_synth_iq_dev": [_vp, _sz, _u64, _u64, _i32, _vp],
 }
 _OTHER = {
@@ -118,6 +128,7 @@ _OTHER = {
     "comms_last_error": (C.c_char_p, []),
     "comms_buf_ptr": (_vp, [_vp]),
     "comms_buf_size": (_sz, [_vp]),
+    "comms_qfilt_len": (_sz, [_u32]),
     "comms_buf_device": (_i32, [_vp]),
     "comms_synth_iq_host": (None, [_vp, _sz, _u64, _u64]),
 }

@@ -9,6 +9,8 @@
 //   PulseNode::new(taps, sam_per_sym)             src/pulse.rs:71
 //   DecimateNode / UpsampleNode::new(rate)        src/util/resample_node.rs:23, :87
 //   FMDemodNode::new()                            src/modulation/analog_node.rs:43
+//   TimingEstimatorNode::new(n, d, alpha)         src/demodulation/timing_estimator.rs:123
+//   NcoNode::new(dphase, phase) (block form)      src/demodulation/nco.rs:118
 // Messages are host vectors (std::vector<Complex>), moved through the channels by
 // value as in the reference; every run() goes H2D -> kernel -> D2H through the C
 // ABI.  The *Dev variants at the bottom keep messages device-resident
@@ -372,6 +374,69 @@ inline std::vector<Complex32> gaussian_taps(uint32_t n_taps, double sam_per_sym,
 inline std::vector<Complex32> rect_taps(size_t n_taps) {
     std::vector<Complex32> t(n_taps);
     throw_on(comms_rect_taps(n_taps, c32(t.data())), "rect_taps");
+    return t;
+}
+
+// ---------------------------------------------------------------- demodulation
+using Complex64 = std::complex<double>;
+
+// TimingEstimatorNode::new(n, d, alpha) -> Result<Self, MathError>; run(&[Complex<f64>]) -> f64
+// (src/demodulation/timing_estimator.rs:116-136).  A bad alpha throws (the reference returns Err).
+class TimingEstimatorNode : public DeriveNode<TimingEstimatorNode> {
+public:
+    NodeReceiver<std::vector<Complex64>> input;
+    NodeSender<double> output;
+
+    TimingEstimatorNode(uint32_t n, uint32_t d, double alpha, int device = 0) {
+        throw_on(comms_timing_create(n, d, alpha, device, &h_), "TimingEstimatorNode::new");
+    }
+    TimingEstimatorNode(TimingEstimatorNode&& o) noexcept
+        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_) { o.h_ = nullptr; }
+    ~TimingEstimatorNode() { comms_timing_destroy(h_); }
+
+    Result<double> run(const std::vector<Complex64>& samples) {
+        double est = 0.0;
+        comms_status_t st = comms_timing_push(h_, reinterpret_cast<const double*>(samples.data()), samples.size(), &est);
+        if (st != COMMS_OK) return to_node_error(st);
+        return est;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_timing_t* h_ = nullptr;
+};
+
+// NcoNode::new(dphase, Option<phase>) (src/demodulation/nco.rs:118-133) in block form: one
+// message is a vector of phase errors, the output is exp(i*phase) per sample.  (The reference
+// node is per sample, f64 -> Complex<f64>; a closed loop runs it at block rate here.)
+class BatchNcoNode : public DeriveNode<BatchNcoNode> {
+public:
+    NodeReceiver<std::vector<double>> input;
+    NodeSender<std::vector<Complex64>> output;
+
+    explicit BatchNcoNode(double dphase, double phase = 0.0, int device = 0) {
+        throw_on(comms_nco_create(dphase, phase, device, &h_), "NcoNode::new");
+    }
+    BatchNcoNode(BatchNcoNode&& o) noexcept : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_) { o.h_ = nullptr; }
+    ~BatchNcoNode() { comms_nco_destroy(h_); }
+
+    Result<std::vector<Complex64>> run(const std::vector<double>& perr) {
+        std::vector<Complex64> out(perr.size());
+        comms_status_t st = comms_nco_run(h_, perr.data(), perr.size(), reinterpret_cast<double*>(out.data()));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_nco_t* h_ = nullptr;
+};
+
+inline std::vector<double> qfilt_taps(uint32_t n_taps, double alpha, uint32_t sam_per_sym) {
+    std::vector<double> t(comms_qfilt_len(n_taps));
+    throw_on(comms_qfilt_taps(n_taps, alpha, sam_per_sym, t.data()), "qfilt_taps");
     return t;
 }
 

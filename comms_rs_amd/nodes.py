@@ -411,6 +411,60 @@ def qam_phase_estimate(symbols, device=0):
     return out.value
 
 
+class TimingEstimatorNode(_Handle):
+    """TimingEstimatorNode::new(n, d, alpha) / run (timing_estimator.rs:116-136): Complex<f64>
+    block in, timing offset in samples out."""
+    _destroy = "comms_timing_destroy"
+
+    def __init__(self, n, d, alpha, device=0):
+        super().__init__()
+        check(lib().comms_timing_create(int(n), int(d), float(alpha), device, C.byref(self._h)))
+
+    def run(self, samples):
+        x = np.ascontiguousarray(samples, dtype=np.complex128)
+        out = C.c_double()
+        check(lib().comms_timing_push(self._h, _ptr(x), x.size, C.byref(out)))
+        return out.value
+
+    def run_dev(self, in_ptr, n, stream=0):
+        out = C.c_double()
+        check(lib().comms_timing_push_dev(self._h, in_ptr, n, C.byref(out), stream))
+        return out.value
+
+
+def qfilt_taps(n_taps, alpha, sam_per_sym):
+    """util/math.rs:307-342 (f64, real); even n_taps is incremented."""
+    out = np.empty(lib().comms_qfilt_len(int(n_taps)), np.float64)
+    check(lib().comms_qfilt_taps(int(n_taps), float(alpha), int(sam_per_sym), _ptr(out)))
+    return out
+
+
+class NcoNode(_Handle):
+    """NcoNode::new(dphase, phase) (nco.rs:118-133) in block form: run() takes a vector of
+    phase errors and returns exp(i*phase) per sample (Complex<f64>)."""
+    _destroy = "comms_nco_destroy"
+
+    def __init__(self, dphase, phase=None, device=0):
+        super().__init__()
+        check(lib().comms_nco_create(float(dphase), 0.0 if phase is None else float(phase), device,
+                                     C.byref(self._h)))
+
+    def run(self, perr):
+        e = np.ascontiguousarray(perr, dtype=np.float64)
+        out = np.empty(e.size, np.complex128)
+        check(lib().comms_nco_run(self._h, _ptr(e), e.size, _ptr(out)))
+        return out
+
+    def run_dev(self, in_ptr, n, out_ptr, stream=0):
+        check(lib().comms_nco_run_dev(self._h, in_ptr, n, out_ptr, stream))
+
+    @property
+    def phase(self):
+        out = C.c_double()
+        check(lib().comms_nco_get_phase(self._h, C.byref(out)))
+        return out.value
+
+
 # ------------------------------------------------------------------ synthetic IQ
 def synth_iq(n, first_index=0, seed=0xC0FFEE):
     out = np.empty(int(n), np.complex64)

@@ -271,6 +271,35 @@ def qam_phase_estimate(symbols):
     return lib().orc_qam_phase_estimate(_p(x), _sz(x.size))
 
 
+def qfilt_taps(n_taps, alpha, sam_per_sym):
+    """util/math.rs:307-342; raises ValueError for alpha outside [0, 1]."""
+    out = np.zeros(int(n_taps) | 1, np.float64)
+    if lib().orc_qfilt_taps(C.c_uint32(int(n_taps)), C.c_double(alpha), C.c_uint32(int(sam_per_sym)), _p(out)):
+        raise ValueError("InvalidRolloffError")
+    return out
+
+
+def timing_push(samples, n, d, alpha):
+    """timing_estimator.rs:85-112 (one push of a fresh-state estimator)."""
+    x = np.ascontiguousarray(samples, dtype=np.complex128)
+    lib().orc_timing_push.restype = C.c_double
+    return lib().orc_timing_push(_p(x), _sz(x.size), C.c_uint32(int(n)), C.c_uint32(int(d)), C.c_double(alpha))
+
+
+class Nco:
+    """nco.rs:41-50, :71-77; NcoNode::new(dphase, phase) argument order."""
+
+    def __init__(self, dphase, phase=None):
+        self.dphase = float(dphase)
+        self.phase = C.c_double(0.0 if phase is None else float(phase))
+
+    def push(self, perr):
+        e = np.ascontiguousarray(perr, dtype=np.float64)
+        out = np.zeros(e.size, np.complex128)
+        lib().orc_nco_push(C.c_double(self.dphase), C.byref(self.phase), _p(e), _sz(e.size), _p(out))
+        return out
+
+
 # ------------------------------------------------------------------ PRBS source
 def prns_u8(poly_mask, state, n):
     """prns.rs:64-71 on an 8-bit register.  Returns (bits, new_state)."""

@@ -5,6 +5,7 @@
 //   mixer (phase 0 / 0.1)   src/mixer.rs:160-246, :250-336
 //   pulse (rect x4)         src/pulse.rs:105-209
 //   decimate / upsample     src/util/resample_node.rs:139-175
+//   timing estimator / NCO  src/demodulation/timing_estimator.rs:178-229, nco.rs:71-77
 // plus a device-resident FIR -> mixer -> decimate graph (DeviceBuf messages).
 // Needs an MI355X (libcomms_hip has no CPU fallback).
 #include <cmath>
@@ -168,6 +169,55 @@ static void test_fm_node() {
     }
 }
 
+static void test_demod_nodes() {
+    // timing_estimator.rs:178-229: QPSK x10 zero-stuffed through a 101-tap RRC; the estimate of
+    // samples[2..] must land within 0.01 samples of -2.  Symbols from an LCG (the reference
+    // draws them from SmallRng).
+    const uint32_t sps = 10;
+    auto rrc = rrc_taps(sps * 10 + 1, static_cast<double>(sps), 0.5);
+    std::vector<Complex64> sig(1000 * sps, Complex64(0, 0)), shaped(sig.size());
+    uint32_t lcg = 12345;
+    for (size_t k = 0; k < 1000; ++k) {
+        lcg = lcg * 1664525u + 1013904223u;
+        sig[k * sps] = std::polar(1.0, 2.0 * M_PI * ((lcg >> 24) & 3) / 4.0 + M_PI / 4.0);
+    }
+    for (size_t i = 0; i < sig.size(); ++i) {
+        Complex64 acc(0, 0);
+        for (size_t k = 0; k < rrc.size() && k <= i; ++k) acc += Complex64(rrc[k].real(), 0.0) * sig[i - k];
+        shaped[i] = acc;
+    }
+    Collect<double> est;
+    pump(Replay<std::vector<Complex64>>({std::vector<Complex64>(shaped.begin() + 2, shaped.end())}),
+         TimingEstimatorNode(sps, 5, 0.5), est);
+    CHECK(est.got.size() == 1);
+    if (est.got.size() == 1) CHECK(std::fabs(2.0 + est.got[0]) < 0.01);
+    bool threw = false;
+    try {
+        TimingEstimatorNode bad(10, 5, 1.5);
+    } catch (const std::runtime_error&) {
+        threw = true;
+    }
+    CHECK(threw);
+
+    // NCO: two blocks, phase carried across (nco.rs:71-77)
+    std::vector<double> e0(1000, 0.01), e1(500, -0.02);
+    Collect<std::vector<Complex64>> osc;
+    pump(Replay<std::vector<double>>({e0, e1}), BatchNcoNode(0.1, M_PI / 4.0), osc);
+    CHECK(osc.got.size() == 2);
+    if (osc.got.size() == 2) {
+        double ph = M_PI / 4.0, worst = 0.0;
+        for (size_t b = 0; b < 2; ++b)
+            for (size_t i = 0; i < osc.got[b].size(); ++i) {
+                ph += 0.1 + (b == 0 ? 0.01 : -0.02);
+                if (ph > 2.0 * M_PI) ph -= 2.0 * M_PI;
+                worst = std::fmax(worst, std::abs(osc.got[b][i] - std::polar(1.0, ph)));
+            }
+        CHECK(worst < 1e-10);
+    }
+    auto q = qfilt_taps(21, 0.25, 2);
+    CHECK(q.size() == 21 && q[6] == 0.0625 && std::fabs(q[10] - 0.07957747154594767) < 1e-16);
+}
+
 static void test_device_resident_graph() {
     // FIR -> mixer -> decimate with DeviceBuf messages; compare with the host-vector nodes
     const size_t n = 1 << 16;
@@ -216,6 +266,7 @@ int main() {
     test_pulse_node();
     test_resample_nodes();
     test_fm_node();
+    test_demod_nodes();
     test_device_resident_graph();
     if (g_fail) {
         std::fprintf(stderr, "%d check(s) failed\n", g_fail);

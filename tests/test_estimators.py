@@ -59,3 +59,97 @@ def test_device_estimators_vs_oracle():
     assert abs(0.123456 - c.psk_phase_estimate(cases[1], 8)) < 1e-6  # the reference's own bound
     with pytest.raises(c.CommsError):
         c.psk_phase_estimate(cases[1], 0)
+
+
+# ------------------------------------------------------------------ timing estimator + NCO
+def timing_stream(rng, alpha=0.5, sps=10, nsym=1000):
+    # timing_estimator.rs:151-176: QPSK, x10 zero-stuffed, 101-tap RRC
+    sym = np.exp(1j * (2 * np.pi * rng.integers(0, 4, nsym) / 4 + np.pi / 4))
+    up = np.zeros(nsym * sps, np.complex128)
+    up[::sps] = sym
+    taps = oracle.rrc_taps(sps * 10 + 1, float(sps), alpha, dtype=np.complex128)
+    return oracle.batch_fir(up, taps, oracle.default_state(taps))
+
+
+def test_qfilt_golden_oracle_and_host():
+    import json
+    import pathlib
+
+    g = json.loads((pathlib.Path(__file__).parent / "golden" / "reference_kats.json").read_text())["qfilt_taps"]
+    want = np.array(g["expected"])
+    got = oracle.qfilt_taps(g["n_taps"], g["alpha"], g["sam_per_sym"])
+    assert got.size == 21 and np.all(np.abs(got[:20] - want) < g["tol_abs"])
+    assert oracle.qfilt_taps(20, 0.25, 2).size == 21  # even counts are incremented (math.rs:317-320)
+    with pytest.raises(ValueError):
+        oracle.qfilt_taps(21, 1.5, 2)
+    # l'Hospital branch: 2*alpha*tt == +-1 exactly (alpha 0.5, tt = +-1)
+    t = oracle.qfilt_taps(9, 0.5, 2)
+    assert np.isfinite(t).all() and abs(t[2] - np.sin(np.pi * 0.5 * -1.0) / -8.0) < 1e-16
+    import comms_rs_amd as c  # host code of the product library: no GPU needed
+
+    assert np.array_equal(c.qfilt_taps(21, 0.25, 2), got)
+    assert np.array_equal(c.qfilt_taps(9, 0.5, 2), t)
+    with pytest.raises(c.CommsError):
+        c.qfilt_taps(21, -0.1, 2)
+
+
+def test_oracle_timing_meets_the_reference_test_bound():
+    # timing_estimator.rs:178-192: estimate of samples[truth..] within 0.01 samples of -truth
+    rng = np.random.default_rng(0)
+    x = timing_stream(rng)
+    for truth in (2, 0, 4):
+        assert abs(truth + oracle.timing_push(x[truth:], 10, 5, 0.5)) < 0.01
+
+
+def test_oracle_nco_against_closed_form():
+    # no test in the reference (nco.rs has none): parity unpinned; check the restatement
+    # against the closed form exp(i*(phase0 + cumsum(dphase + perr)))
+    rng = np.random.default_rng(2)
+    perr = 0.01 * rng.standard_normal(5000)
+    nco = oracle.Nco(0.1, np.pi / 4)
+    got = np.concatenate([nco.push(perr[:1234]), nco.push(perr[1234:])])
+    want = np.exp(1j * (np.pi / 4 + np.cumsum(0.1 + perr)))
+    assert np.max(np.abs(got - want)) < 1e-11
+    assert np.max(np.abs(oracle.Nco(0.1 + 4 * np.pi).push(perr) - oracle.Nco(0.1).push(perr))) < 1e-9
+
+
+@pytest.mark.gpu
+def test_device_timing_estimator_vs_oracle():
+    import comms_rs_amd as c
+
+    rng = np.random.default_rng(3)
+    x = timing_stream(rng)
+    for n, d, alpha, off in ((10, 5, 0.5, 2), (10, 5, 0.5, 0), (10, 30, 0.25, 3), (2, 5, 0.25, 0), (4, 1, 1.0, 1)):
+        est = c.TimingEstimatorNode(n, d, alpha)
+        got = est.run(x[off:])
+        want = oracle.timing_push(x[off:], n, d, alpha)
+        assert abs(got - want) < 1e-9, (n, d, alpha, off, got, want)
+        assert abs(est.run(x[off:]) - got) == 0.0  # fresh filter state on every push, reproducible
+    assert abs(2 + c.TimingEstimatorNode(10, 5, 0.5).run(x[2:])) < 0.01  # the reference's own bound
+    # ragged / tiny blocks, shorter than the filter
+    for ln in (1, 7, 100, 257, 513):
+        y = rng.standard_normal(ln) + 1j * rng.standard_normal(ln)
+        assert abs(c.TimingEstimatorNode(10, 5, 0.5).run(y) - oracle.timing_push(y, 10, 5, 0.5)) < 1e-9
+    with pytest.raises(c.CommsError):
+        c.TimingEstimatorNode(10, 5, 1.5)
+    with pytest.raises(c.CommsError):
+        c.TimingEstimatorNode(0, 5, 0.5)
+
+
+@pytest.mark.gpu
+def test_device_nco_vs_oracle():
+    import comms_rs_amd as c
+
+    rng = np.random.default_rng(4)
+    for dphase, phase, n in ((0.1, np.pi / 4, 5000), (0.1, None, 1), (6.0, 1.0, 2049), (-0.3, 0.0, 1 << 20),
+                             (2 * np.pi * 0.123 + 4 * np.pi, 5.0, 300000)):
+        perr = 0.01 * rng.standard_normal(n)
+        ref, dev = oracle.Nco(dphase, phase), c.NcoNode(dphase, phase)
+        cuts = sorted({0, n // 3, n // 3 + 1, n})
+        for a, b in zip(cuts[:-1], cuts[1:]):  # the phase persists across calls
+            got, want = dev.run(perr[a:b]), ref.push(perr[a:b])
+            assert np.max(np.abs(got - want)) < 1e-9, (dphase, n, a, b)
+        assert abs(np.exp(1j * dev.phase) - np.exp(1j * ref.phase.value)) < 1e-9
+    assert c.NcoNode(0.1).run(np.zeros(0)).size == 0
+    with pytest.raises(c.CommsError):
+        c.NcoNode(float("nan"))
