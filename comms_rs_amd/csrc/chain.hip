@@ -4,17 +4,20 @@
 // reference nodes in series -- MixerNode -> BatchFirNode -> DecimateNode
 // [-> FMDemodNode] (BASELINE config 3; examples/fm_radio.rs:146-148 order with a
 // mixer in front) or BatchFirNode -> MixerNode -> DecimateNode (the BASELINE
-// metric's chain).  Up to 257 taps it is one launch of the 1024-point
-// overlap-save kernel with the extra stages fused in registers
-// (fir_os1024_kernel<.., MODE>): 8 B read per input sample and 8/R (or 4/R) B
-// written, instead of 16 + 16 + 9 + 1.5 B for the four nodes.  Longer filters run
-// the four device kernels back to back through HBM temporaries.
+// metric's chain).  Up to 257 taps it is ONE launch: 8 B read per input sample and
+// 8/R (or 4/R) B written, instead of 16 + 16 + 9 + 1.5 B for the four nodes --
+//   * fir_decim_kernel (fir_decim.hip): time domain, computes only the kept outputs;
+//     used when taps/rate is small enough to beat the FFT (rates 2,3,4,5,6,8,10,12,16);
+//   * fir_os1024_kernel<.., MODE> (fir.hip): the 1024-point overlap-save kernel with
+//     the extra stages fused in registers, for everything else.
+// Longer filters run the four device kernels back to back through HBM temporaries.
 #include "common.hpp"
 
 using namespace comms;
 
 struct comms_chain : Handle {
     bool fused = false;
+    bool decim = false;  // fused on the time-domain decimating kernel
     int mode = 0;
     // fused path state
     comms_fir_t* fir = nullptr;
@@ -62,10 +65,14 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
     h->fm_demod = (flags & COMMS_CHAIN_FM_DEMOD) != 0;
     h->mixer_after = (flags & COMMS_CHAIN_MIXER_AFTER_FIR) != 0;
     st = comms_fir_create(taps, n_taps, nullptr, 0, device, &h->fir);
+    const int decim_ok = st == COMMS_OK && rate <= 16 ? comms_fir_decim_supported(h->fir, static_cast<uint32_t>(rate)) : 0;
+    const bool can_decim = !(flags & (COMMS_CHAIN_UNFUSED | COMMS_CHAIN_FREQ_DOMAIN)) &&
+                           (decim_ok == 2 || (decim_ok == 1 && (flags & COMMS_CHAIN_TIME_DOMAIN)));
     const bool can_fuse = !(flags & COMMS_CHAIN_UNFUSED) && n_taps <= 257 && rate <= (1u << 20) &&
                           (!h->fm_demod || (rate <= 64 && n_taps + rate <= 257));
-    if (st == COMMS_OK && can_fuse) {
+    if (st == COMMS_OK && (can_fuse || can_decim)) {
         h->fused = true;
+        h->decim = can_decim;
         h->mode = (h->mixer_after ? COMMS_CHAIN_POST : COMMS_CHAIN_PRE) | COMMS_CHAIN_DEC |
                   (h->fm_demod ? COMMS_CHAIN_FM : 0);
         h->frac = mix_to_turns(mix_wrap_dphase(dphase));
@@ -95,7 +102,7 @@ comms_status_t comms_chain_create(double dphase, double phase, const comms_c32* 
 
 comms_status_t comms_chain_is_fused(const comms_chain_t* h, int32_t* out_fused) {
     COMMS_ARG(h && out_fused, "NULL argument");
-    *out_fused = h->fused ? 1 : 0;
+    *out_fused = h->fused ? (h->decim ? 2 : 1) : 0;
     return COMMS_OK;
 }
 
@@ -108,9 +115,9 @@ comms_status_t comms_chain_run_dev(comms_chain_t* h, const comms_c32* d_in, size
     if (!n) return COMMS_OK;
     void* s = stream == COMMS_STREAM_HANDLE ? static_cast<void*>(h->stream) : stream;
     if (h->fused) {
-        COMMS_TRY(comms_fir_run_fused_dev(h->fir, d_in, n, d_out, h->mode, h->turns, h->frac,
-                                          static_cast<uint32_t>(h->rate), h->d_prev[h->cur],
-                                          h->d_prev[h->cur ^ 1], s));
+        COMMS_TRY((h->decim ? comms_fir_run_decim_dev : comms_fir_run_fused_dev)(
+            h->fir, d_in, n, d_out, h->mode, h->turns, h->frac, static_cast<uint32_t>(h->rate), h->d_prev[h->cur],
+            h->d_prev[h->cur ^ 1], s));
         h->turns += static_cast<uint64_t>(n) * h->frac;
         if (h->fm_demod) h->cur ^= 1;
         return COMMS_OK;

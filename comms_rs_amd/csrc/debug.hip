@@ -46,6 +46,47 @@ __global__ __launch_bounds__(256) void probe_tile4_kernel(const float4* __restri
     }
 }
 
+// modes 4/5: the four-step FFT passes' access patterns for N = 2^20 (1024 x 1024) without the
+// math: one 16-wave workgroup per CU owns 16-transform tiles, the next tile's 16 loads per lane
+// are requested before this tile's 16 stores.  ROWIN 0: 16 adjacent columns in, same places
+// out (128-B chunks at 8-KiB stride both ways); ROWIN 1: 16 adjacent rows in (256-B runs),
+// transposed out (128-B chunks).
+template <int ROWIN>
+__global__ __launch_bounds__(1024) void probe_fft_tile_kernel(const float2* __restrict__ in, float2* __restrict__ out,
+                                                              size_t n_tiles) {
+    const unsigned tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    unsigned in_off, out_off;
+    if (ROWIN) {
+        const unsigned c = 2 * (w & 7) + (l >> 5), r0 = 32 * (w >> 3) + (l & 31);
+        in_off = c * 1024 + r0;                      // + 64 a
+        out_off = (w + 16 * (l >> 4)) * 1024 + (l & 15);  // + (64 i + 256 k2) * 1024
+    } else {
+        const unsigned c = tid & 15, r0 = tid >> 4;
+        in_off = r0 * 1024 + c;  // + 64 a * 1024
+        out_off = (w + 16 * (l >> 4)) * 1024 + (l & 15);
+    }
+    auto src = [&](size_t t) { return in + (t >> 6) * (1u << 20) + (t & 63) * (ROWIN ? 16 * 1024 : 16); };
+    float2 x[16];
+    if (blockIdx.x < n_tiles) {
+        const float2* sp = src(blockIdx.x);
+#pragma unroll
+        for (int a = 0; a < 16; ++a) x[a] = sp[in_off + a * (ROWIN ? 64u : 65536u)];
+    }
+    for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        float2 v[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = x[a];
+        if (t + gridDim.x < n_tiles) {
+            const float2* sp = src(t + gridDim.x);
+#pragma unroll
+            for (int a = 0; a < 16; ++a) x[a] = sp[in_off + a * (ROWIN ? 64u : 65536u)];
+        }
+        float2* dp = out + (t >> 6) * (1u << 20) + (t & 63) * 16;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) dp[out_off + a * 65536u] = v[a];
+    }
+}
+
 }  // namespace comms
 
 using namespace comms;
@@ -60,6 +101,13 @@ extern "C" comms_status_t comms_debug_copy(const void* d_in, void* d_out, size_t
     } else if (mode == 2) {
         const size_t ntiles = n_c32 / 768, runs = static_cast<size_t>(waves_per_cu) * kNumCU;
         probe_tile_kernel<12><<<dim3((runs + 3) / 4), dim3(256), 0, s>>>(static_cast<const float2*>(d_in), static_cast<float2*>(d_out), ntiles, runs);
+    } else if (mode == 4 || mode == 5) {
+        const size_t n_tiles = (n_c32 >> 20) * 64;  // 64 tiles of 16 transforms per 2^20-point matrix
+        const unsigned blocks = static_cast<unsigned>(waves_per_cu > 0 ? waves_per_cu : kNumCU);
+        if (mode == 4)
+            probe_fft_tile_kernel<0><<<dim3(blocks), dim3(1024), 0, s>>>(static_cast<const float2*>(d_in), static_cast<float2*>(d_out), n_tiles);
+        else
+            probe_fft_tile_kernel<1><<<dim3(blocks), dim3(1024), 0, s>>>(static_cast<const float2*>(d_in), static_cast<float2*>(d_out), n_tiles);
     } else {
         const size_t ntiles = n_c32 / 768, runs = static_cast<size_t>(waves_per_cu) * kNumCU;
         probe_tile4_kernel<<<dim3((runs + 3) / 4), dim3(256), 0, s>>>(static_cast<const float4*>(d_in), static_cast<float4*>(d_out), ntiles, runs);

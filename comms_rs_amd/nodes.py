@@ -313,11 +313,15 @@ class ChainNode(_Handle):
     mixer_after_fir=False: mixer -> FIR -> decimate [-> FM]; True: FIR -> mixer -> decimate."""
     _destroy = "comms_chain_destroy"
 
-    def __init__(self, dphase, phase, taps, rate, fm_demod, device=0, mixer_after_fir=False, unfused=False):
+    def __init__(self, dphase, phase, taps, rate, fm_demod, device=0, mixer_after_fir=False, unfused=False,
+                 kernel="auto"):
+        """kernel: "auto", "freq" (always the overlap-save kernel) or "time" (the decimating
+        time-domain kernel wherever it applies)."""
         super().__init__()
         taps = _as_c64(taps)
         self.rate, self.fm_demod = int(rate), bool(fm_demod)
         flags = (1 if fm_demod else 0) | (2 if mixer_after_fir else 0) | (4 if unfused else 0)
+        flags |= {"auto": 0, "freq": 8, "time": 16}[kernel]
         check(lib().comms_chain_create_ex(float(dphase), float(phase), _ptr(taps), taps.size, self.rate,
                                           flags, device, C.byref(self._h)))
 
@@ -326,6 +330,13 @@ class ChainNode(_Handle):
         f = C.c_int32()
         check(lib().comms_chain_is_fused(self._h, C.byref(f)))
         return bool(f.value)
+
+    @property
+    def kernel(self):
+        """"unfused", "freq" (fir_os1024_kernel) or "time" (fir_decim_kernel)."""
+        f = C.c_int32()
+        check(lib().comms_chain_is_fused(self._h, C.byref(f)))
+        return ("unfused", "freq", "time")[f.value]
 
     def run(self, x):
         x = _as_c64(x)

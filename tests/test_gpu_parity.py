@@ -500,18 +500,21 @@ def fm_stream(n, first=0):
     return np.exp(1j * phase).astype(np.complex64)
 
 
+@pytest.mark.parametrize("kernel", ["auto", "time", "freq"])
 @pytest.mark.parametrize("fm", [False, True])
-def test_config3_mixer_fir_decimate_fm_chain(c, fm):
+def test_config3_mixer_fir_decimate_fm_chain(c, fm, kernel):
     """BASELINE config 3 (mixer -> 127-tap LPF -> /8 -> FM demod): node by node, through the
-    fused chain node and through the unfused chain node, in three batches (state carry-over)."""
+    fused chain node (time-domain decimating kernel = the default here, and the overlap-save
+    kernel) and through the unfused chain node, in three batches (state carry-over)."""
     n = 1 << 18
     x = fm_stream(n)
     taps = lowpass_taps(127, 1 / 16)
     dphase = 2 * np.pi * 0.05
     om, ost, ofm = oracle.Mixer(0.0, dphase), oracle.default_state(taps), oracle.FM()
-    fused = c.ChainNode(dphase, 0.0, taps, 8, fm)
+    fused = c.ChainNode(dphase, 0.0, taps, 8, fm, kernel=kernel)
     plain = c.ChainNode(dphase, 0.0, taps, 8, fm, unfused=True)
-    assert fused.fused and not plain.fused
+    assert fused.fused and not plain.fused and plain.kernel == "unfused"
+    assert fused.kernel == ("time" if kernel == "auto" else kernel)
     gm, gf, gd, gfm = c.MixerNode(dphase), c.BatchFirNode(taps), c.DecimateNode(8), c.FMDemodNode()
     for a, b in [(0, 8 * 1000), (8 * 1000, 8 * 1001), (8 * 1001, n)]:
         w = oracle.decimate(oracle.batch_fir(om.mix(x[a:b]), taps, ost, norotate=True), 8)
@@ -532,8 +535,9 @@ def test_config3_mixer_fir_decimate_fm_chain(c, fm):
             fir_close(got, w, taps, x)
 
 
+@pytest.mark.parametrize("kernel", ["auto", "time", "freq"])
 @pytest.mark.parametrize("rate", [1, 2, 5, 8, 64, 100])
-def test_metric_chain_fir_mixer_decimate_fused(c, rate):
+def test_metric_chain_fir_mixer_decimate_fused(c, rate, kernel):
     """The BASELINE metric's chain (255-tap FIR -> mixer -> decimate) as one fused node."""
     rng = np.random.default_rng(rate)
     n = 40 * 768 * rate // np.gcd(768, rate)
@@ -541,8 +545,12 @@ def test_metric_chain_fir_mixer_decimate_fused(c, rate):
     x = rand_c(rng, n)
     taps = oracle.rrc_taps(255, 8.0, 0.35)
     dphase = 2 * np.pi * 0.1
-    node = c.ChainNode(dphase, 0.3, taps, rate, False, mixer_after_fir=True)
+    node = c.ChainNode(dphase, 0.3, taps, rate, False, mixer_after_fir=True, kernel=kernel)
     assert node.fused
+    if kernel == "time":  # forced: every rate with an instantiation, whatever taps/rate is
+        assert node.kernel == ("time" if rate in (2, 5, 8) else "freq")
+    elif kernel == "auto":  # 255 real taps: 32 MACs per input sample at rate 8, 128 at rate 2
+        assert node.kernel == ("time" if rate == 8 else "freq")
     ost, om = oracle.default_state(taps), oracle.Mixer(0.3, dphase)
     cut = (n // 3) - (n // 3) % rate
     for a, b in [(0, cut), (cut, n)]:
@@ -550,13 +558,14 @@ def test_metric_chain_fir_mixer_decimate_fused(c, rate):
         fir_close(node.run(x[a:b]), w, taps, x)
 
 
+@pytest.mark.parametrize("kernel", ["time", "freq"])
 @pytest.mark.parametrize("rate", [3, 5, 8, 64])
-def test_fused_fm_chain_rates_and_fallbacks(c, rate):
+def test_fused_fm_chain_rates_and_fallbacks(c, rate, kernel):
     n = 768 * rate * 6
     x = fm_stream(n)
     taps = lowpass_taps(63, 1 / (2.5 * rate))
-    node = c.ChainNode(0.3, 0.1, taps, rate, True)
-    assert node.fused
+    node = c.ChainNode(0.3, 0.1, taps, rate, True, kernel=kernel)
+    assert node.fused and node.kernel == (kernel if rate != 64 else "freq")
     ost, om, ofm = oracle.default_state(taps), oracle.Mixer(0.1, 0.3), oracle.FM()
     for a, b in [(0, 768 * rate), (768 * rate, n)]:
         w = ofm.demod(oracle.decimate(oracle.batch_fir(om.mix(x[a:b]), taps, ost, norotate=True), rate))
@@ -566,11 +575,48 @@ def test_fused_fm_chain_rates_and_fallbacks(c, rate):
         ok = mag > 0.05  # the angle is ill-conditioned where the filtered signal is ~0
         assert np.max(circ(got.astype(np.float64) - w)[ok]) <= 1e-4
     # combinations the fused kernel does not cover fall back to the four-kernel path
-    assert not c.ChainNode(0.3, 0.1, lowpass_taps(255, 0.1), 8, True).fused      # taps + rate > 257
+    assert c.ChainNode(0.3, 0.1, lowpass_taps(255, 0.1), 8, True).kernel == "time"
+    assert not c.ChainNode(0.3, 0.1, lowpass_taps(255, 0.1), 8, True, kernel="freq").fused  # taps + rate > 257
+    assert not c.ChainNode(0.3, 0.1, lowpass_taps(255, 0.1), 7, True).fused      # ... and no time kernel for /7
     assert not c.ChainNode(0.3, 0.1, lowpass_taps(63, 0.1), 128, True).fused     # rate > 64
     assert not c.ChainNode(0.3, 0.1, lowpass_taps(300, 0.1), 8, False).fused     # > 257 taps
     with pytest.raises(c.CommsError):
         c.ChainNode(0.3, 0.1, taps, 8, True).run(x[:12])  # n not a multiple of rate
+
+
+@pytest.mark.parametrize("rate", [2, 3, 4, 5, 6, 8, 10, 12, 16])
+def test_time_domain_decimating_chain_kernel(c, rate):
+    """fir_decim_kernel on every instantiated rate: real and complex taps, tap counts around the
+    block edges (1 .. 257), mixer before / after the FIR, with and without FM demod, ragged
+    lengths (a single output, one short of / one past a tile) and state carried over batches."""
+    rng = np.random.default_rng(100 + rate)
+    for n_taps, real, after, fm in [(1, True, False, False), (2, False, True, False), (2 * rate, True, False, True),
+                                    (2 * rate + 1, False, False, False), (63, True, True, True),
+                                    (127, True, False, True), (129, False, True, False), (257, True, False, False)]:
+        taps = lowpass_taps(n_taps, 1 / (2.5 * rate))
+        if not real:
+            taps = (taps * np.exp(0.2j * np.arange(n_taps))).astype(np.complex64)
+        node = c.ChainNode(0.3, 0.1, taps, rate, fm, mixer_after_fir=after, kernel="time")
+        assert node.kernel == "time"
+        cuts = [0, rate, rate * 512, rate * (512 + 511), rate * (3 * 512 + 1), rate * 5000]
+        n = cuts[-1]
+        x = fm_stream(n) if fm else rand_c(rng, n)
+        ost, om, ofm = oracle.default_state(taps), oracle.Mixer(0.1, 0.3), oracle.FM()
+        ys = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if after:
+                y = oracle.decimate(om.mix(oracle.batch_fir(x[a:b], taps, ost, norotate=True)), rate)
+            else:
+                y = oracle.decimate(oracle.batch_fir(om.mix(x[a:b]), taps, ost, norotate=True), rate)
+            got = node.run(x[a:b])
+            if fm:
+                w = ofm.demod(y)
+                prev = np.concatenate([ys[-1][-1:] if ys else [0.0], y[:-1]])
+                ok = np.minimum(np.abs(y), np.abs(prev)) > 0.05  # the angle is ill-conditioned near 0
+                assert got.shape == w.shape and np.max(circ(got.astype(np.float64) - w)[ok], initial=0.0) <= 1e-4, (n_taps, a, b)
+            else:
+                fir_close(got, y, taps, x)
+            ys.append(y)
 
 
 def test_config3_full_size_2p26_fused_vs_nodes(c):
@@ -587,11 +633,15 @@ def test_config3_full_size_2p26_fused_vs_nodes(c):
     s = torch.cuda.current_stream().cuda_stream
     a = torch.empty(n // 8, dtype=torch.complex64, device="cuda:0")
     b = torch.empty_like(a)
-    c.ChainNode(dphase, 0.0, taps, 8, False).run_dev(x.data_ptr(), n, a.data_ptr(), s)
+    a2 = torch.empty_like(a)
+    c.ChainNode(dphase, 0.0, taps, 8, False, kernel="time").run_dev(x.data_ptr(), n, a.data_ptr(), s)
+    c.ChainNode(dphase, 0.0, taps, 8, False, kernel="freq").run_dev(x.data_ptr(), n, a2.data_ptr(), s)
     c.ChainNode(dphase, 0.0, taps, 8, False, unfused=True).run_dev(x.data_ptr(), n, b.data_ptr(), s)
     torch.cuda.synchronize()
     scale = float(np.sum(np.abs(taps)))
     assert float((a - b).abs().max()) <= TOL * scale
+    assert float((a2 - b).abs().max()) <= TOL * scale
+    del a2
     for start in (0, 1 << 20, n - 65536):  # multiples of 8
         lo = max(0, start - 126)
         xs = c.synth_iq(start + 16384 - lo, lo, 3)
@@ -604,13 +654,14 @@ def test_config3_full_size_2p26_fused_vs_nodes(c):
     # FM demod variant: fused vs unfused on the circle, where the signal is not ~0
     fa = torch.empty(n // 8, dtype=torch.float32, device="cuda:0")
     fb = torch.empty_like(fa)
-    c.ChainNode(dphase, 0.0, taps, 8, True).run_dev(x.data_ptr(), n, fa.data_ptr(), s)
     c.ChainNode(dphase, 0.0, taps, 8, True, unfused=True).run_dev(x.data_ptr(), n, fb.data_ptr(), s)
-    torch.cuda.synchronize()
     mag = torch.minimum(b.abs(), torch.roll(b.abs(), 1))
-    d = (fa - fb).abs()
-    d = torch.minimum(d, 2 * np.pi - d)
-    assert float((d * mag).max()) <= 4 * TOL * scale  # angle error x magnitude ~ FIR error
+    for kernel in ("time", "freq"):
+        c.ChainNode(dphase, 0.0, taps, 8, True, kernel=kernel).run_dev(x.data_ptr(), n, fa.data_ptr(), s)
+        torch.cuda.synchronize()
+        d = (fa - fb).abs()
+        d = torch.minimum(d, 2 * np.pi - d)
+        assert float((d * mag).max()) <= 4 * TOL * scale  # angle error x magnitude ~ FIR error
 
 
 def test_fm_radio_example_chain(c):
