@@ -56,6 +56,7 @@ struct DecimArgs {
     float2 step[2 * DC_RMAX];      // e^{i * 256 m * dphi}, staging row m
     float are[DC_AMAX];            // A[m] = Re h[m - (2R-1)], zero outside [0, N)
     float aim[DC_AMAX];
+    unsigned long long* stamps;    // diagnostic (scripts/stamp_decim.py): per-wave cycles per phase, or NULL
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -94,6 +95,40 @@ __device__ __forceinline__ void rotor_step(double& c, double& s, double sc, doub
     const double nc = c * sc - s * ss;
     s = c * ss + s * sc;
     c = nc;
+}
+
+// atan2 for the fused FM demod: |error| <= ~2e-7 rad (the reference's f32 atan2 is good to 1 ulp,
+// 2.4e-7 near pi), about a third of the library routine's instructions.  Minimax fit of
+// atan(t)/t in t^2 on [0, 1] (degree 8), octant folding on max/min, signed zeros as atan2.
+__device__ __forceinline__ float fast_atan2f(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mx > 0.f ? mn * __builtin_amdgcn_rcpf(mx) : 0.f;
+    const float z = t * t;
+    float p = 0.0024567078799009323f;
+    p = __builtin_fmaf(p, z, -0.014401284977793694f);
+    p = __builtin_fmaf(p, z, 0.03978108987212181f);
+    p = __builtin_fmaf(p, z, -0.0723484456539154f);
+    p = __builtin_fmaf(p, z, 0.10498938709497452f);
+    p = __builtin_fmaf(p, z, -0.14161226153373718f);
+    p = __builtin_fmaf(p, z, 0.19985906779766083f);
+    p = __builtin_fmaf(p, z, -0.33332598209381104f);
+    p = __builtin_fmaf(p, z, 0.9999998807907104f);
+    float r = p * t;
+    if (ay > ax) r = 1.57079637f - r;
+    if (__builtin_signbit(x)) r = 3.14159274f - r;
+    return __builtin_copysignf(r, y);
+}
+// FM::demod step (src/modulation/analog.rs:27-28) with the fast atan2
+__device__ __forceinline__ float fm_step_fast(float2 x, float2 p) {
+    const float pcr = p.x, pci = -p.y;
+    return fast_atan2f(x.x * pci + x.y * pcr, x.x * pcr - x.y * pci);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would
+// stall on the next tile's global loads that are deliberately left in flight across it.
+__device__ __forceinline__ void lds_barrier() {  // (kept light: nothing global is shared between waves here)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 template <int R, bool REAL>
@@ -152,41 +187,61 @@ __global__ __launch_bounds__(DC_WG, DcGeom<R>::WGPC) void fir_decim_kernel(const
         slot_h[m] = s < static_cast<unsigned>(hl) ? static_cast<int>((s % PR) * S + s / PR) : -1;
     }
 
-    for (size_t t = t0; t < t1; ++t) {
-        const long long jb = static_cast<long long>(t) * ts - ovl;  // first output computed by this tile
-        const long long ib = R * jb;                                // its input sample
-        // ---- stage the tile: 2R rows of new samples, then the halo (<= 2 rows)
-        {
-            cf x[PR], xh[2];
-            if (ib - hl >= 0 && static_cast<size_t>(ib) + 256u * PR <= a.n) {  // interior tile: no edge handling
-                const float2* src = a.in + ib;
+    // The tile's samples travel global -> VGPRs -> (mixer) -> LDS.  (Requesting the next tile's
+    // rows before this tile's filter loop was measured and does not pay: it costs 36 VGPRs, i.e.
+    // either the persistent row rotors or the fourth workgroup per CU, and the four workgroups
+    // already cover each other's loads: 158 us without, 162-171 us with, config 3 at 2^26.)
+    cf x[PR], xh[2];
+    auto load_tile = [&](size_t t) {
+        const long long ib = R * (static_cast<long long>(t) * ts - ovl);
+        if (ib - hl >= 0 && static_cast<size_t>(ib) + 256u * PR <= a.n) {  // interior tile: no edge handling
+            const float2* src = a.in + ib;
 #pragma unroll
-                for (int m = 0; m < PR; ++m) x[m] = to_cf((src + 256 * m)[static_cast<unsigned>(tid)]);
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-                    xh[m] = slot_h[m] >= 0 ? to_cf((src - hl + 256 * m)[static_cast<unsigned>(tid)]) : cf{0.f, 0.f};
-            } else {
-#pragma unroll
-                for (int m = 0; m < PR; ++m)
-                    x[m] = to_cf(stream_at(a.in, a.hist, a.hist_len, ib + tid + 256 * m, a.n));
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-                    xh[m] = slot_h[m] >= 0 ? to_cf(stream_at(a.in, a.hist, a.hist_len, ib - hl + tid + 256 * m, a.n))
-                                           : cf{0.f, 0.f};
-            }
-            if (pre) {
-#pragma unroll
-                for (int m = 0; m < PR; ++m) x[m] = cmulf(x[m], lrow[m]);
-#pragma unroll
-                for (int m = 0; m < 2; ++m) xh[m] = cmulf(xh[m], lhalo[m]);
-            }
-#pragma unroll
-            for (int m = 0; m < PR; ++m) sh[slot[m]] = x[m];
+            for (int m = 0; m < PR; ++m) x[m] = to_cf((src + 256 * m)[static_cast<unsigned>(tid)]);
 #pragma unroll
             for (int m = 0; m < 2; ++m)
-                if (slot_h[m] >= 0) sh[slot_h[m]] = xh[m];
+                xh[m] = slot_h[m] >= 0 ? to_cf((src - hl + 256 * m)[static_cast<unsigned>(tid)]) : cf{0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int m = 0; m < PR; ++m) x[m] = to_cf(stream_at(a.in, a.hist, a.hist_len, ib + tid + 256 * m, a.n));
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                xh[m] = slot_h[m] >= 0 ? to_cf(stream_at(a.in, a.hist, a.hist_len, ib - hl + tid + 256 * m, a.n))
+                                       : cf{0.f, 0.f};
         }
-        __syncthreads();
+    };
+
+    // diagnostic only: cycles per phase, summed per wave (every stamp drains the memory counters)
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long st_prev = 0;
+#define DC_STAMP(i)                                                     \
+    if (a.stamps) {                                                     \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
+        const unsigned long long st_now = __builtin_amdgcn_s_memtime(); \
+        st_acc[i] += st_now - st_prev;                                  \
+        st_prev = st_now;                                               \
+    }
+    if (a.stamps) st_prev = __builtin_amdgcn_s_memtime();
+
+    for (size_t t = t0; t < t1; ++t) {
+        const long long jb = static_cast<long long>(t) * ts - ovl;  // first output computed by this tile
+        // ---- stage the tile: 2R rows of new samples, then the halo (<= 2 rows)
+        load_tile(t);
+        DC_STAMP(0)  // global loads landed
+        if (pre) {
+#pragma unroll
+            for (int m = 0; m < PR; ++m) x[m] = cmulf(x[m], lrow[m]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) xh[m] = cmulf(xh[m], lhalo[m]);
+        }
+#pragma unroll
+        for (int m = 0; m < PR; ++m) sh[slot[m]] = x[m];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+            if (slot_h[m] >= 0) sh[slot_h[m]] = xh[m];
+        DC_STAMP(1)  // mixer + LDS writes
+        lds_barrier();
+        DC_STAMP(2)
 
         // ---- outputs j = jb + 2 tid + c:  y_c = sum_k h[k] u[R j - k]
         // tile sample index of u[R j - k] is 2R (tid + hlq) + (R c - k) = 2R (tid + hlq - d) + p with
@@ -243,6 +298,7 @@ __global__ __launch_bounds__(DC_WG, DcGeom<R>::WGPC) void fir_decim_kernel(const
         }
 
         // ---- epilogue: mixer after the FIR, FM demod, stores
+        DC_STAMP(4)  // filter loop
         float2 y0 = to_f2(acc0), y1 = to_f2(acc1);
         if (pre) {
             const cf tt = cf{static_cast<float>(tt_c), static_cast<float>(tt_s)};
@@ -261,13 +317,13 @@ __global__ __launch_bounds__(DC_WG, DcGeom<R>::WGPC) void fir_decim_kernel(const
             if (j0 < 0) y0 = a.fm_prev[0];  // FM.prev of the previous call stands in for y[-1]
             if (l == 63) sh_y[w] = y1;
         }
-        __syncthreads();  // sh_y visible; every lane is done reading the staged tile
+        lds_barrier();  // sh_y visible; every lane is done reading the staged tile
         if (fm) {
             float2 p0 = make_float2(__shfl_up(y1.x, 1), __shfl_up(y1.y, 1));
             if (l == 0 && w > 0) p0 = sh_y[w - 1];
             float* o = static_cast<float*>(a.out);
-            if (tid > 0 && j0 < static_cast<long long>(a.n_out)) o[j0] = fm_step(y0, p0);
-            if (j1 < static_cast<long long>(a.n_out)) o[j1] = fm_step(y1, y0);
+            if (tid > 0 && j0 < static_cast<long long>(a.n_out)) o[j0] = fm_step_fast(y0, p0);
+            if (j1 < static_cast<long long>(a.n_out)) o[j1] = fm_step_fast(y1, y0);
             if (j0 == static_cast<long long>(a.n_out) - 1) a.fm_prev_new[0] = y0;
             if (j1 == static_cast<long long>(a.n_out) - 1) a.fm_prev_new[0] = y1;
         } else {
@@ -275,7 +331,11 @@ __global__ __launch_bounds__(DC_WG, DcGeom<R>::WGPC) void fir_decim_kernel(const
             if (j0 < static_cast<long long>(a.n_out)) o[j0] = y0;
             if (j1 < static_cast<long long>(a.n_out)) o[j1] = y1;
         }
+        DC_STAMP(5)  // barrier 2 + epilogue + stores
     }
+    if (a.stamps && l == 0)
+        for (int i = 0; i < 6; ++i) a.stamps[(static_cast<size_t>(blockIdx.x) * (DC_WG / 64) + w) * 8 + i] = st_acc[i];
+#undef DC_STAMP
 }
 
 template <int R>
@@ -303,7 +363,12 @@ static comms_status_t launch_decim(const DecimArgs& a, bool real, hipStream_t s)
 
 using namespace comms;
 
+static unsigned long long* g_decim_stamps = nullptr;
+
 extern "C" {
+
+// diagnostic hook (not in the public header): device buffer of 8 u64 per wave, or NULL
+void comms_debug_decim_stamps(void* d_buf) { g_decim_stamps = static_cast<unsigned long long*>(d_buf); }
 
 // Whether (taps, rate) runs on the decimating kernel: 0 = no (no instantiation for the rate, or
 // taps beyond the kernel-argument budget), 1 = it can, 2 = and with few enough MACs per input
@@ -316,7 +381,7 @@ int32_t comms_fir_decim_supported(const comms_fir_t* h, uint32_t rate) {
     }
     static const int max_macs = [] {
         const char* v = getenv("COMMS_DECIM_MAX_MACS");
-        return v && *v ? atoi(v) : 48;
+        return v && *v ? atoi(v) : 44;
     }();
     const int macs = (h->n_eff + static_cast<int>(rate) - 1) / static_cast<int>(rate) * (h->real_taps ? 1 : 2);
     return macs <= max_macs ? 2 : 1;
@@ -353,6 +418,8 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const comms_c32* d_in, si
     a.mode = mode;
     a.turns0 = turns0;
     a.frac = frac;
+    a.stamps = g_decim_stamps;
+    if (getenv("COMMS_DECIM_DEBUG_NOMAC")) a.nd = 0;  // diagnostic: staging + epilogue only
     mix_host_rotor(static_cast<uint64_t>(R) * ts * frac, a.tile_c, a.tile_s);
     double c, sn;
     mix_host_rotor(static_cast<uint64_t>(R) * frac, c, sn);

@@ -41,7 +41,7 @@ for name, logn, taps, after, fm in (("config2 FIR255->mix->/8", 24, c.rrc_taps(2
                                     ("mix->cplx127->/8 (32 MACs/sample)", 24, lpf(127, 1 / 16.0) * np.exp(0.2j * np.arange(127)).astype(np.complex64), False, False)):
     if os.environ.get("CHAIN_ONLY", "") not in name:
         continue
-    n = 1 << logn
+    n = 1 << int(os.environ.get("CHAIN_LOGN", logn))
     rate = int(name.split("->/")[1].split("-")[0].split(" ")[0])
     n -= n % (rate * 1024)
     x = torch.empty(n, dtype=torch.complex64, device="cuda:0")
