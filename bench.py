@@ -229,6 +229,8 @@ def main():
         }
         out["fused_chain"] = {"value": round(total / fused_elapsed / 1e6, 1), "unit": "Msamples/s",
                               "ms_per_step": round(fused_elapsed / args.steps * 1e3, 4), "fused": chain.fused,
+                              "kernel": {"time": "fir_decim_kernel", "freq": "fir_os1024_kernel<.., MODE>",
+                                         "unfused": "four kernels"}[chain.kernel],
                               "note": "same FIR->mixer->decimate chain as one comms_chain_* launch "
                                       "(8 B read + 1 B written per input sample); not the headline value"}
         if world == 1 and not args.no_cpu_baseline:
