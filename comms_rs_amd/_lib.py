@@ -98,6 +98,7 @@ _PROTOS = {
     "comms_chain_is_fused": [_vp, C.POINTER(_i32)],
     "comms_chain_run_dev": [_vp, _vp, _sz, _vp, _vp],
     "comms_chain_run": [_vp, _vp, _sz, _vp],
+    "comms_chain_set_fir_state": [_vp, _vp, _sz],
     "comms_chain_destroy": [_vp],
     "comms_iq_i16_to_c32": [_vp, _sz, C.c_float, _vp, _i32],
     "comms_iq_c32_to_i16": [_vp, _sz, C.c_float, _vp, _i32],

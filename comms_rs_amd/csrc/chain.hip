@@ -11,6 +11,9 @@
 //   * fir_os1024_kernel<.., MODE> (fir.hip): the 1024-point overlap-save kernel with
 //     the extra stages fused in registers, for everything else.
 // Longer filters run the four device kernels back to back through HBM temporaries.
+#include <cmath>
+#include <vector>
+
 #include "common.hpp"
 
 using namespace comms;
@@ -28,6 +31,7 @@ struct comms_chain : Handle {
     comms_mixer_t* mixer = nullptr;
     comms_fmdemod_t* fm = nullptr;
     size_t rate = 1;
+    double dphase = 0.0;  // wrapped, as the mixer steps it
     bool fm_demod = false, mixer_after = false;
     Scratch t1, t2, t3;
 };
@@ -62,6 +66,7 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
         return st;
     }
     h->rate = rate;
+    h->dphase = mix_wrap_dphase(dphase);
     h->fm_demod = (flags & COMMS_CHAIN_FM_DEMOD) != 0;
     h->mixer_after = (flags & COMMS_CHAIN_MIXER_AFTER_FIR) != 0;
     st = comms_fir_create(taps, n_taps, nullptr, 0, device, &h->fir);
@@ -161,6 +166,26 @@ comms_status_t comms_chain_run(comms_chain_t* h, const comms_c32* in, size_t n, 
 comms_status_t comms_chain_set_timer(comms_chain_t* h, comms_timer_t* t) {
     COMMS_ARG(h != nullptr, "handle is NULL");
     return comms_fir_set_timer(h->fir, t);
+}
+
+comms_status_t comms_chain_set_fir_state(comms_chain_t* h, const comms_c32* state, size_t n_state) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG(state || !n_state, "state is NULL");
+    if (h->fused || h->mixer_after) return comms_fir_set_state(h->fir, state, n_state);
+    // four-kernel path with the mixer in front: its FIR node keeps MIXED samples, so the raw
+    // history is mixed here with the phases the oscillator had at samples -1, -2, ...
+    // (Mixer::mix arithmetic: f64 product rounded once, src/mixer.rs:77-78)
+    double ph = 0.0;
+    COMMS_TRY(comms_mixer_get_phase(h->mixer, &ph));
+    std::vector<comms_c32> mixed(n_state);
+    for (size_t k = 0; k < n_state; ++k) {
+        const double a = ph - static_cast<double>(k + 1) * h->dphase;
+        const double c = std::cos(a), s = std::sin(a);
+        const double re = state[k].re, im = state[k].im;
+        mixed[k].re = static_cast<float>(re * c - im * s);
+        mixed[k].im = static_cast<float>(re * s + im * c);
+    }
+    return comms_fir_set_state(h->fir, mixed.data(), n_state);
 }
 
 comms_status_t comms_chain_destroy(comms_chain_t* h) {

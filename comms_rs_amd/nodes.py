@@ -347,6 +347,12 @@ class ChainNode(_Handle):
     def run_dev(self, in_ptr, n, out_ptr, stream=0):
         check(lib().comms_chain_run_dev(self._h, in_ptr, n, out_ptr, stream))
 
+    def set_fir_state(self, state):
+        """FIR history, reference layout (newest first) -- e.g. the halo of a sharded stream."""
+        st = _as_c64(state)
+        check(lib().comms_chain_set_fir_state(self._h, _ptr(st), st.size))
+        return self
+
 
 # ------------------------------------------------------------------ tap design
 def _taps(fn, n_taps, *args):

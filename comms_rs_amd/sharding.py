@@ -40,3 +40,15 @@ def halo_exchange(dist, tail, rank, world):
 def state_from_halo(halo_samples):
     """Reference `state` layout (newest first) from time-ordered halo samples."""
     return halo_samples[::-1].copy()
+
+
+def shard_mixer_phase(phase0, dphase, first_index):
+    """Mixer start phase of the shard that begins at stream sample `first_index`:
+    (phase0 + first_index * dphase) mod 2*pi, in extended precision -- the closed form of the
+    reference's per-sample `phase += dphase` with wrap (src/mixer.rs:79-82), so every rank's
+    MixerNode continues the un-sharded oscillator without any communication."""
+    import numpy as np
+
+    two_pi = np.longdouble(2.0) * np.longdouble(np.pi)
+    ph = np.fmod(np.longdouble(phase0) + np.longdouble(first_index) * np.longdouble(dphase), two_pi)
+    return float(ph + two_pi if ph < 0 else ph)

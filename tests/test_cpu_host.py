@@ -134,7 +134,7 @@ sys.path.insert(0, sys.argv[1])
 import numpy as np, torch, torch.distributed as dist
 import oracle
 from comms_rs_amd import synth_iq
-from comms_rs_amd.sharding import shard_range, halo_exchange, state_from_halo
+from comms_rs_amd.sharding import shard_range, halo_exchange, state_from_halo, shard_mixer_phase
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 total, n_taps = 50000, 255
@@ -148,7 +148,12 @@ if rank > 0:
     state = state_from_halo(torch.view_as_complex(halo).numpy())
 y = oracle.batch_fir(x, taps, state, norotate=True)      # checker stands in for the GPU node here
 full = oracle.batch_fir(synth_iq(total, 0), taps, oracle.default_state(taps), norotate=True)
-ok = torch.tensor([1.0 if np.array_equal(y, full[a:b]) else 0.0])
+# mixer after the FIR: the shard's oscillator starts at the closed-form phase of sample a
+dphase = 2 * np.pi * 0.1
+ym = oracle.Mixer(shard_mixer_phase(0.3, dphase, a), dphase).mix(y)
+fullm = oracle.Mixer(0.3, dphase).mix(full)
+same_mix = np.max(np.abs(ym - fullm[a:b])) <= 1e-6 * np.max(np.abs(fullm))
+ok = torch.tensor([1.0 if (np.array_equal(y, full[a:b]) and same_mix) else 0.0])
 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
 dist.destroy_process_group()
 sys.exit(0 if ok.item() == 1.0 else 3)

@@ -619,6 +619,26 @@ def test_time_domain_decimating_chain_kernel(c, rate):
             ys.append(y)
 
 
+@pytest.mark.parametrize("after", [False, True])
+@pytest.mark.parametrize("variant", ["time", "freq", "unfused"])
+def test_chain_shard_continues_the_stream(c, variant, after):
+    """Multi-GPU sharding of the chain: a second shard that starts with the
+    halo as FIR history and the closed-form mixer phase reproduces the un-sharded output."""
+    from comms_rs_amd.sharding import shard_mixer_phase, state_from_halo
+
+    rng = np.random.default_rng(5)
+    n, cut, rate = 8 * 6000, 8 * 2500, 8
+    x = rand_c(rng, n)
+    taps = lowpass_taps(127, 1 / 16)
+    dphase, phase0 = 2 * np.pi * 0.05, 0.3
+    kw = dict(mixer_after_fir=after, unfused=variant == "unfused", kernel="auto" if variant == "unfused" else variant)
+    whole = c.ChainNode(dphase, phase0, taps, rate, False, **kw).run(x)
+    shard = c.ChainNode(dphase, shard_mixer_phase(phase0, dphase, cut), taps, rate, False, **kw)
+    shard.set_fir_state(state_from_halo(x[cut - taps.size:cut]))
+    got = shard.run(x[cut:])
+    fir_close(got, whole[cut // rate:], taps, x)
+
+
 def test_config3_full_size_2p26_fused_vs_nodes(c):
     """BASELINE config 3 at its full size (2^26 samples, mixer -> 127-tap LPF -> /8 [-> FM]),
     device-resident: the fused launch against the four kernels in series, plus the oracle on
