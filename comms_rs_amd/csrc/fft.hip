@@ -338,6 +338,143 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void fft1024x16_kernel(c
     }
 }
 
+// ---------------------------------------------------------------- N = RAD * 1024 in ONE pass (RAD = 1, 2, 4, 8, 16)
+// n = 1024 n1 + n2, k = k1 + RAD k2:
+//   X[k1 + RAD k2] = sum_{n2} W_1024^{n2 k2} * W_N^{n2 k1} * ( sum_{n1} x[1024 n1 + n2] W_RAD^{n1 k1} )
+// A 16-wave workgroup owns 16 rows of 1024 points = 16/RAD transforms.  Lane n2 loads the RAD
+// rows of a transform (coalesced), does the radix-RAD butterfly over n1 in registers, applies
+// W_N^{n2 k1} (two small LDS tables: W_N^{64 wave k1} * W_N^{lane k1}) and drops row k1 into the
+// LDS buffer of the wave that will transform it; every wave then runs the same barrier-free
+// 1024-point transform as fft1024x16_kernel, and the tile goes back fully coalesced, because
+// element i = k1 + RAD k2 (+ N j) of the tile is simply output i.  One HBM read and one write
+// per point, where the tile kernel needs two passes above 4096 points.
+template <int DIR>
+__device__ __forceinline__ void radix2(cf& a, cf& b) {
+    const cf t = cadd(a, b);
+    b = csub(a, b);
+    a = t;
+}
+// 8-point DFT, natural order in and out
+template <int DIR>
+__device__ __forceinline__ void radix8(cf (&v)[8]) {
+    constexpr float R2 = 0.70710678118654752440f;
+    radix4<DIR>(v[0], v[2], v[4], v[6]);  // E[0..3] in v[0], v[2], v[4], v[6]
+    radix4<DIR>(v[1], v[3], v[5], v[7]);  // O[0..3] in v[1], v[3], v[5], v[7]
+    const cf o1 = tw_mul<DIR>(v[3], cf{R2, -R2});
+    const cf o3 = tw_mul<DIR>(v[7], cf{-R2, -R2});
+    const cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o2 = v[5];
+    v[0] = cadd(e0, o0);
+    v[4] = csub(e0, o0);
+    v[1] = cadd(e1, o1);
+    v[5] = csub(e1, o1);
+    v[2] = cadd_di<DIR>(e2, o2);  // W8^2 = -+i
+    v[6] = csub_di<DIR>(e2, o2);
+    v[3] = cadd(e3, o3);
+    v[7] = csub(e3, o3);
+}
+
+template <int RAD>
+struct RxGeom {
+    static constexpr int BUF = 1088 + 32 / RAD;  // per-wave buffer stride: rows k1 land 32/RAD slots apart -> conflict-free tile reads
+    static constexpr size_t LDS = (1024 + 64 + RAD * 16 + RAD * 64 + 16 * BUF) * sizeof(float2);
+};
+
+template <int DIR, int RAD>
+__global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* out, size_t n_tiles,
+                                                             const cf* __restrict__ tw1g, const cf* __restrict__ tw2g,
+                                                             const cf* __restrict__ twag, const cf* __restrict__ twbg) {
+    constexpr int N = RAD * 1024, XPT = 16 / RAD, BUF = RxGeom<RAD>::BUF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* tw1 = reinterpret_cast<cf*>(smem);  // [16][64]   W1024^{lane*k0}
+    cf* tw2 = tw1 + 1024;                   // [16][4]    W64^{c*k1}
+    cf* twa = tw2 + 64;                     // [RAD][16]  W_N^{64*wave*k1}
+    cf* twb = twa + RAD * 16;               // [RAD][64]  W_N^{lane*k1}
+    cf* bufs = twb + RAD * 64;              // [16][BUF]
+    const int tid = threadIdx.x;
+    const int l = tid & 63, wave = tid >> 6;
+    const int q0 = l & 15, q1 = l >> 4;
+    cf* buf = bufs + wave * BUF;
+    tw1[tid] = tw1g[tid];
+    if (tid < 64) tw2[tid] = tw2g[tid];
+    if (tid < RAD * 16) twa[tid] = twag[tid];
+    if (tid < RAD * 64) twb[tid] = twbg[tid];
+
+    cf pre[16];
+    auto fetch = [&](size_t tix) {
+        const cf* src = in + tix * (16u * 1024u);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) pre[u] = src[1024u * u + static_cast<unsigned>(tid)];  // u = j*RAD + n1
+    };
+    if (blockIdx.x < n_tiles) fetch(blockIdx.x);
+
+    for (size_t tix = blockIdx.x; tix < n_tiles; tix += gridDim.x) {
+        __syncthreads();  // previous tile fully stored (and the tables are in place)
+        // ---- radix-RAD over n1, times W_N^{n2*k1}, row k1 -> buffer j*RAD + k1, position n2 = tid
+#pragma unroll
+        for (int j = 0; j < XPT; ++j) {
+            cf v[RAD];
+#pragma unroll
+            for (int a = 0; a < RAD; ++a) v[a] = pre[j * RAD + a];
+            if constexpr (RAD == 2) radix2<DIR>(v[0], v[1]);  // (RAD == 1: N = 1024, the rows go straight to the waves)
+            if constexpr (RAD == 4) radix4<DIR>(v[0], v[1], v[2], v[3]);
+            if constexpr (RAD == 8) radix8<DIR>(v);
+            if constexpr (RAD == 16) radix16<DIR>(v);
+#pragma unroll
+            for (int k = 0; k < RAD; ++k) {
+                cf x = v[RAD == 16 ? R16_POS(k) : k];
+                if (k) x = tw_mul<DIR>(x, cmulf(twa[k * 16 + wave], twb[k * 64 + l]));
+                bufs[(j * RAD + k) * BUF + tid] = x;
+            }
+        }
+        __syncthreads();
+        if (tix + gridDim.x < n_tiles) fetch(tix + gridDim.x);
+        // ---- this wave's 1024-point transform, in its own buffer (as fft1024x16_kernel)
+        cf v[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = buf[64 * a + l];
+        fw_wave_sync();
+        radix16<DIR>(v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            cf x = v[R16_POS(k)];
+            if (k) x = tw_mul<DIR>(x, tw1[k * 64 + l]);
+            buf[k * FW_S1 + l] = x;
+        }
+        fw_wave_sync();
+#pragma unroll
+        for (int bb = 0; bb < 16; ++bb) v[bb] = buf[q0 * FW_S1 + 4 * bb + q1];
+        fw_wave_sync();
+        radix16<DIR>(v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            cf x = v[R16_POS(k)];
+            if (k) x = tw_mul<DIR>(x, tw2[k * 4 + q1]);
+            buf[q1 * FW_P + 17 * q0 + k] = x;
+        }
+        fw_wave_sync();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[4 * j + c] = buf[c * FW_P + 17 * (q1 + 4 * j) + q0];
+        fw_wave_sync();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            radix4<DIR>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) buf[q1 + 4 * j + 17 * q0 + 272 * k2] = v[4 * j + k2];
+        }
+        __syncthreads();
+        // ---- store: tile element i = j*N + RAD*k2 + k1 is output i
+        cf* dst = out + tix * (16u * 1024u);
+#pragma unroll 8
+        for (int u = 0; u < 16; ++u) {
+            const unsigned i = static_cast<unsigned>(tid) + 1024u * u;
+            const unsigned k1 = i % RAD, k2 = (i / RAD) & 1023u, j = i / N;
+            dst[i] = bufs[(j * RAD + k1) * BUF + k2 + (k2 >> 4)];
+        }
+    }
+}
+
 // Exact-index O(N^2) DFT, one transform per workgroup, f64 accumulation.
 __global__ __launch_bounds__(256) void dft_direct_kernel(const cf* __restrict__ in,
                                                          cf* __restrict__ out, int N,
@@ -419,6 +556,9 @@ struct Pow2Plan {
     float2* d_tw[4] = {nullptr, nullptr, nullptr, nullptr};  // twL(pass0), twL(pass1), tw_lo, tw_hi
     float2* d_fw1 = nullptr;  // fast 16x1024 kernel: W1024^{lane*k0} [16][64]
     float2* d_fw2 = nullptr;  //                       W64^{c*k1}     [16][4]
+    int rx_rad = 0;           // N = rx_rad * 1024 (2, 4, 8, 16): single-pass fft_rx1024_kernel
+    float2* d_rxa = nullptr;  //   W_N^{64*wave*k1} [rad][16]
+    float2* d_rxb = nullptr;  //   W_N^{lane*k1}    [rad][64]
     int threads[2] = {0, 0};
     size_t lds[2] = {0, 0};
 
@@ -430,7 +570,9 @@ struct Pow2Plan {
             }
         if (d_fw1) (void)hipFree(d_fw1);
         if (d_fw2) (void)hipFree(d_fw2);
-        d_fw1 = d_fw2 = nullptr;
+        if (d_rxa) (void)hipFree(d_rxa);
+        if (d_rxb) (void)hipFree(d_rxb);
+        d_fw1 = d_fw2 = d_rxa = d_rxb = nullptr;
     }
     bool fast(int i) const { return pass[i].L == 1024 && (pass[i].C == 16 || pass[i].C == 8) && d_fw1 != nullptr; }
 };
@@ -484,12 +626,14 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
         p.twL = reinterpret_cast<const cf*>(pl.d_tw[0]);
     } else {
         pl.n_pass = 2;
-        const int log1 = logN / 2, log2v = logN - log1;
+        // 2^15 .. 2^20: N2 = 1024 so that pass 2 (and for 2^20 pass 1 too) runs on fft1024x16_kernel;
+        // the short column pass takes wide tiles (2-KiB row pieces at N1 = 64)
+        const int log1 = (logN >= 15 && logN <= 20) ? logN - 10 : logN / 2, log2v = logN - log1;
         const size_t N1 = static_cast<size_t>(1) << log1, N2 = static_cast<size_t>(1) << log2v;
         // pass 1: columns n2, FFT over n1 (stride N2), twiddle, in place
         FftTileParams& a = pl.pass[0];
         memset(&a, 0, sizeof(a));
-        tile_geometry(a, static_cast<int>(N1), 16);
+        tile_geometry(a, static_cast<int>(N1), N1 < 1024 ? (FT_MAX_POINTS / N1 < N2 ? FT_MAX_POINTS / N1 : N2) : 16);
         a.in_c_fast = 1;
         a.out_c_fast = 1;
         a.in_cs = 1;
@@ -531,7 +675,8 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
         pl.threads[i] = T;
         pl.lds[i] = static_cast<size_t>(npts) * sizeof(float2);
     }
-    if (pl.pass[0].L == 1024 || (pl.n_pass == 2 && pl.pass[1].L == 1024)) {
+    const bool rx = N == 1024 || N == 2048 || N == 4096 || N == 8192 || N == 16384;
+    if (pl.pass[0].L == 1024 || (pl.n_pass == 2 && pl.pass[1].L == 1024) || rx) {
         std::vector<float2> t1(1024), t2(64);
         for (int k0 = 0; k0 < 16; ++k0)
             for (int t = 0; t < 64; ++t) {
@@ -556,6 +701,25 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
         COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft1024x16_kernel<-1, 8>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
+    }
+    if (rx) {
+        const int rad = static_cast<int>(N / 1024);
+        std::vector<float2> ta(rad * 16), tb(rad * 64);
+        for (int k = 0; k < rad; ++k) {
+            for (int w = 0; w < 16; ++w) {
+                const double a = -2.0 * kPiF * static_cast<double>((64ull * w * k) % N) / static_cast<double>(N);
+                ta[k * 16 + w] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
+            }
+            for (int l = 0; l < 64; ++l) {
+                const double a = -2.0 * kPiF * static_cast<double>((static_cast<size_t>(l) * k) % N) / static_cast<double>(N);
+                tb[k * 64 + l] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
+            }
+        }
+        COMMS_HIP_TRY(hipMalloc(&pl.d_rxa, ta.size() * sizeof(float2)));
+        COMMS_HIP_TRY(hipMalloc(&pl.d_rxb, tb.size() * sizeof(float2)));
+        COMMS_HIP_TRY(hipMemcpy(pl.d_rxa, ta.data(), ta.size() * sizeof(float2), hipMemcpyHostToDevice));
+        COMMS_HIP_TRY(hipMemcpy(pl.d_rxb, tb.data(), tb.size() * sizeof(float2), hipMemcpyHostToDevice));
+        pl.rx_rad = rad;
     }
     // tiles above 64 KiB need the dynamic-LDS limit raised (160 KiB per CU on gfx950)
     COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_tile_kernel<1>),
@@ -595,8 +759,56 @@ static comms_status_t launch_fast(Pow2Plan& pl, const float2* src, float2* dst, 
     return launch_ok("fft1024x16_kernel");
 }
 
+template <int RAD>
+static comms_status_t launch_rx(Pow2Plan& pl, const float2* src, float2* dst, size_t n_tiles, bool inverse,
+                                hipStream_t s) {
+    constexpr size_t lds = RxGeom<RAD>::LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rx1024_kernel<1, RAD>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rx1024_kernel<-1, RAD>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        attr_set = true;
+    }
+    const unsigned blocks = static_cast<unsigned>(n_tiles < static_cast<size_t>(kNumCU) ? n_tiles : kNumCU);
+    const cf* a = reinterpret_cast<const cf*>(src);
+    cf* d = reinterpret_cast<cf*>(dst);
+    const cf* t1 = reinterpret_cast<const cf*>(pl.d_fw1);
+    const cf* t2 = reinterpret_cast<const cf*>(pl.d_fw2);
+    const cf* ta = reinterpret_cast<const cf*>(pl.d_rxa);
+    const cf* tb = reinterpret_cast<const cf*>(pl.d_rxb);
+    if (inverse)
+        fft_rx1024_kernel<1, RAD><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, n_tiles, t1, t2, ta, tb);
+    else
+        fft_rx1024_kernel<-1, RAD><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, n_tiles, t1, t2, ta, tb);
+    return launch_ok("fft_rx1024_kernel");
+}
+
 static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size_t batch,
                                bool inverse, hipStream_t s, float2* scratch) {
+    static const bool no_rx = [] {
+        const char* v = getenv("COMMS_FFT_NO_RX");
+        return v && *v && *v != '0';
+    }();
+    if (pl.rx_rad && !no_rx) {
+        // whole 16-row tiles go through the single-pass kernel; a ragged tail of transforms
+        // falls through to the tile passes below
+        const size_t xpt = 16 / static_cast<size_t>(pl.rx_rad), full = batch / xpt;
+        if (full) {
+            switch (pl.rx_rad) {
+                case 1: COMMS_TRY(launch_rx<1>(pl, in, out, full, inverse, s)); break;
+                case 2: COMMS_TRY(launch_rx<2>(pl, in, out, full, inverse, s)); break;
+                case 4: COMMS_TRY(launch_rx<4>(pl, in, out, full, inverse, s)); break;
+                case 8: COMMS_TRY(launch_rx<8>(pl, in, out, full, inverse, s)); break;
+                default: COMMS_TRY(launch_rx<16>(pl, in, out, full, inverse, s)); break;
+            }
+            in += full * xpt * pl.N;
+            out += full * xpt * pl.N;
+            batch -= full * xpt;
+        }
+        if (!batch) return COMMS_OK;
+    }
     for (int i = 0; i < pl.n_pass; ++i) {
         FftTileParams p = pl.pass[i];
         const float2* src = in;

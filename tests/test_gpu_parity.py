@@ -446,6 +446,28 @@ def test_fft_batch_tiles_and_wrong_length(c):
     assert e.value.code == 1
 
 
+@pytest.mark.parametrize("n", [2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_fft_single_pass_radix_times_1024(c, n, inverse):
+    """N = r x 1024 (r = 2, 4, 8, 16) runs in one pass (fft_rx1024_kernel): 16-row tiles of
+    16/r transforms plus a ragged tail on the tile passes; also in place on the device."""
+    import torch
+
+    rng = np.random.default_rng(n + inverse)
+    xpt = 16384 // n
+    for batch in (xpt, 2 * xpt + 1, 300 * xpt + (1 if xpt > 1 else 0)):
+        x = rand_c(rng, n * batch)
+        f = (lambda v: np.fft.ifft(v, axis=1) * n) if inverse else (lambda v: np.fft.fft(v, axis=1))
+        want = f(x.astype(np.complex128).reshape(batch, n)).reshape(-1)
+        fft_close(c.FFTBatchNode(n, inverse).run(x), want)
+        if batch == 2 * xpt + 1:
+            fft_close(c.FFTBatchNode(n, inverse).run(x[:n]), oracle.fft(x[:n], inverse))  # tail path vs the oracle
+            t = torch.from_numpy(x).cuda()
+            c.FFTBatchNode(n, inverse).run_dev(t.data_ptr(), t.numel(), t.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            fft_close(t.cpu().numpy(), want)
+
+
 def test_fft_config4_size_roundtrip(c):
     # BASELINE config 4 length (2^20), small batch: forward vs oracle, then inverse / N == input
     import torch
