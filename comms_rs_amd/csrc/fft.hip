@@ -610,7 +610,10 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
         memset(&p, 0, sizeof(p));
         // 1024-point batches: two 8-wave workgroups per CU overlap load/compute/store (measured
         // 258 vs 226 Gpoints/s); four-step passes keep 16 columns = 128-B row pieces
-        tile_geometry(p, static_cast<int>(N), N == 1024 ? 8 : 16);
+        // short transforms: full 16384-point tiles (1024 lanes, 128 KiB of LDS) -- with 16 transforms
+        // per tile a 64-point batch ran one wave per workgroup (74 -> 173 Gpoints/s)
+        static const size_t tile_pts = [] { const char* v = getenv("COMMS_FFT_TILE_PTS"); return static_cast<size_t>(v && *v ? atoi(v) : 16384); }();
+        tile_geometry(p, static_cast<int>(N), N == 1024 ? 8 : (N < 1024 ? tile_pts / N : 16));
         // rows mode: tile = C consecutive transforms; the "transform" seen by the
         // kernel is the tile itself (distance C*N), one tile per transform
         p.in_c_fast = 0;
@@ -820,7 +823,8 @@ static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size
             if (full && pl.fast(i)) {
                 COMMS_TRY(launch_fast(pl, src, dst, p, inverse, s));
             } else if (full) {
-                unsigned blocks = static_cast<unsigned>(full < 4u * kNumCU ? full : 4u * kNumCU);
+                static const unsigned wgs = [] { const char* v = getenv("COMMS_FFT_TILE_WGS"); return static_cast<unsigned>(v && *v ? atoi(v) : 4); }();
+                unsigned blocks = static_cast<unsigned>(full < wgs * kNumCU ? full : wgs * kNumCU);
                 if (inverse)
                     fft_tile_kernel<1><<<dim3(blocks), dim3(pl.threads[i]), pl.lds[i], s>>>(reinterpret_cast<const cf*>(src), reinterpret_cast<cf*>(dst), p);
                 else

@@ -446,6 +446,17 @@ def test_fft_batch_tiles_and_wrong_length(c):
     assert e.value.code == 1
 
 
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024])
+def test_fft_short_transforms_full_tiles(c, n):
+    """Short transforms are batched 16384 points to a tile: two full tiles and a ragged tail."""
+    rng = np.random.default_rng(n)
+    batch = 2 * (16384 // n) + 3
+    x = rand_c(rng, n * batch)
+    for inverse in (False, True):
+        f = (lambda v: np.fft.ifft(v, axis=1) * n) if inverse else (lambda v: np.fft.fft(v, axis=1))
+        fft_close(c.FFTBatchNode(n, inverse).run(x), f(x.astype(np.complex128).reshape(batch, n)).reshape(-1))
+
+
 @pytest.mark.parametrize("n", [2048, 4096, 8192, 16384])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_fft_single_pass_radix_times_1024(c, n, inverse):
