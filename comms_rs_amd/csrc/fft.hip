@@ -373,31 +373,38 @@ __device__ __forceinline__ void radix8(cf (&v)[8]) {
     v[7] = csub(e3, o3);
 }
 
+// RAD = 0 stands for N = 64: the rows are 16 contiguous 64-point transforms each, which is the
+// 1024-point wave transform with its first radix-16 stage (and twiddle) left out.
+// RAD = 256 stands for N = 256: a row is 4 transforms, lane (t, b) does radix-16 over a
+// (m = 16a + b), times W256^{b*ka}, one exchange, radix-16 over b: f = ka + 16 kb.
+typedef float cf2v __attribute__((ext_vector_type(4)));  // two packed complex values (16 B)
+constexpr int F256_T = 272;  // 256 + 16: the four transforms of a row start 32 banks apart
 template <int RAD>
 struct RxGeom {
-    static constexpr int BUF = 1088 + 32 / RAD;  // per-wave buffer stride: rows k1 land 32/RAD slots apart -> conflict-free tile reads
-    static constexpr size_t LDS = (1024 + 64 + RAD * 16 + RAD * 64 + 16 * BUF) * sizeof(float2);
+    static constexpr int R = (RAD && RAD != 256) ? RAD : 1;
+    static constexpr int BUF = RAD == 256 ? 1160 : 1088 + 32 / R;  // per-wave buffer stride: rows k1 land 32/RAD slots apart -> conflict-free tile reads
+    static constexpr size_t LDS = (1024 + 64 + R * 16 + R * 64 + 16 * BUF) * sizeof(float2);
 };
 
 template <int DIR, int RAD>
 __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* out, size_t n_tiles,
                                                              const cf* __restrict__ tw1g, const cf* __restrict__ tw2g,
                                                              const cf* __restrict__ twag, const cf* __restrict__ twbg) {
-    constexpr int N = RAD * 1024, XPT = 16 / RAD, BUF = RxGeom<RAD>::BUF;
+    constexpr int R = RxGeom<RAD>::R, N = R * 1024, XPT = 16 / R, BUF = RxGeom<RAD>::BUF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* tw1 = reinterpret_cast<cf*>(smem);  // [16][64]   W1024^{lane*k0}
     cf* tw2 = tw1 + 1024;                   // [16][4]    W64^{c*k1}
     cf* twa = tw2 + 64;                     // [RAD][16]  W_N^{64*wave*k1}
-    cf* twb = twa + RAD * 16;               // [RAD][64]  W_N^{lane*k1}
-    cf* bufs = twb + RAD * 64;              // [16][BUF]
+    cf* twb = twa + R * 16;                 // [RAD][64]  W_N^{lane*k1}
+    cf* bufs = twb + R * 64;                // [16][BUF]
     const int tid = threadIdx.x;
     const int l = tid & 63, wave = tid >> 6;
     const int q0 = l & 15, q1 = l >> 4;
     cf* buf = bufs + wave * BUF;
     tw1[tid] = tw1g[tid];
     if (tid < 64) tw2[tid] = tw2g[tid];
-    if (tid < RAD * 16) twa[tid] = twag[tid];
-    if (tid < RAD * 64) twb[tid] = twbg[tid];
+    if (tid < R * 16) twa[tid] = twag[tid];
+    if (tid < R * 64) twb[tid] = twbg[tid];
 
     cf pre[16];
     auto fetch = [&](size_t tix) {
@@ -410,37 +417,75 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
     for (size_t tix = blockIdx.x; tix < n_tiles; tix += gridDim.x) {
         __syncthreads();  // previous tile fully stored (and the tables are in place)
         // ---- radix-RAD over n1, times W_N^{n2*k1}, row k1 -> buffer j*RAD + k1, position n2 = tid
+        if constexpr (RAD == 0) {  // 64-point rows: block a = wave of row u goes to exchange-1 row a as it is
 #pragma unroll
-        for (int j = 0; j < XPT; ++j) {
-            cf v[RAD];
+            for (int u = 0; u < 16; ++u) bufs[u * BUF + wave * FW_S1 + l] = pre[u];
+        }
+        if constexpr (RAD == 256) {  // transform t = tid >> 8 of row u at t*272
 #pragma unroll
-            for (int a = 0; a < RAD; ++a) v[a] = pre[j * RAD + a];
+            for (int u = 0; u < 16; ++u) bufs[u * BUF + (tid >> 8) * F256_T + (tid & 255)] = pre[u];
+        }
+#pragma unroll
+        for (int j = 0; j < ((RAD && RAD != 256) ? XPT : 0); ++j) {
+            cf v[R];
+#pragma unroll
+            for (int a = 0; a < R; ++a) v[a] = pre[j * R + a];
             if constexpr (RAD == 2) radix2<DIR>(v[0], v[1]);  // (RAD == 1: N = 1024, the rows go straight to the waves)
             if constexpr (RAD == 4) radix4<DIR>(v[0], v[1], v[2], v[3]);
             if constexpr (RAD == 8) radix8<DIR>(v);
             if constexpr (RAD == 16) radix16<DIR>(v);
 #pragma unroll
-            for (int k = 0; k < RAD; ++k) {
+            for (int k = 0; k < R; ++k) {
                 cf x = v[RAD == 16 ? R16_POS(k) : k];
                 if (k) x = tw_mul<DIR>(x, cmulf(twa[k * 16 + wave], twb[k * 64 + l]));
-                bufs[(j * RAD + k) * BUF + tid] = x;
+                bufs[(j * R + k) * BUF + tid] = x;
             }
         }
         __syncthreads();
         if (tix + gridDim.x < n_tiles) fetch(tix + gridDim.x);
         // ---- this wave's 1024-point transform, in its own buffer (as fft1024x16_kernel)
         cf v[16];
+        if constexpr (RAD == 256) {
+            // this wave's row: four 256-point transforms, lane (t, b) = (q1, q0)
 #pragma unroll
-        for (int a = 0; a < 16; ++a) v[a] = buf[64 * a + l];
-        fw_wave_sync();
-        radix16<DIR>(v);
+            for (int a = 0; a < 16; ++a) v[a] = buf[q1 * F256_T + 16 * a + q0];
+            fw_wave_sync();
+            radix16<DIR>(v);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            cf x = v[R16_POS(k)];
-            if (k) x = tw_mul<DIR>(x, tw1[k * 64 + l]);
-            buf[k * FW_S1 + l] = x;
+            for (int k = 0; k < 16; ++k) {  // -> exchange row (t, ka), column b; 18-element rows
+                cf x = v[R16_POS(k)];
+                if (k) x = tw_mul<DIR>(x, tw1[k * 16 + q0]);
+                buf[(q1 * 16 + k) * 18 + q0] = x;
+            }
+            fw_wave_sync();
+            {  // lane (t, ka): its 16 consecutive b values
+                const cf2v* r = reinterpret_cast<const cf2v*>(buf + l * 18);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const cf2v x = r[j];
+                    v[2 * j] = cf{x.x, x.y};
+                    v[2 * j + 1] = cf{x.z, x.w};
+                }
+            }
+            fw_wave_sync();
+            radix16<DIR>(v);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) buf[q1 * F256_T + q0 + 16 * k] = v[R16_POS(k)];  // f = ka + 16 kb
         }
-        fw_wave_sync();
+        if constexpr (RAD != 0 && RAD != 256) {
+#pragma unroll
+            for (int a = 0; a < 16; ++a) v[a] = buf[64 * a + l];
+            fw_wave_sync();
+            radix16<DIR>(v);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                cf x = v[R16_POS(k)];
+                if (k) x = tw_mul<DIR>(x, tw1[k * 64 + l]);
+                buf[k * FW_S1 + l] = x;
+            }
+            fw_wave_sync();
+        }
+        if constexpr (RAD != 256) {
 #pragma unroll
         for (int bb = 0; bb < 16; ++bb) v[bb] = buf[q0 * FW_S1 + 4 * bb + q1];
         fw_wave_sync();
@@ -463,14 +508,21 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
 #pragma unroll
             for (int k2 = 0; k2 < 4; ++k2) buf[q1 + 4 * j + 17 * q0 + 272 * k2] = v[4 * j + k2];
         }
+        }
         __syncthreads();
         // ---- store: tile element i = j*N + RAD*k2 + k1 is output i
         cf* dst = out + tix * (16u * 1024u);
 #pragma unroll 8
         for (int u = 0; u < 16; ++u) {
             const unsigned i = static_cast<unsigned>(tid) + 1024u * u;
-            const unsigned k1 = i % RAD, k2 = (i / RAD) & 1023u, j = i / N;
-            dst[i] = bufs[(j * RAD + k1) * BUF + k2 + (k2 >> 4)];
+            if constexpr (RAD == 0) {  // row u, block a = wave, frequency f = l sits at a + 17 f
+                dst[i] = bufs[u * BUF + wave + 17 * l];
+            } else if constexpr (RAD == 256) {
+                dst[i] = bufs[u * BUF + (tid >> 8) * F256_T + (tid & 255)];
+            } else {
+                const unsigned k1 = i % R, k2 = (i / R) & 1023u, j = i / N;
+                dst[i] = bufs[(j * R + k1) * BUF + k2 + (k2 >> 4)];
+            }
         }
     }
 }
@@ -678,7 +730,7 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
         pl.threads[i] = T;
         pl.lds[i] = static_cast<size_t>(npts) * sizeof(float2);
     }
-    const bool rx = N == 1024 || N == 2048 || N == 4096 || N == 8192 || N == 16384;
+    const bool rx = N == 64 || N == 256 || N == 1024 || N == 2048 || N == 4096 || N == 8192 || N == 16384;
     if (pl.pass[0].L == 1024 || (pl.n_pass == 2 && pl.pass[1].L == 1024) || rx) {
         std::vector<float2> t1(1024), t2(64);
         for (int k0 = 0; k0 < 16; ++k0)
@@ -706,7 +758,7 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
     }
     if (rx) {
-        const int rad = static_cast<int>(N / 1024);
+        const int rad = N < 1024 ? 1 : static_cast<int>(N / 1024);  // (N = 64, 256: tables unused, kept for the common signature)
         std::vector<float2> ta(rad * 16), tb(rad * 64);
         for (int k = 0; k < rad; ++k) {
             for (int w = 0; w < 16; ++w) {
@@ -722,7 +774,16 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
         COMMS_HIP_TRY(hipMalloc(&pl.d_rxb, tb.size() * sizeof(float2)));
         COMMS_HIP_TRY(hipMemcpy(pl.d_rxa, ta.data(), ta.size() * sizeof(float2), hipMemcpyHostToDevice));
         COMMS_HIP_TRY(hipMemcpy(pl.d_rxb, tb.data(), tb.size() * sizeof(float2), hipMemcpyHostToDevice));
-        pl.rx_rad = rad;
+        pl.rx_rad = N == 64 ? -1 : N == 256 ? -2 : rad;  // -1 / -2: the 64- / 256-point forms
+        if (N == 256) {  // its stage twiddle W256^{b*ka} at [ka*16 + b] takes the place of the W1024 table
+            std::vector<float2> t1(1024, make_float2(1.f, 0.f));
+            for (int k = 0; k < 16; ++k)
+                for (int bq = 0; bq < 16; ++bq) {
+                    const double a = -2.0 * kPiF * static_cast<double>((bq * k) % 256) / 256.0;
+                    t1[k * 16 + bq] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
+                }
+            COMMS_HIP_TRY(hipMemcpy(pl.d_fw1, t1.data(), t1.size() * sizeof(float2), hipMemcpyHostToDevice));
+        }
     }
     // tiles above 64 KiB need the dynamic-LDS limit raised (160 KiB per CU on gfx950)
     COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_tile_kernel<1>),
@@ -797,9 +858,11 @@ static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size
     if (pl.rx_rad && !no_rx) {
         // whole 16-row tiles go through the single-pass kernel; a ragged tail of transforms
         // falls through to the tile passes below
-        const size_t xpt = 16 / static_cast<size_t>(pl.rx_rad), full = batch / xpt;
+        const size_t xpt = pl.rx_rad == -1 ? 256 : pl.rx_rad == -2 ? 64 : 16 / static_cast<size_t>(pl.rx_rad), full = batch / xpt;
         if (full) {
             switch (pl.rx_rad) {
+                case -1: COMMS_TRY(launch_rx<0>(pl, in, out, full, inverse, s)); break;
+                case -2: COMMS_TRY(launch_rx<256>(pl, in, out, full, inverse, s)); break;
                 case 1: COMMS_TRY(launch_rx<1>(pl, in, out, full, inverse, s)); break;
                 case 2: COMMS_TRY(launch_rx<2>(pl, in, out, full, inverse, s)); break;
                 case 4: COMMS_TRY(launch_rx<4>(pl, in, out, full, inverse, s)); break;
