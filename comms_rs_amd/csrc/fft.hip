@@ -378,11 +378,16 @@ __device__ __forceinline__ void radix8(cf (&v)[8]) {
 // RAD = 256 stands for N = 256: a row is 4 transforms, lane (t, b) does radix-16 over a
 // (m = 16a + b), times W256^{b*ka}, one exchange, radix-16 over b: f = ka + 16 kb.
 typedef float cf2v __attribute__((ext_vector_type(4)));  // two packed complex values (16 B)
+// RAD = 128 / 512 stand for N = 2 x 64 / 2 x 256: a radix-2 butterfly over the two halves of a
+// transform (x W_N^{n2}) on the way into LDS, then the 64- / 256-point form; lanes load both
+// halves themselves (eight row pairs each), and the interleave k = k1 + 2 k2 is undone by the
+// coalesced tile store.
 constexpr int F256_T = 272;  // 256 + 16: the four transforms of a row start 32 banks apart
 template <int RAD>
 struct RxGeom {
-    static constexpr int R = (RAD && RAD != 256) ? RAD : 1;
-    static constexpr int BUF = RAD == 256 ? 1160 : 1088 + 32 / R;  // per-wave buffer stride: rows k1 land 32/RAD slots apart -> conflict-free tile reads
+    static constexpr bool C64 = RAD == 0 || RAD == 128, C256 = RAD == 256 || RAD == 512, PRE2 = RAD == 128 || RAD == 512;
+    static constexpr int R = (C64 || C256) ? 1 : RAD;
+    static constexpr int BUF = C256 ? 1160 : 1088 + 32 / R;  // per-wave buffer stride: rows k1 land 32/RAD slots apart -> conflict-free tile reads
     static constexpr size_t LDS = (1024 + 64 + R * 16 + R * 64 + 16 * BUF) * sizeof(float2);
 };
 
@@ -391,6 +396,7 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
                                                              const cf* __restrict__ tw1g, const cf* __restrict__ tw2g,
                                                              const cf* __restrict__ twag, const cf* __restrict__ twbg) {
     constexpr int R = RxGeom<RAD>::R, N = R * 1024, XPT = 16 / R, BUF = RxGeom<RAD>::BUF;
+    constexpr bool C64 = RxGeom<RAD>::C64, C256 = RxGeom<RAD>::C256, PRE2 = RxGeom<RAD>::PRE2, C1024 = !C64 && !C256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* tw1 = reinterpret_cast<cf*>(smem);  // [16][64]   W1024^{lane*k0}
     cf* tw2 = tw1 + 1024;                   // [16][4]    W64^{c*k1}
@@ -406,17 +412,45 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
     if (tid < R * 16) twa[tid] = twag[tid];
     if (tid < R * 64) twb[tid] = twbg[tid];
 
+    // PRE2: lane (h, rest) handles rows 2 rp + h; its two halves sit HALF points apart at offset e2
+    constexpr unsigned HALF = RAD == 512 ? 256u : 64u;
+    const unsigned h2 = static_cast<unsigned>(tid) >> 9, rest = static_cast<unsigned>(tid) & 511u;
+    const unsigned n2 = rest & (HALF - 1), tr = rest / HALF;       // position in the half, transform of the row
+    const unsigned e2 = 2 * HALF * tr + n2;
+    cf w2 = cf{1.f, 0.f};
+    if constexpr (PRE2) w2 = twbg[n2];  // W_N^{n2}
     cf pre[16];
     auto fetch = [&](size_t tix) {
         const cf* src = in + tix * (16u * 1024u);
+        if constexpr (PRE2) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) pre[u] = src[1024u * u + static_cast<unsigned>(tid)];  // u = j*RAD + n1
+            for (int u = 0; u < 16; ++u) pre[u] = src[1024u * (2 * (u >> 1) + h2) + e2 + HALF * (u & 1)];  // u = 2*rp + n1
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) pre[u] = src[1024u * u + static_cast<unsigned>(tid)];  // u = j*RAD + n1
+        }
     };
     if (blockIdx.x < n_tiles) fetch(blockIdx.x);
 
     for (size_t tix = blockIdx.x; tix < n_tiles; tix += gridDim.x) {
         __syncthreads();  // previous tile fully stored (and the tables are in place)
         // ---- radix-RAD over n1, times W_N^{n2*k1}, row k1 -> buffer j*RAD + k1, position n2 = tid
+        if constexpr (PRE2) {  // radix-2 over the halves; half-spectrum k1 of transform tr -> slot 2 tr + k1 of row 2 rp + h
+#pragma unroll
+            for (int rp = 0; rp < 8; ++rp) {
+                cf y0 = pre[2 * rp], y1 = pre[2 * rp + 1];
+                radix2<DIR>(y0, y1);
+                y1 = tw_mul<DIR>(y1, w2);
+                cf* row = bufs + (2 * rp + h2) * BUF;
+                if constexpr (C256) {
+                    row[(2 * tr) * F256_T + n2] = y0;
+                    row[(2 * tr + 1) * F256_T + n2] = y1;
+                } else {
+                    row[(2 * tr) * FW_S1 + n2] = y0;
+                    row[(2 * tr + 1) * FW_S1 + n2] = y1;
+                }
+            }
+        }
         if constexpr (RAD == 0) {  // 64-point rows: block a = wave of row u goes to exchange-1 row a as it is
 #pragma unroll
             for (int u = 0; u < 16; ++u) bufs[u * BUF + wave * FW_S1 + l] = pre[u];
@@ -426,7 +460,7 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
             for (int u = 0; u < 16; ++u) bufs[u * BUF + (tid >> 8) * F256_T + (tid & 255)] = pre[u];
         }
 #pragma unroll
-        for (int j = 0; j < ((RAD && RAD != 256) ? XPT : 0); ++j) {
+        for (int j = 0; j < (C1024 ? XPT : 0); ++j) {
             cf v[R];
 #pragma unroll
             for (int a = 0; a < R; ++a) v[a] = pre[j * R + a];
@@ -445,7 +479,7 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
         if (tix + gridDim.x < n_tiles) fetch(tix + gridDim.x);
         // ---- this wave's 1024-point transform, in its own buffer (as fft1024x16_kernel)
         cf v[16];
-        if constexpr (RAD == 256) {
+        if constexpr (C256) {
             // this wave's row: four 256-point transforms, lane (t, b) = (q1, q0)
 #pragma unroll
             for (int a = 0; a < 16; ++a) v[a] = buf[q1 * F256_T + 16 * a + q0];
@@ -472,7 +506,7 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
 #pragma unroll
             for (int k = 0; k < 16; ++k) buf[q1 * F256_T + q0 + 16 * k] = v[R16_POS(k)];  // f = ka + 16 kb
         }
-        if constexpr (RAD != 0 && RAD != 256) {
+        if constexpr (C1024) {
 #pragma unroll
             for (int a = 0; a < 16; ++a) v[a] = buf[64 * a + l];
             fw_wave_sync();
@@ -485,7 +519,7 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
             }
             fw_wave_sync();
         }
-        if constexpr (RAD != 256) {
+        if constexpr (!C256) {
 #pragma unroll
         for (int bb = 0; bb < 16; ++bb) v[bb] = buf[q0 * FW_S1 + 4 * bb + q1];
         fw_wave_sync();
@@ -519,6 +553,12 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
                 dst[i] = bufs[u * BUF + wave + 17 * l];
             } else if constexpr (RAD == 256) {
                 dst[i] = bufs[u * BUF + (tid >> 8) * F256_T + (tid & 255)];
+            } else if constexpr (RAD == 128) {  // transform tid >> 7, k = k1 + 2 k2: block 2 tr + k1, frequency k2
+                const unsigned k = static_cast<unsigned>(tid) & 127u;
+                dst[i] = bufs[u * BUF + 2 * (static_cast<unsigned>(tid) >> 7) + (k & 1u) + 17 * (k >> 1)];
+            } else if constexpr (RAD == 512) {  // transform tid >> 9: slot 2 tr + k1, frequency k2
+                const unsigned k = static_cast<unsigned>(tid) & 511u;
+                dst[i] = bufs[u * BUF + (2 * (static_cast<unsigned>(tid) >> 9) + (k & 1u)) * F256_T + (k >> 1)];
             } else {
                 const unsigned k1 = i % R, k2 = (i / R) & 1023u, j = i / N;
                 dst[i] = bufs[(j * R + k1) * BUF + k2 + (k2 >> 4)];
@@ -730,7 +770,7 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
         pl.threads[i] = T;
         pl.lds[i] = static_cast<size_t>(npts) * sizeof(float2);
     }
-    const bool rx = N == 64 || N == 256 || N == 1024 || N == 2048 || N == 4096 || N == 8192 || N == 16384;
+    const bool rx = N == 64 || N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096 || N == 8192 || N == 16384;
     if (pl.pass[0].L == 1024 || (pl.n_pass == 2 && pl.pass[1].L == 1024) || rx) {
         std::vector<float2> t1(1024), t2(64);
         for (int k0 = 0; k0 < 16; ++k0)
@@ -774,8 +814,19 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
         COMMS_HIP_TRY(hipMalloc(&pl.d_rxb, tb.size() * sizeof(float2)));
         COMMS_HIP_TRY(hipMemcpy(pl.d_rxa, ta.data(), ta.size() * sizeof(float2), hipMemcpyHostToDevice));
         COMMS_HIP_TRY(hipMemcpy(pl.d_rxb, tb.data(), tb.size() * sizeof(float2), hipMemcpyHostToDevice));
-        pl.rx_rad = N == 64 ? -1 : N == 256 ? -2 : rad;  // -1 / -2: the 64- / 256-point forms
-        if (N == 256) {  // its stage twiddle W256^{b*ka} at [ka*16 + b] takes the place of the W1024 table
+        pl.rx_rad = N == 64 ? -1 : N == 256 ? -2 : N == 128 ? -3 : N == 512 ? -4 : rad;  // < 0: the short forms
+        if (N == 128 || N == 512) {  // W_N^{n2}, n2 < N/2, for the radix-2 front stage
+            std::vector<float2> t(N / 2);
+            for (size_t j = 0; j < N / 2; ++j) {
+                const double a = -2.0 * kPiF * static_cast<double>(j) / static_cast<double>(N);
+                t[j] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
+            }
+            (void)hipFree(pl.d_rxb);
+            pl.d_rxb = nullptr;
+            COMMS_HIP_TRY(hipMalloc(&pl.d_rxb, t.size() * sizeof(float2)));
+            COMMS_HIP_TRY(hipMemcpy(pl.d_rxb, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice));
+        }
+        if (N == 256 || N == 512) {  // its stage twiddle W256^{b*ka} at [ka*16 + b] takes the place of the W1024 table
             std::vector<float2> t1(1024, make_float2(1.f, 0.f));
             for (int k = 0; k < 16; ++k)
                 for (int bq = 0; bq < 16; ++bq) {
@@ -858,11 +909,13 @@ static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size
     if (pl.rx_rad && !no_rx) {
         // whole 16-row tiles go through the single-pass kernel; a ragged tail of transforms
         // falls through to the tile passes below
-        const size_t xpt = pl.rx_rad == -1 ? 256 : pl.rx_rad == -2 ? 64 : 16 / static_cast<size_t>(pl.rx_rad), full = batch / xpt;
+        const size_t xpt = pl.rx_rad < 0 ? 16384 / pl.N : 16 / static_cast<size_t>(pl.rx_rad), full = batch / xpt;
         if (full) {
             switch (pl.rx_rad) {
                 case -1: COMMS_TRY(launch_rx<0>(pl, in, out, full, inverse, s)); break;
                 case -2: COMMS_TRY(launch_rx<256>(pl, in, out, full, inverse, s)); break;
+                case -3: COMMS_TRY(launch_rx<128>(pl, in, out, full, inverse, s)); break;
+                case -4: COMMS_TRY(launch_rx<512>(pl, in, out, full, inverse, s)); break;
                 case 1: COMMS_TRY(launch_rx<1>(pl, in, out, full, inverse, s)); break;
                 case 2: COMMS_TRY(launch_rx<2>(pl, in, out, full, inverse, s)); break;
                 case 4: COMMS_TRY(launch_rx<4>(pl, in, out, full, inverse, s)); break;
