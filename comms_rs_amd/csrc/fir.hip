@@ -30,6 +30,7 @@
 #include "common.hpp"
 #include "fft_radix.hpp"
 #include "fir_handle.hpp"
+#include "sgpr_mac.hpp"
 
 namespace comms {
 
@@ -787,6 +788,70 @@ __global__ __launch_bounds__(256) void pulse_kernel(const float2* __restrict__ s
     }
 }
 
+// Polyphase pulse shaper for the usual small sam_per_sym (2, 3, 4, 5, 8, 10, 16):
+//   out[m*SPS + p] = sum_j taps[p + j*SPS] * sym[m - j]          (k = p + j*SPS ascending, as fir())
+// A lane owns one symbol m and its SPS outputs: each symbol of the window (from LDS, consecutive
+// lanes -> consecutive addresses) feeds SPS packed FMAs whose taps sit in SGPR pairs (kernel
+// arguments, rows of SPS taps padded to an even count), and the lane stores its SPS outputs as
+// one contiguous run.  2/SPS + 8 bytes of HBM traffic per output; the generic pulse_kernel
+// (any SPS, any tap count) stays as the fallback.
+constexpr int PP_AMAX = 384;  // floats per tap array (rows * padded row)
+constexpr int PP_JB = 4;      // tap rows per loop iteration
+constexpr int PP_JMAX = 128;  // rows: bounds the LDS window (256 + PP_JMAX symbols)
+struct PulseArgs {
+    const float2* sym;
+    const float2* hist;
+    float2* out;
+    size_t n_sym;
+    int hist_len, J;       // J rows of taps (multiple of PP_JB, zero rows appended)
+    float are[PP_AMAX];    // A[j*SPSP + p] = Re taps[p + j*SPS]
+    float aim[PP_AMAX];
+};
+
+template <int SPS, bool REAL>
+__global__ __launch_bounds__(256) void pulse_poly_kernel(const PulseArgs a) {
+    constexpr int SPSP = SPS + (SPS & 1);
+    __shared__ cf sh[256 + PP_JMAX];
+    const int tid = threadIdx.x;
+    const int halo = a.J - 1;
+    const size_t ntiles = (a.n_sym + 255) / 256;
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long long m0 = static_cast<long long>(t) * 256;
+        __syncthreads();
+        for (int i = tid; i < 256 + halo; i += 256)
+            sh[i] = to_cf(stream_at(a.sym, a.hist, a.hist_len, m0 - halo + i, a.n_sym));
+        __syncthreads();
+        cf acc[SPS];
+#pragma unroll
+        for (int p = 0; p < SPS; ++p) acc[p] = cf{0.f, 0.f};
+        const cf* sp = sh + halo + tid;
+        for (int j0 = 0; j0 < a.J; j0 += PP_JB) {
+            cf sv[PP_JB];
+            v2f tr[PP_JB * SPSP / 2], ti[PP_JB * SPSP / 2];
+#pragma unroll
+            for (int i = 0; i < PP_JB * SPSP / 2; ++i) {
+                tr[i] = v2f{a.are[j0 * SPSP + 2 * i], a.are[j0 * SPSP + 2 * i + 1]};
+                if (!REAL) ti[i] = v2f{a.aim[j0 * SPSP + 2 * i], a.aim[j0 * SPSP + 2 * i + 1]};
+            }
+#pragma unroll
+            for (int jj = 0; jj < PP_JB; ++jj) sv[jj] = sp[-(j0 + jj)];
+#pragma unroll
+            for (int jj = 0; jj < PP_JB; ++jj)
+#pragma unroll
+                for (int p = 0; p < SPS; ++p) {
+                    const int e = jj * SPSP + p;
+                    mac_tap<REAL>(acc[p], sv[jj], tr[e >> 1], ti[e >> 1], (e & 1) != 0);
+                }
+        }
+        const size_t m = static_cast<size_t>(m0) + tid;
+        if (m < a.n_sym) {
+            float2* o = a.out + m * SPS;
+#pragma unroll
+            for (int p = 0; p < SPS; ++p) o[p] = to_f2(acc[p]);
+        }
+    }
+}
+
 }  // namespace comms
 
 using namespace comms;
@@ -1342,7 +1407,57 @@ struct comms_pulse : Handle {
     float2* d_taps = nullptr;
     float2* d_hist[2] = {nullptr, nullptr};
     int cur = 0;
+    std::vector<comms_c32> taps;  // host copy (kernel-argument taps of the polyphase kernel)
+    bool real_taps = false;
 };
+
+// Launches pulse_poly_kernel if (sps, taps) fit it; false -> the caller runs the generic kernel.
+template <int SPS>
+static bool pulse_poly_try(comms_pulse* h, const float2* sym, size_t n_sym, float2* out, hipStream_t s) {
+    constexpr int SPSP = SPS + (SPS & 1);
+    int J = (h->n_taps + SPS - 1) / SPS;
+    J = (J + comms::PP_JB - 1) / comms::PP_JB * comms::PP_JB;
+    if (J > comms::PP_JMAX || J * SPSP > comms::PP_AMAX) return false;
+    comms::PulseArgs a{};
+    a.sym = sym;
+    a.hist = h->d_hist[h->cur];
+    a.out = out;
+    a.n_sym = n_sym;
+    a.hist_len = h->hist_len;
+    a.J = J;
+    for (int j = 0; j < J; ++j)
+        for (int p = 0; p < SPS; ++p) {
+            const int k = p + j * SPS;
+            if (k < h->n_taps) {
+                a.are[j * SPSP + p] = h->taps[k].re;
+                a.aim[j * SPSP + p] = h->taps[k].im;
+            }
+        }
+    const size_t ntiles = (n_sym + 255) / 256;
+    const unsigned blocks = static_cast<unsigned>(ntiles < 8u * comms::kNumCU ? ntiles : 8u * comms::kNumCU);
+    if (h->real_taps)
+        comms::pulse_poly_kernel<SPS, true><<<dim3(blocks), dim3(256), 0, s>>>(a);
+    else
+        comms::pulse_poly_kernel<SPS, false><<<dim3(blocks), dim3(256), 0, s>>>(a);
+    return true;
+}
+static bool pulse_poly_launch(comms_pulse* h, const float2* sym, size_t n_sym, float2* out, hipStream_t s) {
+    static const bool off = [] {
+        const char* v = getenv("COMMS_PULSE_GENERIC");
+        return v && *v && *v != '0';
+    }();
+    if (off) return false;
+    switch (h->sps) {
+        case 2: return pulse_poly_try<2>(h, sym, n_sym, out, s);
+        case 3: return pulse_poly_try<3>(h, sym, n_sym, out, s);
+        case 4: return pulse_poly_try<4>(h, sym, n_sym, out, s);
+        case 5: return pulse_poly_try<5>(h, sym, n_sym, out, s);
+        case 8: return pulse_poly_try<8>(h, sym, n_sym, out, s);
+        case 10: return pulse_poly_try<10>(h, sym, n_sym, out, s);
+        case 16: return pulse_poly_try<16>(h, sym, n_sym, out, s);
+        default: return false;
+    }
+}
 
 static void free_pulse(comms_pulse* h) {
     (void)use_device(h->device);
@@ -1373,6 +1488,10 @@ comms_status_t comms_pulse_create(const comms_c32* taps, size_t n_taps, size_t s
     h->n_taps = static_cast<int>(n_taps);
     h->sps = static_cast<int>(sam_per_sym);
     h->hist_len = static_cast<int>((n_taps + sam_per_sym - 1) / sam_per_sym);
+    h->taps.assign(taps, taps + n_taps);
+    h->real_taps = true;
+    for (size_t k = 0; k < n_taps; ++k)
+        if (taps[k].im != 0.0f) h->real_taps = false;
     hipError_t e = hipMalloc(&h->d_taps, n_taps * sizeof(float2));
     if (e == hipSuccess) e = hipMemcpy(h->d_taps, taps, n_taps * sizeof(float2), hipMemcpyHostToDevice);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
@@ -1398,12 +1517,16 @@ comms_status_t comms_pulse_run_dev(comms_pulse_t* h, const comms_c32* d_sym, siz
     COMMS_ARG(!ranges_overlap(d_sym, n_sym * 8, d_out, n_out * 8), "pulse shaping cannot run in place");
     hipStream_t s = h->pick(stream);
     const float2* sym = reinterpret_cast<const float2*>(d_sym);
-    size_t blocks = (n_out + 255) / 256;
-    if (blocks > 8u * kNumCU) blocks = 8u * kNumCU;
-    pulse_kernel<<<dim3(static_cast<unsigned>(blocks)), dim3(256), h->n_taps * sizeof(float2), s>>>(
-        sym, h->d_hist[h->cur], h->hist_len, h->d_taps, h->n_taps, h->sps,
-        reinterpret_cast<float2*>(d_out), n_sym);
-    COMMS_TRY(launch_ok("pulse_kernel"));
+    h->tic(s);
+    if (!pulse_poly_launch(h, sym, n_sym, reinterpret_cast<float2*>(d_out), s)) {
+        size_t blocks = (n_out + 255) / 256;
+        if (blocks > 8u * kNumCU) blocks = 8u * kNumCU;
+        pulse_kernel<<<dim3(static_cast<unsigned>(blocks)), dim3(256), h->n_taps * sizeof(float2), s>>>(
+            sym, h->d_hist[h->cur], h->hist_len, h->d_taps, h->n_taps, h->sps,
+            reinterpret_cast<float2*>(d_out), n_sym);
+    }
+    h->toc(s);
+    COMMS_TRY(launch_ok("pulse kernel"));
     fir_hist_update_kernel<<<dim3((h->hist_len + 255) / 256), dim3(256), 0, s>>>(
         h->d_hist[h->cur], sym, n_sym, h->d_hist[h->cur ^ 1], h->hist_len);
     COMMS_TRY(launch_ok("fir_hist_update_kernel"));

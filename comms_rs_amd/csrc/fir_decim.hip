@@ -23,6 +23,7 @@
 #include "common.hpp"
 #include "fft_radix.hpp"
 #include "fir_handle.hpp"
+#include "sgpr_mac.hpp"
 
 namespace comms {
 
@@ -58,33 +59,6 @@ struct DecimArgs {
     float aim[DC_AMAX];
     unsigned long long* stamps;    // diagnostic (scripts/stamp_decim.py): per-wave cycles per phase, or NULL
 };
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-// acc += t * u for a real tap held in the lo / hi half of an SGPR pair
-__device__ __forceinline__ void mac_s_lo(cf& acc, cf u, v2f tp) {
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(u), "s"(tp));
-}
-__device__ __forceinline__ void mac_s_hi(cf& acc, cf u, v2f tp) {
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(u), "s"(tp));
-}
-// acc += (i * t) * u : acc.re -= t*u.im, acc.im += t*u.re
-__device__ __forceinline__ void mac_si_lo(cf& acc, cf u, v2f tp) {
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "+v"(acc) : "v"(u), "s"(tp));
-}
-__device__ __forceinline__ void mac_si_hi(cf& acc, cf u, v2f tp) {
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "+v"(acc) : "v"(u), "s"(tp));
-}
-
-template <bool REAL>
-__device__ __forceinline__ void mac_tap(cf& acc, cf u, const v2f& pre, const v2f& pim, bool hi) {
-    if (hi) {
-        mac_s_hi(acc, u, pre);
-        if (!REAL) mac_si_hi(acc, u, pim);
-    } else {
-        mac_s_lo(acc, u, pre);
-        if (!REAL) mac_si_lo(acc, u, pim);
-    }
-}
 
 constexpr double kTwoPiD = 2.0 * 3.14159265358979323846264338327950288;
 

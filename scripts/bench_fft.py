@@ -7,7 +7,7 @@ import torch
 import comms_rs_amd as c
 
 sizes = [int(a) for a in sys.argv[1:]] or [10, 12, 16, 20]
-total = 1 << 26  # points per launch (512 MiB in, 512 MiB out)
+total = 1 << int(os.environ.get("FFT_TOTAL_LOG", 26))  # points per launch (512 MiB in, 512 MiB out at 26)
 s = torch.cuda.current_stream().cuda_stream
 x = torch.empty(total, dtype=torch.complex64, device="cuda:0")
 y = torch.empty_like(x)

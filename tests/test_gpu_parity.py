@@ -252,10 +252,16 @@ def test_pulse_reference_golden(c, kats):
     assert np.array_equal(got, cx(k["expected"]))
 
 
-@pytest.mark.parametrize("n_taps,sps", [(63, 4), (32, 4), (5, 1), (17, 3), (8, 16)])
-def test_pulse_vs_oracle(c, n_taps, sps):
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n_taps,sps", [(63, 4), (32, 4), (5, 1), (17, 3), (8, 16), (255, 8), (127, 2), (100, 5),
+                                        (64, 10), (63, 7), (400, 2), (1, 4), (511, 4)])
+def test_pulse_vs_oracle(c, n_taps, sps, cplx):
+    # sps 2,3,4,5,8,10,16 with few enough taps: the polyphase kernel (SGPR taps); sps 1 / 7, 400 taps / 2:
+    # the generic one
     rng = np.random.default_rng(n_taps + sps)
     taps = oracle.rrc_taps(n_taps, float(max(sps, 2)), 0.25)
+    if cplx:
+        taps = (taps * np.exp(0.3j * np.arange(n_taps))).astype(np.complex64)
     sym = (rng.integers(0, 2, 5000) * 2 - 1).astype(np.complex64) + 1j * (rng.integers(0, 2, 5000) * 2 - 1)
     sym = sym.astype(np.complex64)
     node = c.PulseNode(taps, sps)
