@@ -74,6 +74,19 @@ inline comms_status_t launch_ok(const char* what) {
     return COMMS_OK;
 }
 
+// hipFuncSetAttribute applies to the current device only: a `static DeviceOnce` per call site
+// remembers which devices have had it (a process may drive several GPUs through the C ABI).
+struct DeviceOnce {
+    bool done[64] = {};
+    bool need() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+        if (done[dev]) return false;
+        done[dev] = true;
+        return true;
+    }
+};
+
 // Grow-only device scratch used by the host-pointer (`*_run`) entry points.
 struct Scratch {
     void* p = nullptr;

@@ -86,8 +86,13 @@ static comms_status_t estimate(int kind, const double* d_x, size_t n, unsigned m
     size_t blocks = (n + 255) / 256;
     if (blocks > 8u * kNumCU) blocks = 8u * kNumCU;
     if (blocks < 1) blocks = 1;
-    double2* d_part = nullptr;
-    COMMS_HIP_TRY(hipMalloc(&d_part, blocks * sizeof(double2)));
+    // per-thread, per-device partials buffer, allocated once (a node lives on one thread and every
+    // call ends with a stream sync, so the buffer is never shared between launches in flight;
+    // hipMalloc / hipFree per call would also synchronise the whole device)
+    static thread_local double2* tl_part[64] = {};
+    COMMS_ARG(device >= 0 && device < 64, "device index out of range");
+    if (!tl_part[device]) COMMS_HIP_TRY(hipMalloc(&tl_part[device], 8u * kNumCU * sizeof(double2)));
+    double2* d_part = tl_part[device];
     const double2* x = reinterpret_cast<const double2*>(d_x);
     if (kind == 0)
         estimator_kernel<0><<<dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s>>>(x, n, m, d_part);
@@ -100,7 +105,6 @@ static comms_status_t estimate(int kind, const double* d_x, size_t n, unsigned m
     hipError_t e = hipSuccess;
     if (st == COMMS_OK) e = hipMemcpyAsync(part.data(), d_part, blocks * sizeof(double2), hipMemcpyDeviceToHost, s);
     if (st == COMMS_OK && e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d_part);
     if (st != COMMS_OK) return st;
     if (e != hipSuccess) return fail(COMMS_ERR_DEVICE, "estimator copy-back: %s", hipGetErrorString(e));
     double re = 0.0, im = 0.0;

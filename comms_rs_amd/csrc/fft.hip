@@ -878,13 +878,12 @@ template <int RAD>
 static comms_status_t launch_rx(Pow2Plan& pl, const float2* src, float2* dst, size_t n_tiles, bool inverse,
                                 hipStream_t s) {
     constexpr size_t lds = RxGeom<RAD>::LDS;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rx1024_kernel<1, RAD>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rx1024_kernel<-1, RAD>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        attr_set = true;
     }
     const unsigned blocks = static_cast<unsigned>(n_tiles < static_cast<size_t>(kNumCU) ? n_tiles : kNumCU);
     const cf* a = reinterpret_cast<const cf*>(src);

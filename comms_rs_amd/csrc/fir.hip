@@ -887,11 +887,10 @@ static comms_status_t launch_os1024(int wpb, size_t runs, hipStream_t s, const f
     using namespace comms;
     if (wpb == 16) {
         const size_t lds = (2112 + 16 * W_LDS) * sizeof(float2);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static DeviceOnce attr_once;
+        if (attr_once.need()) {
             COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os1024_kernel<16, 4, MODE>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-            attr_set = true;
         }
         fir_os1024_kernel<16, 4, MODE><<<dim3(static_cast<unsigned>((runs + 15) / 16)), dim3(1024), lds, s>>>(
             in, hist, n_eff, o, n, nseg, runs, tb, nh, ch);

@@ -318,13 +318,12 @@ static comms_status_t launch_decim(const DecimArgs& a, bool real, hipStream_t s)
     // persistent grid: every workgroup slot of the chip gets a contiguous run of tiles
     const size_t slots = static_cast<size_t>(DcGeom<R>::WGPC) * kNumCU;
     const unsigned blocks = static_cast<unsigned>(a.n_tiles < slots ? a.n_tiles : slots);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_decim_kernel<R, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_decim_kernel<R, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        attr_set = true;
     }
     if (real)
         fir_decim_kernel<R, true><<<dim3(blocks), dim3(DC_WG), lds, s>>>(a);
