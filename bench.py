@@ -69,10 +69,38 @@ def cpu_baseline(n):
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     assert y.size == n // DEC_RATE
-    return {"value": round(n / best / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": "full config-2 batch (%d samples) through oracle batch_fir(255 taps, rotate_right per "
-                      "sample) -> Mixer::mix (f64) -> decimate(8), best of 2, g++ -O3 -ffp-contract=off, "
-                      "1 thread of %d host cores" % (n, os.cpu_count() or 0)}
+    out = {"value": round(n / best / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+           "sample": "full config-2 batch (%d samples) through oracle batch_fir(255 taps, rotate_right per "
+                     "sample) -> Mixer::mix (f64) -> decimate(8), best of 2, g++ -O3 -ffp-contract=off, "
+                     "1 thread of %d host cores" % (n, os.cpu_count() or 0)}
+    # the same work cut into independent chunks over the host's cores (SURVEY 8d iii): an upper
+    # bound for what a CPU graph of such nodes could reach on this box; the no-rotate variant
+    # (circular index instead of the per-sample memmove) is listed beside it, labelled as such
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+
+        threads = max(1, min(os.cpu_count() or 1, 64))
+        chunk = n // threads
+
+        def run_chunk(i, norotate):
+            st = oracle.default_state(taps)
+            seg = x[i * chunk:(i + 1) * chunk]
+            oracle.decimate(oracle.Mixer(0.0, MIX_DPHASE).mix(oracle.batch_fir(seg, taps, st, norotate=norotate)), DEC_RATE)
+
+        for key, norot in (("all_cores", False), ("all_cores_norotate", True)):
+            with ThreadPoolExecutor(threads) as ex:
+                list(ex.map(lambda i: run_chunk(i, norot), range(threads)))  # warm-up: threads, first-touch pages
+                t0 = time.perf_counter()
+                list(ex.map(lambda i: run_chunk(i, norot), range(threads)))
+                dt = time.perf_counter() - t0
+            out[key] = {"value": round(chunk * threads / dt / 1e6, 2), "unit": "Msamples/s", "cores": threads}
+        t0 = time.perf_counter()
+        run_chunk(0, True)
+        out["one_core_norotate"] = {"value": round(chunk / (time.perf_counter() - t0) / 1e6, 2), "unit": "Msamples/s",
+                                    "cores": 1}
+    except Exception as e:  # the single-thread figure above is the contract; these are extras
+        out["all_cores"] = {"error": str(e)}
+    return out
 
 
 def main():
