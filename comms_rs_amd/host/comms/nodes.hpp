@@ -25,6 +25,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../../include/comms_hip.h"
@@ -514,6 +515,145 @@ public:
     auto senders() { return std::tie(output); }
 
 private:
+    size_t rate_;
+    int device_;
+};
+
+// One macro-free pattern for the remaining device-resident nodes: own the C handle, move-only,
+// run() allocates the output DeviceBuf and launches on the default stream.
+class FFTBatchNodeDev : public DeriveNode<FFTBatchNodeDev> {
+public:
+    NodeReceiver<DeviceBuf<Complex32>> input;
+    NodeSender<DeviceBuf<Complex32>> output;
+    FFTBatchNodeDev(size_t fft_size, bool ifft, int device = 0) : device_(device) {
+        throw_on(comms_fft_create(fft_size, ifft ? 1 : 0, device, &h_), "FFTBatchNodeDev::new");
+    }
+    FFTBatchNodeDev(FFTBatchNodeDev&& o) noexcept
+        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), device_(o.device_) { o.h_ = nullptr; }
+    ~FFTBatchNodeDev() { comms_fft_destroy(h_); }
+    // the message may hold any whole number of transforms (the reference: exactly one)
+    Result<DeviceBuf<Complex32>> run(const DeviceBuf<Complex32>& in) {
+        DeviceBuf<Complex32> out(in.size(), device_);
+        comms_status_t st = comms_fft_run_dev(h_, c32(in.ptr()), in.size(), c32(out.ptr()), nullptr);
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_fft_t* h_ = nullptr;
+    int device_;
+};
+
+class FMDemodNodeDev : public DeriveNode<FMDemodNodeDev> {
+public:
+    NodeReceiver<DeviceBuf<Complex32>> input;
+    NodeSender<DeviceBuf<float>> output;
+    explicit FMDemodNodeDev(int device = 0) : device_(device) {
+        throw_on(comms_fmdemod_create(device, &h_), "FMDemodNodeDev::new");
+    }
+    FMDemodNodeDev(FMDemodNodeDev&& o) noexcept
+        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), device_(o.device_) { o.h_ = nullptr; }
+    ~FMDemodNodeDev() { comms_fmdemod_destroy(h_); }
+    Result<DeviceBuf<float>> run(const DeviceBuf<Complex32>& in) {
+        DeviceBuf<float> out(in.size(), device_);
+        comms_status_t st = comms_fmdemod_run_dev(h_, c32(in.ptr()), in.size(), out.ptr(), nullptr);
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_fmdemod_t* h_ = nullptr;
+    int device_;
+};
+
+// PulseNode over whole symbol blocks: n symbols in, n * sam_per_sym samples out
+class BatchPulseNodeDev : public DeriveNode<BatchPulseNodeDev> {
+public:
+    NodeReceiver<DeviceBuf<Complex32>> input;
+    NodeSender<DeviceBuf<Complex32>> output;
+    BatchPulseNodeDev(const std::vector<Complex32>& taps, size_t sam_per_sym, int device = 0)
+        : sps_(sam_per_sym), device_(device) {
+        throw_on(comms_pulse_create(c32(taps.data()), taps.size(), sam_per_sym, device, &h_), "BatchPulseNodeDev::new");
+    }
+    BatchPulseNodeDev(BatchPulseNodeDev&& o) noexcept
+        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), sps_(o.sps_), device_(o.device_) { o.h_ = nullptr; }
+    ~BatchPulseNodeDev() { comms_pulse_destroy(h_); }
+    Result<DeviceBuf<Complex32>> run(const DeviceBuf<Complex32>& sym) {
+        DeviceBuf<Complex32> out(sym.size() * sps_, device_);
+        comms_status_t st = comms_pulse_run_dev(h_, c32(sym.ptr()), sym.size(), c32(out.ptr()), nullptr);
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_pulse_t* h_ = nullptr;
+    size_t sps_;
+    int device_;
+};
+
+class UpsampleNodeDev : public DeriveNode<UpsampleNodeDev> {
+public:
+    NodeReceiver<DeviceBuf<Complex32>> input;
+    NodeSender<DeviceBuf<Complex32>> output;
+    explicit UpsampleNodeDev(size_t ups_rate, int device = 0) : rate_(ups_rate), device_(device) {}
+    Result<DeviceBuf<Complex32>> run(const DeviceBuf<Complex32>& in) {
+        size_t n_out = 0;
+        comms_upsample_out_len(in.size(), rate_, &n_out);
+        DeviceBuf<Complex32> out(n_out, device_);
+        comms_status_t st = comms_upsample_run_dev(in.ptr(), in.size(), sizeof(Complex32), rate_, out.ptr(), nullptr,
+                                                   device_, nullptr);
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    size_t rate_;
+    int device_;
+};
+
+// mixer / FIR / decimate [/ FM demod] as ONE node (comms_chain_*; an additional node, the results of
+// the reference nodes in series).  Out = Complex32 without FM demod, float with it.
+template <class Out>
+class ChainNodeDev : public DeriveNode<ChainNodeDev<Out>> {
+public:
+    static constexpr bool kFm = std::is_same<Out, float>::value;
+    NodeReceiver<DeviceBuf<Complex32>> input;
+    NodeSender<DeviceBuf<Out>> output;
+    ChainNodeDev(double dphase, double phase, const std::vector<Complex32>& taps, size_t rate, bool mixer_after_fir = false,
+                 int device = 0)
+        : rate_(rate), device_(device) {
+        const int32_t flags = (kFm ? COMMS_CHAIN_FM_DEMOD : 0) | (mixer_after_fir ? COMMS_CHAIN_MIXER_AFTER_FIR : 0);
+        throw_on(comms_chain_create_ex(dphase, phase, c32(taps.data()), taps.size(), rate, flags, device, &h_),
+                 "ChainNodeDev::new");
+    }
+    ChainNodeDev(ChainNodeDev&& o) noexcept
+        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), rate_(o.rate_), device_(o.device_) { o.h_ = nullptr; }
+    ~ChainNodeDev() { comms_chain_destroy(h_); }
+    Result<DeviceBuf<Out>> run(const DeviceBuf<Complex32>& in) {
+        if (rate_ == 0 || in.size() % rate_) return NodeError::DataError;
+        DeviceBuf<Out> out(in.size() / rate_, device_);
+        comms_status_t st = comms_chain_run_dev(h_, c32(in.ptr()), in.size(), out.ptr(), nullptr);
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    int fused_kind() const {  // 0 four kernels, 1 overlap-save fusion, 2 time-domain decimating kernel
+        int32_t f = 0;
+        comms_chain_is_fused(h_, &f);
+        return f;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_chain_t* h_ = nullptr;
     size_t rate_;
     int device_;
 };

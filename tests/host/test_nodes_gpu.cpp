@@ -254,6 +254,75 @@ static void test_device_resident_graph() {
     CHECK(worst < 1e-5f * 15.0f);
 }
 
+static void test_device_resident_chain_and_fft() {
+    // config 3 as a graph of device-resident messages: source -> fused chain (mixer, 127-tap LPF, /8,
+    // FM demod) -> sink, against the four host-vector nodes in series; then FFT -> IFFT round trip
+    const size_t n = 8 * 8192;
+    std::vector<C> x(n);
+    for (size_t i = 0; i < n; ++i) {
+        const double ph = -2.0 * M_PI * 0.05 * static_cast<double>(i) + 8.0 * std::cos(2.0 * M_PI * static_cast<double>(i) / 4096.0);
+        x[i] = C(static_cast<float>(std::cos(ph)), static_cast<float>(std::sin(ph)));
+    }
+    std::vector<C> taps(127);
+    for (int k = 0; k < 127; ++k) {
+        const double t = k - 63.0, sc = t == 0.0 ? 1.0 : std::sin(M_PI * t / 8.0) / (M_PI * t / 8.0);
+        taps[k] = C(static_cast<float>(0.125 * sc * (0.54 - 0.46 * std::cos(2.0 * M_PI * k / 126.0))), 0.f);
+    }
+    const double dphase = 2.0 * M_PI * 0.05;
+    BatchMixerNode m(dphase);
+    BatchFirNode f(taps);
+    DecimateNode<C> d(8);
+    FMDemodNode fm;
+    auto want = fm.run(d.run(f.run(m.run(x).value()).value()).value()).value();
+
+    Collect<DeviceBuf<float>> chk;
+    Replay<DeviceBuf<C>> src({DeviceBuf<C>::from_host(std::vector<C>(x.begin(), x.begin() + n / 2)),
+                              DeviceBuf<C>::from_host(std::vector<C>(x.begin() + n / 2, x.end()))});
+    ChainNodeDev<float> chain(dphase, 0.0, taps, 8);
+    CHECK(chain.fused_kind() == 2);
+    connect_nodes(src.output, chain.input);
+    connect_nodes(chain.output, chk.input);
+    start_nodes(std::move(src), std::move(chain));
+    while (chk.call().is_ok()) {
+    }
+    CHECK(chk.got.size() == 2);
+    if (chk.got.size() == 2) {
+        std::vector<float> got = chk.got[0].to_host();
+        const std::vector<float> g1 = chk.got[1].to_host();
+        got.insert(got.end(), g1.begin(), g1.end());
+        CHECK(got.size() == want.size());
+        double worst = 0.0;
+        for (size_t i = 64; i < got.size() && i < want.size(); ++i) {  // past the filter's start-up transient
+            double e = std::fabs(static_cast<double>(got[i]) - want[i]);
+            if (e > M_PI) e = 2.0 * M_PI - e;
+            worst = std::fmax(worst, e);
+        }
+        CHECK(worst < 1e-4);
+    }
+
+    FFTBatchNodeDev fwd(1024, false), inv(1024, true);
+    DeviceBuf<C> X = fwd.run(DeviceBuf<C>::from_host(std::vector<C>(x.begin(), x.begin() + 16 * 1024))).value();
+    std::vector<C> back = inv.run(X).value().to_host();
+    double worst = 0.0;
+    for (size_t i = 0; i < back.size(); ++i) worst = std::fmax(worst, std::abs(back[i] / 1024.0f - x[i]));
+    CHECK(worst < 1e-5);
+
+    // pulse shaping on a symbol block equals upsample + FIR (rect taps x4: every symbol held 4 samples)
+    std::vector<C> sym(1000);
+    for (size_t i = 0; i < sym.size(); ++i) sym[i] = C((i * 7) % 3 == 0 ? 1.f : -1.f, (i * 5) % 4 < 2 ? 1.f : -1.f);
+    BatchPulseNodeDev shaper(rect_taps(4), 4);
+    std::vector<C> shaped = shaper.run(DeviceBuf<C>::from_host(sym)).value().to_host();
+    CHECK(shaped.size() == 4000);
+    bool held = true;
+    for (size_t i = 0; i < shaped.size(); ++i) held = held && shaped[i] == sym[i / 4];
+    CHECK(held);
+    UpsampleNodeDev up(4);
+    std::vector<C> stuffed = up.run(DeviceBuf<C>::from_host(sym)).value().to_host();
+    bool zs = stuffed.size() == 4000;
+    for (size_t i = 0; i < stuffed.size() && zs; ++i) zs = stuffed[i] == (i % 4 ? C(0, 0) : sym[i / 4]);
+    CHECK(zs);
+}
+
 int main() {
     int32_t ndev = 0;
     if (comms_device_count(&ndev) != COMMS_OK || ndev < 1) {
@@ -268,6 +337,7 @@ int main() {
     test_fm_node();
     test_demod_nodes();
     test_device_resident_graph();
+    test_device_resident_chain_and_fft();
     if (g_fail) {
         std::fprintf(stderr, "%d check(s) failed\n", g_fail);
         return 1;
