@@ -200,6 +200,149 @@ impl FFTBatchNode {
 }
 
 /// Device-resident message: `Clone` bumps the library's refcount (the derive macro
+
+/// resample_node.rs:74-132
+#[derive(Node)]
+#[pass_by_ref]
+pub struct UpsampleNode {
+    pub input: NodeReceiver<Vec<Complex<f32>>>,
+    ups_rate: usize,
+    pub output: NodeSender<Vec<Complex<f32>>>,
+}
+impl UpsampleNode {
+    pub fn new(ups_rate: usize) -> Self {
+        UpsampleNode { input: Default::default(), ups_rate, output: Default::default() }
+    }
+    pub fn run(&mut self, signal: &[Complex<f32>]) -> Result<Vec<Complex<f32>>, NodeError> {
+        let mut n_out = 0usize;
+        unsafe { comms_upsample_out_len(signal.len(), self.ups_rate, &mut n_out) };
+        let mut out = vec![Complex::new(0.0f32, 0.0); n_out];
+        let st = unsafe {
+            comms_upsample_run(signal.as_ptr() as *const _, signal.len(), 8, self.ups_rate,
+                               out.as_mut_ptr() as *mut _, &mut n_out, 0)
+        };
+        if st == COMMS_OK { Ok(out) } else { Err(to_err(st)) }
+    }
+}
+
+/// An additional node: MixerNode -> BatchFirNode -> DecimateNode [-> FMDemodNode] (or
+/// BatchFirNode -> MixerNode -> DecimateNode with `mixer_after_fir`) as one launch
+/// (comms_chain_*).  `ChainNode` emits Complex<f32>, `FmChainNode` the demodulated f32.
+#[derive(Node)]
+#[pass_by_ref]
+pub struct ChainNode {
+    pub input: NodeReceiver<Vec<Complex<f32>>>,
+    h: *mut comms_chain_t,
+    rate: usize,
+    pub output: NodeSender<Vec<Complex<f32>>>,
+}
+handle_node!(ChainNode, comms_chain_t, comms_chain_destroy);
+impl ChainNode {
+    pub fn new(dphase: f64, phase: Option<f64>, taps: Vec<Complex<f32>>, rate: usize, mixer_after_fir: bool) -> Self {
+        let mut h = ptr::null_mut();
+        let flags = if mixer_after_fir { COMMS_CHAIN_MIXER_AFTER_FIR } else { 0 };
+        let st = unsafe { comms_chain_create_ex(dphase, phase.unwrap_or(0.0), taps.as_ptr(), taps.len(), rate, flags, 0, &mut h) };
+        assert_eq!(st, COMMS_OK, "comms_chain_create_ex failed");
+        ChainNode { input: Default::default(), h, rate, output: Default::default() }
+    }
+    pub fn run(&mut self, input: &[Complex<f32>]) -> Result<Vec<Complex<f32>>, NodeError> {
+        if self.rate == 0 || input.len() % self.rate != 0 { return Err(NodeError::DataError); }
+        let mut out = vec![Complex::new(0.0f32, 0.0); input.len() / self.rate];
+        let st = unsafe { comms_chain_run(self.h, input.as_ptr(), input.len(), out.as_mut_ptr() as *mut _) };
+        if st == COMMS_OK { Ok(out) } else { Err(to_err(st)) }
+    }
+}
+
+#[derive(Node)]
+#[pass_by_ref]
+pub struct FmChainNode {
+    pub input: NodeReceiver<Vec<Complex<f32>>>,
+    h: *mut comms_chain_t,
+    rate: usize,
+    pub output: NodeSender<Vec<f32>>,
+}
+handle_node!(FmChainNode, comms_chain_t, comms_chain_destroy);
+impl FmChainNode {
+    pub fn new(dphase: f64, phase: Option<f64>, taps: Vec<Complex<f32>>, rate: usize) -> Self {
+        let mut h = ptr::null_mut();
+        let st = unsafe {
+            comms_chain_create_ex(dphase, phase.unwrap_or(0.0), taps.as_ptr(), taps.len(), rate, COMMS_CHAIN_FM_DEMOD, 0, &mut h)
+        };
+        assert_eq!(st, COMMS_OK, "comms_chain_create_ex failed");
+        FmChainNode { input: Default::default(), h, rate, output: Default::default() }
+    }
+    pub fn run(&mut self, input: &[Complex<f32>]) -> Result<Vec<f32>, NodeError> {
+        if self.rate == 0 || input.len() % self.rate != 0 { return Err(NodeError::DataError); }
+        let mut out = vec![0.0f32; input.len() / self.rate];
+        let st = unsafe { comms_chain_run(self.h, input.as_ptr(), input.len(), out.as_mut_ptr() as *mut _) };
+        if st == COMMS_OK { Ok(out) } else { Err(to_err(st)) }
+    }
+}
+
+/// demodulation/timing_estimator.rs:116-136
+#[derive(Node)]
+#[pass_by_ref]
+pub struct TimingEstimatorNode {
+    pub input: NodeReceiver<Vec<Complex<f64>>>,
+    h: *mut comms_timing_t,
+    pub output: NodeSender<f64>,
+}
+handle_node!(TimingEstimatorNode, comms_timing_t, comms_timing_destroy);
+impl TimingEstimatorNode {
+    /// `Err(())` stands for the reference's `MathError::InvalidRolloffError`.
+    pub fn new(n: u32, d: u32, alpha: f64) -> Result<Self, ()> {
+        let mut h = ptr::null_mut();
+        let st = unsafe { comms_timing_create(n, d, alpha, 0, &mut h) };
+        if st != COMMS_OK { return Err(()); }
+        Ok(TimingEstimatorNode { input: Default::default(), h, output: Default::default() })
+    }
+    pub fn run(&mut self, input: &[Complex<f64>]) -> Result<f64, NodeError> {
+        let mut est = 0.0f64;
+        let st = unsafe { comms_timing_push(self.h, input.as_ptr() as *const f64, input.len(), &mut est) };
+        if st == COMMS_OK { Ok(est) } else { Err(to_err(st)) }
+    }
+}
+
+/// demodulation/nco.rs:118-133 in block form: a vector of phase errors per message.
+#[derive(Node)]
+#[pass_by_ref]
+pub struct BatchNcoNode {
+    pub input: NodeReceiver<Vec<f64>>,
+    h: *mut comms_nco_t,
+    pub output: NodeSender<Vec<Complex<f64>>>,
+}
+handle_node!(BatchNcoNode, comms_nco_t, comms_nco_destroy);
+impl BatchNcoNode {
+    pub fn new(dphase: f64, phase: Option<f64>) -> Self {
+        let mut h = ptr::null_mut();
+        let st = unsafe { comms_nco_create(dphase, phase.unwrap_or(0.0), 0, &mut h) };
+        assert_eq!(st, COMMS_OK, "comms_nco_create failed");
+        BatchNcoNode { input: Default::default(), h, output: Default::default() }
+    }
+    pub fn run(&mut self, perr: &[f64]) -> Result<Vec<Complex<f64>>, NodeError> {
+        let mut out = vec![Complex::new(0.0f64, 0.0); perr.len()];
+        let st = unsafe { comms_nco_run(self.h, perr.as_ptr(), perr.len(), out.as_mut_ptr() as *mut f64) };
+        if st == COMMS_OK { Ok(out) } else { Err(to_err(st)) }
+    }
+}
+
+/// demodulation/frequency_estimator.rs:27-42, phase_estimator.rs:26-33, :58-65 (free functions there too)
+pub fn frequency_offset_estimate(samples: &[Complex<f64>]) -> f64 {
+    let mut out = 0.0f64;
+    unsafe { comms_frequency_offset_estimate(samples.as_ptr() as *const f64, samples.len(), &mut out, 0) };
+    out
+}
+pub fn psk_phase_estimate(symbols: &[Complex<f64>], m: u32) -> f64 {
+    let mut out = 0.0f64;
+    unsafe { comms_psk_phase_estimate(symbols.as_ptr() as *const f64, symbols.len(), m, &mut out, 0) };
+    out
+}
+pub fn qam_phase_estimate(symbols: &[Complex<f64>]) -> f64 {
+    let mut out = 0.0f64;
+    unsafe { comms_qam_phase_estimate(symbols.as_ptr() as *const f64, symbols.len(), &mut out, 0) };
+    out
+}
+
 /// clones once per sender, node_derive/src/lib.rs:156).
 pub struct DeviceBuf { b: *mut comms_buf_t, pub len: usize }
 unsafe impl Send for DeviceBuf {}

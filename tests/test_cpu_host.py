@@ -173,3 +173,12 @@ def test_sharded_stream_equals_unsharded_gloo_world2(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r))) for r in range(2)]
     rcs = [p.wait(timeout=300) for p in procs]
     assert rcs == [0, 0], rcs
+
+
+def test_rust_shim_declares_every_header_symbol():
+    """The Rust shim is untested source (no rustc here); at least its `extern "C"` block is
+    generated from the header and must be in step with it."""
+    import subprocess
+
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "scripts", "gen_rust_ffi.py"), "--check"]) == 0, \
+        "comms_rs_amd/rust_shim/src/ffi.rs is stale: run scripts/gen_rust_ffi.py"
