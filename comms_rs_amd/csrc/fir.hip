@@ -1115,17 +1115,21 @@ static comms_status_t fir_prepare_direct(comms_fir* h) {
 static int fir_pick(const comms_fir* h, size_t n) {
     int algo = h->algo;
     if (algo == COMMS_FIR_AUTO) {
-        // measured on MI355X (2^24 samples): the 1024-point overlap-save kernel takes ~62 us for
-        // any tap count up to 257, the direct kernel 70 us at 16 taps and 88 us at 63 -- so the
-        // direct form is kept for very short filters and for calls too short to fill segments
-        if (h->n_eff > DIRECT_MAX_TAPS)
+        // Measured on MI355X (launch to completion, `scripts/bench_fir.py`), 16 ... 255 taps, 2^16 ... 2^24
+        // samples: the direct kernel costs about 6.5 us + 0.025 us/tap + n * (3.3 + 0.038 * taps) ps,
+        // the 1024-point overlap-save kernel about 12.4 us + n * 2.0 ps for any tap count up to 257.
+        // Radio-sized batches (2^18 samples) of the 32- and 63-tap filters the reference's examples
+        // use are therefore direct-form work (8 us against 13); long streams are not.
+        if (h->n_eff > DIRECT_MAX_TAPS) {
             algo = COMMS_FIR_OVERLAP_SAVE;
-        else if (h->n_eff <= 8)
-            algo = COMMS_FIR_DIRECT;
-        else if (n * static_cast<size_t>(h->n_eff) < (1u << 18) || n < (1u << 14))
-            algo = COMMS_FIR_DIRECT;
-        else
-            algo = COMMS_FIR_OVERLAP_SAVE;
+        } else if (h->n_eff <= 8 || n < 1024) {
+            algo = COMMS_FIR_DIRECT;  // <= 8 taps: a tie on long streams (66 us both at 2^24); less than one segment
+        } else {
+            const double t = static_cast<double>(h->n_eff), nn = static_cast<double>(n);
+            const double direct_ps = 6.5e6 + 0.025e6 * t + nn * (3.3 + 0.038 * t);
+            const double os_ps = 12.4e6 + nn * 2.0;
+            algo = direct_ps < os_ps ? COMMS_FIR_DIRECT : COMMS_FIR_OVERLAP_SAVE;
+        }
     }
     if (algo == COMMS_FIR_OVERLAP_SAVE)
         algo = h->n_eff <= 257 ? COMMS_FIR_OS1024 : h->n_eff <= 2049 ? COMMS_FIR_OS4096 : COMMS_FIR_OS16K;
@@ -1234,7 +1238,7 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
         const size_t nseg = (n + WV - 1) / WV;
         // one wave per run of consecutive segments
         static const int wpb = tune_int("COMMS_OS1024_WPB", 16);
-        static const int min_run = tune_int("COMMS_OS1024_MINRUN", 4);
+        static const int min_run = tune_int("COMMS_OS1024_MINRUN", 1);
         const size_t runs = os1024_runs(wpb, nseg, min_run);
         WTables tb{reinterpret_cast<const cf*>(h->d_wtw1), reinterpret_cast<const cf*>(h->d_wtw2), reinterpret_cast<const cf*>(h->d_whdev)};
         h->tic(s);
@@ -1362,7 +1366,7 @@ comms_status_t comms_fir_run_fused_dev(comms_fir_t* h, const comms_c32* d_in, si
     ch.fm_prev_new = static_cast<float2*>(fm_prev_new);
     const size_t nseg = (n + WV - 1) / WV;
     static const int wpb = tune_int("COMMS_OS1024_WPB", 16);
-    const size_t runs = os1024_runs(wpb, nseg, 4);
+    const size_t runs = os1024_runs(wpb, nseg, 1);
     WTables tb{reinterpret_cast<const cf*>(h->d_wtw1), reinterpret_cast<const cf*>(h->d_wtw2), reinterpret_cast<const cf*>(h->d_whdev)};
     h->tic(s);
     switch (mode) {

@@ -186,6 +186,11 @@ def test_fir_auto_selection_and_errors(c):
     assert c.BatchFirNode(np.ones(8, np.complex64)).algo_for(1 << 24) == c.FIR_DIRECT
     assert c.BatchFirNode(np.ones(63, np.complex64)).algo_for(1 << 24) == c.FIR_OS1024
     assert c.BatchFirNode(np.ones(63, np.complex64)).algo_for(4096) == c.FIR_DIRECT
+    # radio-sized batches of the examples' 32- / 63-tap filters are direct-form work, long filters are not
+    assert c.BatchFirNode(np.ones(63, np.complex64)).algo_for(1 << 18) == c.FIR_DIRECT
+    assert c.BatchFirNode(np.ones(32, np.complex64)).algo_for(1 << 20) == c.FIR_DIRECT
+    assert c.BatchFirNode(np.ones(63, np.complex64)).algo_for(1 << 22) == c.FIR_OS1024
+    assert node.algo_for(1 << 18) == c.FIR_OS1024
     assert node.run(np.zeros(0, np.complex64)).size == 0
     with pytest.raises(c.CommsError) as e:
         c.BatchFirNode(np.zeros(0, np.complex64))
