@@ -141,6 +141,15 @@ struct Handle {
         }
     }
 
+    // For launches made with hipExtLaunchKernelGGL: the pair is updated with the kernel's own
+    // begin / end timestamps (no dispatch gap), which is what rocprofv3 reports as its duration.
+    bool timed() const { return timer && timer->n; }
+    void next_events(hipEvent_t& a, hipEvent_t& b) {
+        a = timer->start[timer->next % timer->n];
+        b = timer->stop[timer->next % timer->n];
+        ++timer->next;
+    }
+
     comms_status_t init(int32_t dev) {
         COMMS_TRY(use_device(dev));
         device = dev;

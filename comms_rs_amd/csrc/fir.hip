@@ -27,6 +27,8 @@
 #include <utility>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "common.hpp"
 #include "fft_radix.hpp"
 #include "fir_handle.hpp"
@@ -883,7 +885,8 @@ static void free_fir(comms_fir* h) {
 template <int MODE>
 static comms_status_t launch_os1024(int wpb, size_t runs, hipStream_t s, const float2* in, const float2* hist,
                                     int n_eff, float2* o, size_t n, size_t nseg, const comms::WTables& tb,
-                                    float2* nh, const comms::ChainArgs& ch) {
+                                    float2* nh, const comms::ChainArgs& ch, hipEvent_t ev_start = nullptr,
+                                    hipEvent_t ev_stop = nullptr) {
     using namespace comms;
     if (wpb == 16) {
         const size_t lds = (2112 + 16 * W_LDS) * sizeof(float2);
@@ -891,6 +894,12 @@ static comms_status_t launch_os1024(int wpb, size_t runs, hipStream_t s, const f
         if (attr_once.need()) {
             COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os1024_kernel<16, 4, MODE>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        }
+        if (ev_start) {  // timed launch: the events take the kernel's own begin / end timestamps
+            hipExtLaunchKernelGGL((fir_os1024_kernel<16, 4, MODE>), dim3(static_cast<unsigned>((runs + 15) / 16)),
+                                  dim3(1024), static_cast<uint32_t>(lds), s, ev_start, ev_stop, 0u, in, hist, n_eff, o, n,
+                                  nseg, runs, tb, nh, ch);
+            return COMMS_OK;
         }
         fir_os1024_kernel<16, 4, MODE><<<dim3(static_cast<unsigned>((runs + 15) / 16)), dim3(1024), lds, s>>>(
             in, hist, n_eff, o, n, nseg, runs, tb, nh, ch);
@@ -1241,9 +1250,11 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
         static const int min_run = tune_int("COMMS_OS1024_MINRUN", 1);
         const size_t runs = os1024_runs(wpb, nseg, min_run);
         WTables tb{reinterpret_cast<const cf*>(h->d_wtw1), reinterpret_cast<const cf*>(h->d_wtw2), reinterpret_cast<const cf*>(h->d_whdev)};
-        h->tic(s);
-        COMMS_TRY(launch_os1024<0>(wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}));
-        h->toc(s);
+        hipEvent_t ea = nullptr, eb = nullptr;
+        if (h->timed() && wpb == 16) h->next_events(ea, eb);
+        if (!ea) h->tic(s);
+        COMMS_TRY(launch_os1024<0>(wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb));
+        if (!ea) h->toc(s);
         COMMS_TRY(launch_ok("fir_os1024_kernel"));
     } else if (algo == COMMS_FIR_OS16K) {
         COMMS_TRY(fir_prepare_os16k(h));
