@@ -539,6 +539,9 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
 #pragma unroll
                 for (int a = 4; a < 16; ++a)
                     v[R16_POS(a)] = cmulf(v[R16_POS(a)], cmulf(rot, to_cf(ch.step_a[a])));
+                // FM demod of row 4 reaches back into the tail of row 3 (valid outputs of the previous
+                // segment's span, recomputed here): they must carry the mixer rotation too
+                if (MODE & CH_FM) v[R16_POS(3)] = cmulf(v[R16_POS(3)], cmulf(rot, to_cf(ch.step_a[3])));
             }
             // FM needs y[idx - rate]: lane l - rate of the same row, or the tail of row a-1
             const int src = (l - static_cast<int>(ch.rate)) & 63;

@@ -663,6 +663,40 @@ def test_time_domain_decimating_chain_kernel(c, rate):
             ys.append(y)
 
 
+def test_chain_kernels_agree_on_random_configurations(c):
+    """Seeded sweep: the time-domain decimating kernel, the overlap-save fusion and the four
+    kernels in series on random (taps, rate, mixer position, FM, phases, lengths, batch cuts)."""
+    rng = np.random.default_rng(2024)
+    rates = [2, 3, 4, 5, 6, 8, 10, 12, 16]
+    for case in range(48):
+        rate = int(rng.choice(rates))
+        fm = bool(rng.integers(0, 2))
+        n_taps = int(rng.integers(1, 258 - (rate if fm else 0)))  # the overlap-save fusion needs taps + rate <= 257 with FM
+        after = bool(rng.integers(0, 2))
+        cplx = bool(rng.integers(0, 2))
+        taps = lowpass_taps(n_taps, 1 / (2.5 * rate))
+        if cplx:
+            taps = (taps * np.exp(1j * rng.uniform(0, 0.5) * np.arange(n_taps))).astype(np.complex64)
+        dphase, phase = float(rng.uniform(-7, 7)), float(rng.uniform(0, 6))
+        n_out = int(rng.integers(1, 3000))
+        cuts = sorted({0, n_out * rate, *(int(v) * rate for v in rng.integers(0, n_out + 1, 2))})
+        x = fm_stream(n_out * rate) if fm else rand_c(rng, n_out * rate)
+        kw = dict(mixer_after_fir=after)
+        nodes = {k: c.ChainNode(dphase, phase, taps, rate, fm, kernel=k, **kw) for k in ("time", "freq")}
+        nodes["unfused"] = c.ChainNode(dphase, phase, taps, rate, fm, unfused=True, **kw)
+        assert nodes["time"].kernel == "time" and nodes["freq"].kernel == "freq", (case, n_taps, rate)
+        outs = {k: np.concatenate([nd.run(x[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]) for k, nd in nodes.items()}
+        ref = outs["unfused"]
+        for k in ("time", "freq"):
+            if fm:
+                # compare on the circle, weighted by the magnitude of the samples the angle comes from
+                y = c.ChainNode(dphase, phase, taps, rate, False, unfused=True, **kw).run(x)
+                mag = np.minimum(np.abs(y), np.abs(np.concatenate([[0.0], y[:-1]])))
+                assert np.max(circ(outs[k].astype(np.float64) - ref) * mag, initial=0.0) <= 4e-5 * np.sum(np.abs(taps)), (case, k)
+            else:
+                fir_close(outs[k], ref, taps, x)
+
+
 @pytest.mark.parametrize("after", [False, True])
 @pytest.mark.parametrize("variant", ["time", "freq", "unfused"])
 def test_chain_shard_continues_the_stream(c, variant, after):
