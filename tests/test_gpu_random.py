@@ -1,0 +1,106 @@
+"""Seeded random sweeps of the HIP nodes against the CPU oracle (-m gpu): every case draws its
+sizes, tap counts, rates, phases, states and batch cuts from a fixed-seed generator, so a
+failure reproduces by case number.  Complements test_gpu_parity.py's hand-picked cases (a sweep
+of this kind found the post-FIR-mixer + FM demod bug of the overlap-save fusion)."""
+import numpy as np
+import pytest
+
+import oracle
+from test_gpu_parity import TOL, circ, fft_close, fir_close, lowpass_taps, rand_c  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c():
+    import comms_rs_amd as c
+
+    assert c.device_count() >= 1, "no MI355X visible: the HIP path cannot be tested (no CPU fallback)"
+    return c
+
+
+def cuts_of(rng, n, k=2, multiple=1):
+    pts = {0, n, *(int(v) // multiple * multiple for v in rng.integers(0, n + 1, k))}
+    return sorted(pts)
+
+
+def test_fir_random_sweep(c):
+    rng = np.random.default_rng(11)
+    algos = [c.FIR_AUTO, c.FIR_DIRECT, c.FIR_OS1024, c.FIR_OS4096, c.FIR_OS16K]
+    for case in range(40):
+        algo = algos[case % len(algos)]
+        hi = {c.FIR_AUTO: 700, c.FIR_DIRECT: 300, c.FIR_OS1024: 257, c.FIR_OS4096: 700, c.FIR_OS16K: 900}[algo]
+        n_taps = int(rng.integers(1, hi + 1))
+        taps = rand_c(rng, n_taps) if rng.integers(0, 2) else rand_c(rng, n_taps).real.astype(np.complex64)
+        n = int(rng.integers(1, 12000))
+        x = rand_c(rng, n)
+        # optional user state, shorter / equal / longer than the taps (zip truncation, fir.rs:53)
+        state = None
+        if rng.integers(0, 3) == 0:
+            state = rand_c(rng, int(rng.integers(1, n_taps + 20)))
+        node = c.BatchFirNode(taps, state)
+        if algo != c.FIR_AUTO:
+            node.set_algo(algo)
+        ost = oracle.default_state(taps) if state is None else state.copy()
+        got, want = [], []
+        cuts = cuts_of(rng, n)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            got.append(node.run(x[a:b]))
+            want.append(oracle.batch_fir(x[a:b], taps, ost))  # literal form: any state length (zip, fir.rs:53)
+        fir_close(np.concatenate(got), np.concatenate(want), taps[:min(n_taps, ost.size)], x)
+
+
+def test_mixer_decimate_upsample_fm_random_sweep(c):
+    rng = np.random.default_rng(12)
+    for case in range(30):
+        n = int(rng.integers(1, 50000))
+        x = rand_c(rng, n)
+        dphase, phase = float(rng.uniform(-20, 20)), float(rng.uniform(-10, 10))
+        gm, om = c.MixerNode(dphase, phase), oracle.Mixer(phase, dphase)
+        gfm, ofm = c.FMDemodNode(), oracle.FM()
+        for a, b in zip(*(lambda cs: (cs[:-1], cs[1:]))(cuts_of(rng, n))):
+            g, w = gm.run(x[a:b]), om.mix(x[a:b])
+            assert np.all(np.abs(g - w) <= TOL * np.abs(x[a:b]) + 1e-30), case
+            gf, wf = gfm.run(x[a:b]), ofm.demod(x[a:b])
+            # the angle of x[i] * conj(x[i-1]) is ill-conditioned where that product is ~0
+            prod = np.abs(x[a:b]) * np.abs(np.concatenate([x[max(a - 1, 0):a] if a else [0], x[a:b - 1]]))
+            ok = prod > 1e-3
+            assert np.max(circ(gf.astype(np.float64) - wf)[ok], initial=0.0) <= 1e-5 / 1e-3 * 1e-2, case
+        rate = int(rng.integers(0, 40))
+        for dt in (np.complex64, np.float32, np.int16, np.uint8, np.complex128):
+            v = (rng.integers(0, 200, n)).astype(dt)
+            assert np.array_equal(c.DecimateNode(rate).run(v), oracle.decimate(v, rate)), (case, rate, dt)
+            if n * max(rate, 1) <= 400000:
+                assert np.array_equal(c.UpsampleNode(rate).run(v), oracle.upsample(v, rate)), (case, rate, dt)
+
+
+def test_fft_random_sweep(c):
+    rng = np.random.default_rng(13)
+    sizes = [2 ** k for k in range(1, 18)] + [3, 6, 10, 12, 15, 60, 100, 360, 1000, 1536, 3000, 4097, 6000, 10000]
+    for case in range(40):
+        n = int(sizes[int(rng.integers(0, len(sizes)))])
+        inverse = bool(rng.integers(0, 2))
+        batch = int(rng.integers(1, max(2, min(600, (1 << 19) // n))))
+        x = rand_c(rng, n * batch)
+        got = c.FFTBatchNode(n, inverse).run(x)
+        f = (lambda v: np.fft.ifft(v, axis=1) * n) if inverse else (lambda v: np.fft.fft(v, axis=1))
+        want = f(x.astype(np.complex128).reshape(batch, n)).reshape(-1)
+        fft_close(got, want)
+        if n <= 2048:  # and the oracle's own f64 DFT on the first transform
+            fft_close(got[:n], oracle.fft(x[:n], inverse))
+
+
+def test_pulse_random_sweep(c):
+    rng = np.random.default_rng(14)
+    for case in range(30):
+        sps = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 10, 16, 20]))
+        n_taps = int(rng.integers(1, 400))
+        taps = rand_c(rng, n_taps) if rng.integers(0, 2) else rand_c(rng, n_taps).real.astype(np.complex64)
+        n = int(rng.integers(1, 4000))
+        sym = rand_c(rng, n)
+        node, st = c.PulseNode(taps, sps), oracle.default_state(taps)
+        got, want = [], []
+        for a, b in zip(*(lambda cs: (cs[:-1], cs[1:]))(cuts_of(rng, n))):
+            got.append(node.run(sym[a:b]))
+            want.append(oracle.pulse(sym[a:b], taps, sps, st))
+        fir_close(np.concatenate(got), np.concatenate(want), taps, sym)
