@@ -355,15 +355,16 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// The 12 new 64-sample rows of the segment that starts at sample nb (zeros past the end)
+// The NR new 64-sample rows of the segment that starts at sample nb (zeros past the end)
+template <int NR>
 __device__ __forceinline__ void load_rows(const float2* __restrict__ in, size_t nb, int l, size_t n,
-                                          cf (&r)[12]) {
-    if (nb + WV <= n) {
+                                          cf (&r)[NR]) {
+    if (nb + 64 * NR <= n) {
 #pragma unroll
-        for (int a = 0; a < 12; ++a) r[a] = to_cf(in[nb + 64 * a + l]);
+        for (int a = 0; a < NR; ++a) r[a] = to_cf(in[nb + 64 * a + l]);
     } else {
 #pragma unroll
-        for (int a = 0; a < 12; ++a) {
+        for (int a = 0; a < NR; ++a) {
             const size_t g = nb + 64 * a + l;
             r[a] = g < n ? to_cf(in[g]) : cf{0.f, 0.f};
         }
@@ -373,7 +374,9 @@ __device__ __forceinline__ void load_rows(const float2* __restrict__ in, size_t 
 // WPB waves per workgroup share the read-only tables in LDS (stage-1 twiddles,
 // filter spectrum, W64 table: 16.5 KiB); every wave has a private 8.5 KiB
 // exchange buffer and runs on its own -- no workgroup barrier after set-up.
-template <int WPB, int MINW, int MODE>
+// HR = halo rows of 64 samples: 4 (up to 257 taps, 768 new samples per segment) or, for the plain
+// FIR with up to 129 taps, 2 (896 new samples per segment: the same transforms yield 1/6 more).
+template <int WPB, int MINW, int MODE, int HR = 4>
 __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2* __restrict__ in,
                                                                     const float2* __restrict__ hist,
                                                                     int hist_len,
@@ -382,6 +385,8 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
                                                                     WTables tb,
                                                                     float2* __restrict__ new_hist,
                                                                     ChainArgs ch) {
+    static_assert(HR == 4 || (HR == 2 && MODE == 0), "the short halo is for the plain FIR only");
+    constexpr int WVK = 1024 - 64 * HR, HALO = 64 * HR, NEWR = 16 - HR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     hist_advance(hist, in, n, new_hist, hist_len);
     cf* tw1 = reinterpret_cast<cf*>(smem);  // [16][64]
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
     // mixer rotor of this lane's first row (sample seg*768 - 256 + l), f64
     double rot_c = 1.0, rot_s = 0.0;
     if ((MODE & (CH_PRE | CH_POST)) && seg0 < seg1) {
-        const long long i0 = static_cast<long long>(seg0 * WV) - 256 + l;
+        const long long i0 = static_cast<long long>(seg0 * WVK) - HALO + l;
         const uint64_t turns = ch.turns0 + static_cast<uint64_t>(i0) * ch.frac;
         sincos(static_cast<double>(turns >> 11) * (kTwoPiF * 0x1.0p-53), &rot_s, &rot_c);
     }
@@ -425,11 +430,11 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
     }
     if (MODE & CH_STAMP) st_prev = __builtin_amdgcn_s_memtime();
 
-    cf v[16], carry[4], nxt[12];
+    cf v[16], carry[HR], nxt[NEWR];
     size_t dec_q = 0;
     unsigned dec_r = 0;
     for (size_t seg = seg0; seg < seg1; ++seg) {
-        const size_t nb = seg * WV;  // first new sample of this segment
+        const size_t nb = seg * WVK;  // first new sample of this segment
         cf rot = cf{static_cast<float>(rot_c), static_cast<float>(rot_s)};
         if (MODE & (CH_PRE | CH_POST)) {  // advance to the next segment's first row
             const double nc = rot_c * ch.seg_c - rot_s * ch.seg_s;
@@ -438,26 +443,26 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
         }
         if (seg == seg0) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                v[a] = to_cf(stream_at(in, hist, hist_len, static_cast<long long>(nb) - 256 + 64 * a + l, n));
+            for (int a = 0; a < HR; ++a) {
+                v[a] = to_cf(stream_at(in, hist, hist_len, static_cast<long long>(nb) - HALO + 64 * a + l, n));
                 if (MODE & CH_PRE) v[a] = cmulf(v[a], a ? cmulf(rot, to_cf(ch.step_a[a])) : rot);
             }
         } else {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) v[a] = carry[a];
+            for (int a = 0; a < HR; ++a) v[a] = carry[a];
         }
         // (A register prefetch of the next segment's rows was tried and lost: vmcnt is one
         // in-order counter for loads and stores, so the wait for prefetched rows also
         // drains the previous segment's 12 stores -- 57.6 -> 65 us.)
         load_rows(in, nb, l, n, nxt);
 #pragma unroll
-        for (int a = 4; a < 16; ++a) v[a] = nxt[a - 4];
+        for (int a = HR; a < 16; ++a) v[a] = nxt[a - HR];
         if (MODE & CH_PRE) {
 #pragma unroll
             for (int a = 4; a < 16; ++a) v[a] = cmulf(v[a], cmulf(rot, to_cf(ch.step_a[a])));
         }
 #pragma unroll
-        for (int a = 0; a < 4; ++a) carry[a] = v[12 + a];
+        for (int a = 0; a < HR; ++a) carry[a] = v[16 - HR + a];
         OS_STAMP(0)  // global loads landed
 
         // ---- forward
@@ -524,13 +529,13 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
         OS_STAMP(8)  // exchange-4 reads + twiddle
         radix16<1>(v);
         if ((MODE & ~CH_STAMP) == 0) {
-            if (nb + WV <= n) {
+            if (nb + WVK <= n) {
 #pragma unroll
-                for (int a = 4; a < 16; ++a) out[nb + 64 * (a - 4) + l] = to_f2(v[R16_POS(a)]);
+                for (int a = HR; a < 16; ++a) out[nb + 64 * (a - HR) + l] = to_f2(v[R16_POS(a)]);
             } else {
 #pragma unroll
-                for (int a = 4; a < 16; ++a) {
-                    const size_t o = nb + 64 * (a - 4) + l;
+                for (int a = HR; a < 16; ++a) {
+                    const size_t o = nb + 64 * (a - HR) + l;
                     if (o < n) out[o] = to_f2(v[R16_POS(a)]);
                 }
             }
@@ -885,7 +890,7 @@ static void free_fir(comms_fir* h) {
 // One launch of fir_os1024_kernel<.., MODE>: 16-wave workgroups (one per CU, 156 KiB of
 // LDS: shared tables + 16 private exchange buffers) by default, 4-wave workgroups
 // (three per CU) with COMMS_OS1024_WPB=4.
-template <int MODE>
+template <int MODE, int HR = 4>
 static comms_status_t launch_os1024(int wpb, size_t runs, hipStream_t s, const float2* in, const float2* hist,
                                     int n_eff, float2* o, size_t n, size_t nseg, const comms::WTables& tb,
                                     float2* nh, const comms::ChainArgs& ch, hipEvent_t ev_start = nullptr,
@@ -895,20 +900,20 @@ static comms_status_t launch_os1024(int wpb, size_t runs, hipStream_t s, const f
         const size_t lds = (2112 + 16 * W_LDS) * sizeof(float2);
         static DeviceOnce attr_once;
         if (attr_once.need()) {
-            COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os1024_kernel<16, 4, MODE>),
+            COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os1024_kernel<16, 4, MODE, HR>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         }
         if (ev_start) {  // timed launch: the events take the kernel's own begin / end timestamps
-            hipExtLaunchKernelGGL((fir_os1024_kernel<16, 4, MODE>), dim3(static_cast<unsigned>((runs + 15) / 16)),
+            hipExtLaunchKernelGGL((fir_os1024_kernel<16, 4, MODE, HR>), dim3(static_cast<unsigned>((runs + 15) / 16)),
                                   dim3(1024), static_cast<uint32_t>(lds), s, ev_start, ev_stop, 0u, in, hist, n_eff, o, n,
                                   nseg, runs, tb, nh, ch);
             return COMMS_OK;
         }
-        fir_os1024_kernel<16, 4, MODE><<<dim3(static_cast<unsigned>((runs + 15) / 16)), dim3(1024), lds, s>>>(
+        fir_os1024_kernel<16, 4, MODE, HR><<<dim3(static_cast<unsigned>((runs + 15) / 16)), dim3(1024), lds, s>>>(
             in, hist, n_eff, o, n, nseg, runs, tb, nh, ch);
     } else {
         const size_t lds = (2112 + 4 * W_LDS) * sizeof(float2);
-        fir_os1024_kernel<4, 3, MODE><<<dim3(static_cast<unsigned>((runs + 3) / 4)), dim3(256), lds, s>>>(
+        fir_os1024_kernel<4, 3, MODE, HR><<<dim3(static_cast<unsigned>((runs + 3) / 4)), dim3(256), lds, s>>>(
             in, hist, n_eff, o, n, nseg, runs, tb, nh, ch);
     }
     return COMMS_OK;
@@ -1247,7 +1252,11 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
         COMMS_TRY(launch_ok("fir_direct_kernel"));
     } else if (algo == COMMS_FIR_OS1024) {
         COMMS_TRY(fir_prepare_os1024(h));
-        const size_t nseg = (n + WV - 1) / WV;
+        // up to 129 taps the halo is two rows, not four: 896 new samples per 1024-point segment
+        static const bool short_halo_ok = tune_int("COMMS_OS1024_SHORT_HALO", 1) != 0;
+        const bool hr2 = short_halo_ok && h->n_eff <= 129;
+        const size_t wv = hr2 ? 896 : WV;
+        const size_t nseg = (n + wv - 1) / wv;
         // one wave per run of consecutive segments
         static const int wpb = tune_int("COMMS_OS1024_WPB", 16);
         static const int min_run = tune_int("COMMS_OS1024_MINRUN", 1);
@@ -1256,7 +1265,10 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
         hipEvent_t ea = nullptr, eb = nullptr;
         if (h->timed() && wpb == 16) h->next_events(ea, eb);
         if (!ea) h->tic(s);
-        COMMS_TRY(launch_os1024<0>(wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb));
+        if (hr2)
+            COMMS_TRY((launch_os1024<0, 2>(wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb)));
+        else
+            COMMS_TRY(launch_os1024<0>(wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb));
         if (!ea) h->toc(s);
         COMMS_TRY(launch_ok("fir_os1024_kernel"));
     } else if (algo == COMMS_FIR_OS16K) {
