@@ -176,6 +176,32 @@ def test_config5_4097_taps_windowed_sinc_long_stream(c):
         fir_close(y[a:a + 3000].cpu().numpy(), want, taps, xs)
 
 
+def test_config5_full_shard_2p27_second_rank(c):
+    """BASELINE config 5 at one GPU's full share: 2^30 samples over 8 GPUs = 2^27 per rank, 4097 taps.
+    Rank 1's shard (stream samples 2^27 .. 2^28) with the halo handed over as FIR state, checked
+    against the oracle on windows (the first one straddles the shard boundary)."""
+    import torch
+
+    from comms_rs_amd.sharding import state_from_halo
+
+    n, first = 1 << 27, 1 << 27
+    k = np.arange(4097) - 2048
+    taps = (0.25 * np.sinc(0.25 * k) * np.hamming(4097)).astype(np.float32).astype(np.complex64)
+    x = torch.empty(n, dtype=torch.complex64, device="cuda:0")
+    y = torch.empty_like(x)
+    c.synth_iq_dev(x.data_ptr(), n, first, 5)
+    node = c.BatchFirNode(taps)
+    node.set_state(state_from_halo(c.synth_iq(4097, first - 4097, 5)))
+    assert node.algo_for(n) == c.FIR_OS16K
+    node.run_dev(x.data_ptr(), n, y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for a in (0, 12288 - 100, 5 * (1 << 20) + 17, n - 3000):
+        lo = first + a - 4096
+        xs = c.synth_iq(4096 + 3000, lo, 5)
+        want = oracle.batch_fir(xs, taps, oracle.default_state(taps), norotate=True)[4096:]
+        fir_close(y[a:a + 3000].cpu().numpy(), want, taps, xs)
+
+
 def test_fir_auto_selection_and_errors(c):
     taps = np.ones(255, np.complex64)
     node = c.BatchFirNode(taps)
@@ -507,6 +533,32 @@ def test_fft_config4_size_roundtrip(c):
     c.FFTBatchNode(n, True).run_dev(y.data_ptr(), n * batch, y.data_ptr(), s)  # in place
     torch.cuda.synchronize()
     fft_close((y / n).cpu().numpy(), xs)
+
+
+def test_fft_config4_full_batch_4096_roundtrip(c):
+    """BASELINE config 4 at its full size: 4096 transforms of 2^20 points (32 GiB), in place on the
+    device: forward, spot checks against the oracle, inverse, round trip of sampled transforms."""
+    import torch
+
+    n, batch = 1 << 20, 4096
+    free, _ = torch.cuda.mem_get_info()
+    if free < (36 << 30):
+        pytest.skip("needs 36 GiB of free HBM")
+    x = torch.empty(n * batch, dtype=torch.complex64, device="cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    c.synth_iq_dev(x.data_ptr(), n * batch, 0, 40)
+    fwd, inv = c.FFTBatchNode(n, False), c.FFTBatchNode(n, True)
+    fwd.run_dev(x.data_ptr(), n * batch, x.data_ptr(), s)
+    torch.cuda.synchronize()
+    picks = (0, 1, 2047, 4095)
+    for b in picks:
+        fft_close(x[b * n:(b + 1) * n].cpu().numpy(), oracle.fft(c.synth_iq(n, b * n, 40), False))
+    inv.run_dev(x.data_ptr(), n * batch, x.data_ptr(), s)
+    torch.cuda.synchronize()
+    for b in picks + (1000, 3000):
+        fft_close((x[b * n:(b + 1) * n] / n).cpu().numpy(), c.synth_iq(n, b * n, 40))
+    del x
+    torch.cuda.empty_cache()
 
 
 # ------------------------------------------------------------------ chains (configs 1 and 3)
