@@ -154,13 +154,9 @@ comms_status_t comms_chain_run(comms_chain_t* h, const comms_c32* in, size_t n, 
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
     const size_t out_bytes = (n / h->rate) * (h->fm_demod ? sizeof(float) : sizeof(comms_c32));
-    COMMS_TRY(h->in_scratch.reserve(n * sizeof(comms_c32)));
-    COMMS_TRY(h->out_scratch.reserve(out_bytes));
-    COMMS_HIP_TRY(hipMemcpyAsync(h->in_scratch.p, in, n * sizeof(comms_c32), hipMemcpyHostToDevice, h->stream));
-    COMMS_TRY(comms_chain_run_dev(h, static_cast<comms_c32*>(h->in_scratch.p), n, h->out_scratch.p, COMMS_STREAM_HANDLE));
-    COMMS_HIP_TRY(hipMemcpyAsync(out, h->out_scratch.p, out_bytes, hipMemcpyDeviceToHost, h->stream));
-    COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
-    return COMMS_OK;
+    return h->run_host(in, n * sizeof(comms_c32), out, out_bytes, [&](void* d_in, void* d_out) {
+        return comms_chain_run_dev(h, static_cast<const comms_c32*>(d_in), n, d_out, COMMS_STREAM_HANDLE);
+    });
 }
 
 comms_status_t comms_chain_set_timer(comms_chain_t* h, comms_timer_t* t) {

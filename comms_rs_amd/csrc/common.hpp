@@ -110,6 +110,37 @@ struct Scratch {
     }
 };
 
+// Host-mapped pinned staging for SHORT host-pointer calls: the kernel reads its input from, and
+// writes its output to, pinned host memory directly, which replaces two DMA submissions by two
+// small CPU copies (mixer: 32 -> 18 us per call at 64 samples, 44 -> 31 us at 16384; measured
+// crossover with the DMA route between 512 KiB and 2 MiB per direction).
+struct Pinned {
+    void* h = nullptr;  // host address
+    void* d = nullptr;  // the same memory as the device sees it
+    size_t cap = 0;
+    comms_status_t reserve(size_t bytes) {
+        if (bytes <= cap) return COMMS_OK;
+        release();
+        const size_t want = bytes < 65536 ? 65536 : bytes;
+        COMMS_HIP_TRY(hipHostMalloc(&h, want, hipHostMallocMapped));
+        hipError_t e = hipHostGetDevicePointer(&d, h, 0);
+        if (e != hipSuccess) {
+            (void)hipHostFree(h);
+            h = d = nullptr;
+            return fail(COMMS_ERR_DEVICE, "hipHostGetDevicePointer failed: %s", hipGetErrorString(e));
+        }
+        cap = want;
+        return COMMS_OK;
+    }
+    void release() {
+        if (h) (void)hipHostFree(h);
+        h = d = nullptr;
+        cap = 0;
+    }
+};
+// calls moving at most this many bytes each way take the zero-copy route (COMMS_ZERO_COPY_BYTES)
+size_t zero_copy_limit();
+
 }  // namespace comms
 
 // Pool of hipEvent pairs recorded around a node's dominant kernel (bench/profiling).
@@ -128,6 +159,7 @@ struct Handle {
     int32_t device = 0;
     hipStream_t stream = nullptr;
     Scratch in_scratch, out_scratch;
+    Pinned pin_in, pin_out;
     comms_timer* timer = nullptr;
 
     // bracket the dominant kernel launch; no-ops without an attached timer
@@ -161,9 +193,34 @@ struct Handle {
     hipStream_t pick(void* s) const {
         return s == COMMS_STREAM_HANDLE ? stream : reinterpret_cast<hipStream_t>(s);
     }
+    // The host-pointer form of a node: `launch(d_in, d_out)` runs the device form on this handle's
+    // stream.  Short calls work on host-mapped pinned staging (two CPU copies instead of two DMA
+    // submissions), longer ones go through device scratch.  Synchronous.
+    template <class F>
+    comms_status_t run_host(const void* in, size_t in_bytes, void* out, size_t out_bytes, F&& launch) {
+        if (in_bytes <= zero_copy_limit() && out_bytes <= zero_copy_limit()) {
+            COMMS_TRY(pin_in.reserve(in_bytes));
+            COMMS_TRY(pin_out.reserve(out_bytes));
+            std::memcpy(pin_in.h, in, in_bytes);
+            COMMS_TRY(launch(pin_in.d, pin_out.d));
+            COMMS_HIP_TRY(hipStreamSynchronize(stream));
+            std::memcpy(out, pin_out.h, out_bytes);
+            return COMMS_OK;
+        }
+        COMMS_TRY(in_scratch.reserve(in_bytes));
+        COMMS_TRY(out_scratch.reserve(out_bytes));
+        COMMS_HIP_TRY(hipMemcpyAsync(in_scratch.p, in, in_bytes, hipMemcpyHostToDevice, stream));
+        COMMS_TRY(launch(in_scratch.p, out_scratch.p));
+        COMMS_HIP_TRY(hipMemcpyAsync(out, out_scratch.p, out_bytes, hipMemcpyDeviceToHost, stream));
+        COMMS_HIP_TRY(hipStreamSynchronize(stream));
+        return COMMS_OK;
+    }
+
     void fini() {
         in_scratch.release();
         out_scratch.release();
+        pin_in.release();
+        pin_out.release();
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
     }

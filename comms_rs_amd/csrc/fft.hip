@@ -1172,14 +1172,9 @@ comms_status_t comms_fft_run(comms_fft_t* h, const comms_c32* in, size_t n, comm
               "input length %zu is not a multiple of fft_size %zu (the reference panics)", n, h->N);
     COMMS_ARG(in && out, "NULL host pointer");
     COMMS_TRY(use_device(h->device));
-    COMMS_TRY(h->in_scratch.reserve(n * sizeof(comms_c32)));
-    COMMS_TRY(h->out_scratch.reserve(n * sizeof(comms_c32)));
-    COMMS_HIP_TRY(hipMemcpyAsync(h->in_scratch.p, in, n * sizeof(comms_c32), hipMemcpyHostToDevice, h->stream));
-    COMMS_TRY(comms_fft_run_dev(h, static_cast<comms_c32*>(h->in_scratch.p), n,
-                                static_cast<comms_c32*>(h->out_scratch.p), COMMS_STREAM_HANDLE));
-    COMMS_HIP_TRY(hipMemcpyAsync(out, h->out_scratch.p, n * sizeof(comms_c32), hipMemcpyDeviceToHost, h->stream));
-    COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
-    return COMMS_OK;
+    return h->run_host(in, n * sizeof(comms_c32), out, n * sizeof(comms_c32), [&](void* d_in, void* d_out) {
+        return comms_fft_run_dev(h, static_cast<const comms_c32*>(d_in), n, static_cast<comms_c32*>(d_out), COMMS_STREAM_HANDLE);
+    });
 }
 
 comms_status_t comms_fft_set_timer(comms_fft_t* h, comms_timer_t* t) {

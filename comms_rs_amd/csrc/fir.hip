@@ -1317,14 +1317,9 @@ comms_status_t comms_fir_run(comms_fir_t* h, const comms_c32* in, size_t n, comm
     COMMS_ARG((in && out) || !n, "NULL host pointer");
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
-    COMMS_TRY(h->in_scratch.reserve(n * sizeof(comms_c32)));
-    COMMS_TRY(h->out_scratch.reserve(n * sizeof(comms_c32)));
-    COMMS_HIP_TRY(hipMemcpyAsync(h->in_scratch.p, in, n * sizeof(comms_c32), hipMemcpyHostToDevice, h->stream));
-    COMMS_TRY(comms_fir_run_dev(h, static_cast<comms_c32*>(h->in_scratch.p), n,
-                                static_cast<comms_c32*>(h->out_scratch.p), COMMS_STREAM_HANDLE));
-    COMMS_HIP_TRY(hipMemcpyAsync(out, h->out_scratch.p, n * sizeof(comms_c32), hipMemcpyDeviceToHost, h->stream));
-    COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
-    return COMMS_OK;
+    return h->run_host(in, n * sizeof(comms_c32), out, n * sizeof(comms_c32), [&](void* d_in, void* d_out) {
+        return comms_fir_run_dev(h, static_cast<const comms_c32*>(d_in), n, static_cast<comms_c32*>(d_out), COMMS_STREAM_HANDLE);
+    });
 }
 
 comms_status_t comms_fir_get_state(comms_fir_t* h, comms_c32* state, size_t n_state) {
@@ -1569,15 +1564,9 @@ comms_status_t comms_pulse_run(comms_pulse_t* h, const comms_c32* sym, size_t n_
     COMMS_ARG((sym && out) || !n_sym, "NULL host pointer");
     COMMS_TRY(use_device(h->device));
     if (!n_sym) return COMMS_OK;
-    const size_t n_out = n_sym * h->sps;
-    COMMS_TRY(h->in_scratch.reserve(n_sym * sizeof(comms_c32)));
-    COMMS_TRY(h->out_scratch.reserve(n_out * sizeof(comms_c32)));
-    COMMS_HIP_TRY(hipMemcpyAsync(h->in_scratch.p, sym, n_sym * sizeof(comms_c32), hipMemcpyHostToDevice, h->stream));
-    COMMS_TRY(comms_pulse_run_dev(h, static_cast<comms_c32*>(h->in_scratch.p), n_sym,
-                                  static_cast<comms_c32*>(h->out_scratch.p), COMMS_STREAM_HANDLE));
-    COMMS_HIP_TRY(hipMemcpyAsync(out, h->out_scratch.p, n_out * sizeof(comms_c32), hipMemcpyDeviceToHost, h->stream));
-    COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
-    return COMMS_OK;
+    return h->run_host(sym, n_sym * sizeof(comms_c32), out, n_sym * h->sps * sizeof(comms_c32), [&](void* d_in, void* d_out) {
+        return comms_pulse_run_dev(h, static_cast<const comms_c32*>(d_in), n_sym, static_cast<comms_c32*>(d_out), COMMS_STREAM_HANDLE);
+    });
 }
 
 comms_status_t comms_pulse_destroy(comms_pulse_t* h) {

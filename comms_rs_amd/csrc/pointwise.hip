@@ -217,13 +217,9 @@ comms_status_t comms_mixer_run(comms_mixer_t* h, const comms_c32* in, size_t n, 
     COMMS_ARG((in && out) || !n, "NULL host pointer");
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
-    COMMS_TRY(h->in_scratch.reserve(n * sizeof(comms_c32)));
-    COMMS_HIP_TRY(hipMemcpyAsync(h->in_scratch.p, in, n * sizeof(comms_c32), hipMemcpyHostToDevice, h->stream));
-    comms_c32* d = static_cast<comms_c32*>(h->in_scratch.p);
-    COMMS_TRY(comms_mixer_run_dev(h, d, n, d, COMMS_STREAM_HANDLE));
-    COMMS_HIP_TRY(hipMemcpyAsync(out, d, n * sizeof(comms_c32), hipMemcpyDeviceToHost, h->stream));
-    COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
-    return COMMS_OK;
+    return h->run_host(in, n * sizeof(comms_c32), out, n * sizeof(comms_c32), [&](void* d_in, void* d_out) {
+        return comms_mixer_run_dev(h, static_cast<const comms_c32*>(d_in), n, static_cast<comms_c32*>(d_out), COMMS_STREAM_HANDLE);
+    });
 }
 
 comms_status_t comms_mixer_get_phase(const comms_mixer_t* h, double* out_phase) {
@@ -415,14 +411,9 @@ comms_status_t comms_fmdemod_run(comms_fmdemod_t* h, const comms_c32* in, size_t
     COMMS_ARG((in && out) || !n, "NULL host pointer");
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
-    COMMS_TRY(h->in_scratch.reserve(n * sizeof(comms_c32)));
-    COMMS_TRY(h->out_scratch.reserve(n * sizeof(float)));
-    COMMS_HIP_TRY(hipMemcpyAsync(h->in_scratch.p, in, n * sizeof(comms_c32), hipMemcpyHostToDevice, h->stream));
-    COMMS_TRY(comms_fmdemod_run_dev(h, static_cast<comms_c32*>(h->in_scratch.p), n,
-                                    static_cast<float*>(h->out_scratch.p), COMMS_STREAM_HANDLE));
-    COMMS_HIP_TRY(hipMemcpyAsync(out, h->out_scratch.p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
-    return COMMS_OK;
+    return h->run_host(in, n * sizeof(comms_c32), out, n * sizeof(float), [&](void* d_in, void* d_out) {
+        return comms_fmdemod_run_dev(h, static_cast<const comms_c32*>(d_in), n, static_cast<float*>(d_out), COMMS_STREAM_HANDLE);
+    });
 }
 
 comms_status_t comms_fmdemod_set_timer(comms_fmdemod_t* h, comms_timer_t* t) {

@@ -6,6 +6,15 @@
 
 namespace comms {
 
+size_t zero_copy_limit() {
+    static const size_t lim = [] {
+        const char* v = getenv("COMMS_ZERO_COPY_BYTES");
+        return static_cast<size_t>(v && *v ? atol(v) : (1u << 20));
+    }();
+    return lim;
+}
+
+
 comms_status_t use_device(int32_t device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
