@@ -324,25 +324,25 @@ static comms_status_t resample_host(bool up, const void* in, size_t n, size_t el
     if (out_n) *out_n = n_out;
     COMMS_TRY(use_device(device));
     if (!n_out) return COMMS_OK;
-    void *d_in = nullptr, *d_out = nullptr;
-    COMMS_HIP_TRY(hipMalloc(&d_in, n * elem));
-    hipError_t e = hipMalloc(&d_out, n_out * elem);
-    if (e != hipSuccess) {
-        (void)hipFree(d_in);
-        return fail(COMMS_ERR_DEVICE, "hipMalloc: %s", hipGetErrorString(e));
+    // these two nodes have no handle in the C ABI: a per-thread, per-device one (stream + staging,
+    // created on first use) carries the host path, so a call costs no hipMalloc / hipFree
+    static thread_local Handle* tl[64] = {};
+    COMMS_ARG(device >= 0 && device < 64, "device index out of range");
+    if (!tl[device]) {
+        Handle* nh = new (std::nothrow) Handle;
+        COMMS_ARG(nh != nullptr, "out of host memory");
+        comms_status_t ist = nh->init(device);
+        if (ist != COMMS_OK) {
+            delete nh;
+            return ist;
+        }
+        tl[device] = nh;
     }
-    comms_status_t st = COMMS_OK;
-    e = hipMemcpy(d_in, in, n * elem, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        st = up ? comms_upsample_run_dev(d_in, n, elem, rate, d_out, nullptr, device, nullptr)
-                : comms_decimate_run_dev(d_in, n, elem, rate, d_out, nullptr, device, nullptr);
-        if (st == COMMS_OK) e = hipMemcpy(out, d_out, n_out * elem, hipMemcpyDeviceToHost);
-    }
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
-    if (st != COMMS_OK) return st;
-    if (e != hipSuccess) return fail(COMMS_ERR_DEVICE, "resample copy: %s", hipGetErrorString(e));
-    return COMMS_OK;
+    Handle* h = tl[device];
+    return h->run_host(in, n * elem, out, n_out * elem, [&](void* d_in, void* d_out) {
+        return up ? comms_upsample_run_dev(d_in, n, elem, rate, d_out, nullptr, device, h->stream)
+                  : comms_decimate_run_dev(d_in, n, elem, rate, d_out, nullptr, device, h->stream);
+    });
 }
 
 comms_status_t comms_decimate_run(const void* in, size_t n, size_t elem, size_t rate, void* out,
