@@ -226,6 +226,26 @@ struct Handle {
     }
 };
 
+// Handle-less host-pointer entry points (resampling, IQ formats, estimators) borrow a per-thread,
+// per-device handle (stream + staging), created on first use and kept for the thread's life:
+// no hipMalloc / hipFree -- which also synchronise the device -- per call.
+inline comms_status_t thread_handle(int32_t device, Handle** out) {
+    static thread_local Handle* tl[64] = {};
+    COMMS_ARG(device >= 0 && device < 64, "device index out of range");
+    if (!tl[device]) {
+        Handle* nh = new (std::nothrow) Handle;
+        COMMS_ARG(nh != nullptr, "out of host memory");
+        comms_status_t st = nh->init(device);
+        if (st != COMMS_OK) {
+            delete nh;
+            return st;
+        }
+        tl[device] = nh;
+    }
+    *out = tl[device];
+    return COMMS_OK;
+}
+
 inline bool ranges_overlap(const void* a, size_t na, const void* b, size_t nb) {
     const char* pa = static_cast<const char*>(a);
     const char* pb = static_cast<const char*>(b);

@@ -120,18 +120,21 @@ static comms_status_t estimate(int kind, const double* d_x, size_t n, unsigned m
 static comms_status_t estimate_host(int kind, const double* x, size_t n, unsigned m, double* out, int32_t device) {
     COMMS_ARG(out != nullptr && (x || !n), "NULL argument");
     COMMS_TRY(use_device(device));
-    double* d = nullptr;
-    if (n) {
-        COMMS_HIP_TRY(hipMalloc(&d, n * 16));
-        hipError_t e = hipMemcpy(d, x, n * 16, hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            (void)hipFree(d);
-            return fail(COMMS_ERR_DEVICE, "estimator upload: %s", hipGetErrorString(e));
-        }
+    Handle* h = nullptr;
+    COMMS_TRY(thread_handle(device, &h));
+    if (!n) return estimate(kind, nullptr, 0, m, out, device, h->stream);
+    // input only: short blocks are read straight from pinned host memory, long ones uploaded
+    const void* d = nullptr;
+    if (n * 16 <= zero_copy_limit()) {
+        COMMS_TRY(h->pin_in.reserve(n * 16));
+        std::memcpy(h->pin_in.h, x, n * 16);
+        d = h->pin_in.d;
+    } else {
+        COMMS_TRY(h->in_scratch.reserve(n * 16));
+        COMMS_HIP_TRY(hipMemcpyAsync(h->in_scratch.p, x, n * 16, hipMemcpyHostToDevice, h->stream));
+        d = h->in_scratch.p;
     }
-    comms_status_t st = estimate(kind, d, n, m, out, device, nullptr);
-    if (d) (void)hipFree(d);
-    return st;
+    return estimate(kind, static_cast<const double*>(d), n, m, out, device, h->stream);
 }
 
 }  // namespace comms

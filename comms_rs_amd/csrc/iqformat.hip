@@ -49,23 +49,13 @@ static unsigned conv_grid(size_t n) {
     return static_cast<unsigned>(b ? b : 1);
 }
 
+// run(d_in, d_out, stream): the device form on the borrowed handle's stream
 template <typename F>
 static comms_status_t via_device(const void* in, size_t in_bytes, void* out, size_t out_bytes, int32_t device, F run) {
     COMMS_TRY(use_device(device));
-    void *d_in = nullptr, *d_out = nullptr;
-    COMMS_HIP_TRY(hipMalloc(&d_in, in_bytes));
-    hipError_t e = hipMalloc(&d_out, out_bytes);
-    comms_status_t st = COMMS_OK;
-    if (e == hipSuccess) e = hipMemcpy(d_in, in, in_bytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        st = run(d_in, d_out);
-        if (st == COMMS_OK) e = hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost);
-    }
-    (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
-    if (st != COMMS_OK) return st;
-    if (e != hipSuccess) return fail(COMMS_ERR_DEVICE, "IQ conversion copy: %s", hipGetErrorString(e));
-    return COMMS_OK;
+    Handle* h = nullptr;
+    COMMS_TRY(thread_handle(device, &h));
+    return h->run_host(in, in_bytes, out, out_bytes, [&](void* d_in, void* d_out) { return run(d_in, d_out, h->stream); });
 }
 
 }  // namespace comms
@@ -110,22 +100,22 @@ comms_status_t comms_iq_u8_to_c32_dev(const uint8_t* d_in, size_t n, comms_c32* 
 comms_status_t comms_iq_i16_to_c32(const int16_t* in, size_t n, float scale, comms_c32* out, int32_t device) {
     COMMS_ARG((in && out) || !n, "NULL host pointer");
     if (!n) return use_device(device);
-    return via_device(in, n * 4, out, n * 8, device, [&](void* a, void* b) {
-        return comms_iq_i16_to_c32_dev(static_cast<const int16_t*>(a), n, scale, static_cast<comms_c32*>(b), device, nullptr);
+    return via_device(in, n * 4, out, n * 8, device, [&](void* a, void* b, void* st) {
+        return comms_iq_i16_to_c32_dev(static_cast<const int16_t*>(a), n, scale, static_cast<comms_c32*>(b), device, st);
     });
 }
 comms_status_t comms_iq_c32_to_i16(const comms_c32* in, size_t n, float scale, int16_t* out, int32_t device) {
     COMMS_ARG((in && out) || !n, "NULL host pointer");
     if (!n) return use_device(device);
-    return via_device(in, n * 8, out, n * 4, device, [&](void* a, void* b) {
-        return comms_iq_c32_to_i16_dev(static_cast<const comms_c32*>(a), n, scale, static_cast<int16_t*>(b), device, nullptr);
+    return via_device(in, n * 8, out, n * 4, device, [&](void* a, void* b, void* st) {
+        return comms_iq_c32_to_i16_dev(static_cast<const comms_c32*>(a), n, scale, static_cast<int16_t*>(b), device, st);
     });
 }
 comms_status_t comms_iq_u8_to_c32(const uint8_t* in, size_t n, comms_c32* out, int32_t device) {
     COMMS_ARG((in && out) || !n, "NULL host pointer");
     if (!n) return use_device(device);
-    return via_device(in, n * 2, out, n * 8, device, [&](void* a, void* b) {
-        return comms_iq_u8_to_c32_dev(static_cast<const uint8_t*>(a), n, static_cast<comms_c32*>(b), device, nullptr);
+    return via_device(in, n * 2, out, n * 8, device, [&](void* a, void* b, void* st) {
+        return comms_iq_u8_to_c32_dev(static_cast<const uint8_t*>(a), n, static_cast<comms_c32*>(b), device, st);
     });
 }
 

@@ -324,21 +324,8 @@ static comms_status_t resample_host(bool up, const void* in, size_t n, size_t el
     if (out_n) *out_n = n_out;
     COMMS_TRY(use_device(device));
     if (!n_out) return COMMS_OK;
-    // these two nodes have no handle in the C ABI: a per-thread, per-device one (stream + staging,
-    // created on first use) carries the host path, so a call costs no hipMalloc / hipFree
-    static thread_local Handle* tl[64] = {};
-    COMMS_ARG(device >= 0 && device < 64, "device index out of range");
-    if (!tl[device]) {
-        Handle* nh = new (std::nothrow) Handle;
-        COMMS_ARG(nh != nullptr, "out of host memory");
-        comms_status_t ist = nh->init(device);
-        if (ist != COMMS_OK) {
-            delete nh;
-            return ist;
-        }
-        tl[device] = nh;
-    }
-    Handle* h = tl[device];
+    Handle* h = nullptr;  // these two nodes have no handle in the C ABI
+    COMMS_TRY(thread_handle(device, &h));
     return h->run_host(in, n * elem, out, n_out * elem, [&](void* d_in, void* d_out) {
         return up ? comms_upsample_run_dev(d_in, n, elem, rate, d_out, nullptr, device, h->stream)
                   : comms_decimate_run_dev(d_in, n, elem, rate, d_out, nullptr, device, h->stream);
