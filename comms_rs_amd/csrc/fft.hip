@@ -391,6 +391,80 @@ struct RxGeom {
     static constexpr size_t LDS = (1024 + 64 + R * 16 + R * 64 + 16 * BUF) * sizeof(float2);
 };
 
+// The wave-level part shared by the row kernel (fft_rx1024_kernel) and the column kernel
+// (fft_cols_kernel): the wave's 1024-point buffer holds one 1024-point transform (exchange
+// layout of fft1024x16_kernel), 16 blocks of 64 points (C64: the same without the first radix-16
+// stage; block a at a*66) or 4 transforms of 256 points (C256: at t*272); spectra are left in
+// place in natural order (k + (k >> 4); a + 17 f; t*272 + f).
+template <int DIR, bool C64, bool C256>
+__device__ __forceinline__ void rx_wave_core(cf* buf, const cf* tw1, const cf* tw2, int l, int q0, int q1) {
+    cf v[16];
+    if constexpr (C256) {
+        // this wave's row: four 256-point transforms, lane (t, b) = (q1, q0)
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = buf[q1 * F256_T + 16 * a + q0];
+        fw_wave_sync();
+        radix16<DIR>(v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {  // -> exchange row (t, ka), column b; 18-element rows
+            cf x = v[R16_POS(k)];
+            if (k) x = tw_mul<DIR>(x, tw1[k * 16 + q0]);
+            buf[(q1 * 16 + k) * 18 + q0] = x;
+        }
+        fw_wave_sync();
+        {  // lane (t, ka): its 16 consecutive b values
+            const cf2v* r = reinterpret_cast<const cf2v*>(buf + l * 18);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const cf2v x = r[j];
+                v[2 * j] = cf{x.x, x.y};
+                v[2 * j + 1] = cf{x.z, x.w};
+            }
+        }
+        fw_wave_sync();
+        radix16<DIR>(v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) buf[q1 * F256_T + q0 + 16 * k] = v[R16_POS(k)];  // f = ka + 16 kb
+    }
+    if constexpr (!C64 && !C256) {
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = buf[64 * a + l];
+        fw_wave_sync();
+        radix16<DIR>(v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            cf x = v[R16_POS(k)];
+            if (k) x = tw_mul<DIR>(x, tw1[k * 64 + l]);
+            buf[k * FW_S1 + l] = x;
+        }
+        fw_wave_sync();
+    }
+    if constexpr (!C256) {
+#pragma unroll
+    for (int bb = 0; bb < 16; ++bb) v[bb] = buf[q0 * FW_S1 + 4 * bb + q1];
+    fw_wave_sync();
+    radix16<DIR>(v);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        cf x = v[R16_POS(k)];
+        if (k) x = tw_mul<DIR>(x, tw2[k * 4 + q1]);
+        buf[q1 * FW_P + 17 * q0 + k] = x;
+    }
+    fw_wave_sync();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[4 * j + c] = buf[c * FW_P + 17 * (q1 + 4 * j) + q0];
+    fw_wave_sync();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        radix4<DIR>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) buf[q1 + 4 * j + 17 * q0 + 272 * k2] = v[4 * j + k2];
+    }
+    }
+}
+
 template <int DIR, int RAD>
 __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* out, size_t n_tiles,
                                                              const cf* __restrict__ tw1g, const cf* __restrict__ tw2g,
@@ -477,72 +551,8 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
         }
         __syncthreads();
         if (tix + gridDim.x < n_tiles) fetch(tix + gridDim.x);
-        // ---- this wave's 1024-point transform, in its own buffer (as fft1024x16_kernel)
-        cf v[16];
-        if constexpr (C256) {
-            // this wave's row: four 256-point transforms, lane (t, b) = (q1, q0)
-#pragma unroll
-            for (int a = 0; a < 16; ++a) v[a] = buf[q1 * F256_T + 16 * a + q0];
-            fw_wave_sync();
-            radix16<DIR>(v);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {  // -> exchange row (t, ka), column b; 18-element rows
-                cf x = v[R16_POS(k)];
-                if (k) x = tw_mul<DIR>(x, tw1[k * 16 + q0]);
-                buf[(q1 * 16 + k) * 18 + q0] = x;
-            }
-            fw_wave_sync();
-            {  // lane (t, ka): its 16 consecutive b values
-                const cf2v* r = reinterpret_cast<const cf2v*>(buf + l * 18);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const cf2v x = r[j];
-                    v[2 * j] = cf{x.x, x.y};
-                    v[2 * j + 1] = cf{x.z, x.w};
-                }
-            }
-            fw_wave_sync();
-            radix16<DIR>(v);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) buf[q1 * F256_T + q0 + 16 * k] = v[R16_POS(k)];  // f = ka + 16 kb
-        }
-        if constexpr (C1024) {
-#pragma unroll
-            for (int a = 0; a < 16; ++a) v[a] = buf[64 * a + l];
-            fw_wave_sync();
-            radix16<DIR>(v);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                cf x = v[R16_POS(k)];
-                if (k) x = tw_mul<DIR>(x, tw1[k * 64 + l]);
-                buf[k * FW_S1 + l] = x;
-            }
-            fw_wave_sync();
-        }
-        if constexpr (!C256) {
-#pragma unroll
-        for (int bb = 0; bb < 16; ++bb) v[bb] = buf[q0 * FW_S1 + 4 * bb + q1];
-        fw_wave_sync();
-        radix16<DIR>(v);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            cf x = v[R16_POS(k)];
-            if (k) x = tw_mul<DIR>(x, tw2[k * 4 + q1]);
-            buf[q1 * FW_P + 17 * q0 + k] = x;
-        }
-        fw_wave_sync();
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[4 * j + c] = buf[c * FW_P + 17 * (q1 + 4 * j) + q0];
-        fw_wave_sync();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            radix4<DIR>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-#pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) buf[q1 + 4 * j + 17 * q0 + 272 * k2] = v[4 * j + k2];
-        }
-        }
+        // ---- this wave's 1024 points: one 1024-point transform, 16 of 64 points or 4 of 256 points
+        rx_wave_core<DIR, C64, C256>(buf, tw1, tw2, l, q0, q1);
         __syncthreads();
         // ---- store: tile element i = j*N + RAD*k2 + k1 is output i
         cf* dst = out + tix * (16u * 1024u);
@@ -563,6 +573,106 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
                 const unsigned k1 = i % R, k2 = (i / R) & 1023u, j = i / N;
                 dst[i] = bufs[(j * R + k1) * BUF + k2 + (k2 >> 4)];
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- four-step pass 1 for N = N1 * 1024, N1 = 64 ... 512
+// Column transforms of length N1 (stride 1024) for all 1024 columns, times W_N^{n2*k1}, in place
+// positions.  A 16-wave workgroup owns all N1 rows of C = 16384/N1 adjacent columns (runs of
+// 256 B ... 2 KiB in HBM); each column lands in a slot of a wave's 1024-point buffer so that the
+// waves can run the same 64- / 256-point forms as the row kernel (128 and 512 through the radix-2
+// front stage: both halves of a column are in the same lane, 8 loads apart), and the spectra go
+// back through the transposed mapping with the four-step twiddle applied on the way.
+template <int KIND>
+struct ColGeom {
+    static constexpr bool C64 = KIND == 0 || KIND == 128, C256 = !C64, PRE2 = KIND == 128 || KIND == 512;
+    static constexpr int N1 = KIND == 0 ? 64 : KIND;
+    static constexpr int C = 16384 / N1;    // columns per tile
+    static constexpr int TPW = 1024 / N1;   // columns per wave buffer
+    static constexpr int BUF = C256 ? 1160 : 1120;
+    static constexpr int SLOT = C64 ? FW_S1 : F256_T;
+    static constexpr size_t LDS = (1024 + 64 + 256 + 16 * BUF) * sizeof(float2);
+};
+
+template <int DIR, int KIND>
+__global__ __launch_bounds__(1024, 4) void fft_cols_kernel(const cf* in, cf* out, size_t n_tiles, unsigned N,
+                                                           const cf* __restrict__ tw1g, const cf* __restrict__ tw2g,
+                                                           const cf* __restrict__ twrg, const cf* __restrict__ tw_lo,
+                                                           const cf* __restrict__ tw_hi) {
+    using G = ColGeom<KIND>;
+    constexpr int C = G::C, TPW = G::TPW, BUF = G::BUF, SLOT = G::SLOT, N1 = G::N1;
+    constexpr bool C64 = G::C64, C256 = G::C256, PRE2 = G::PRE2;
+    constexpr unsigned TPX = 1024 / C;  // tiles per transform
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* tw1 = reinterpret_cast<cf*>(smem);  // the core's stage table (W256^{b*ka} for the 256-point form)
+    cf* tw2 = tw1 + 1024;                   // [16][4] W64^{c*k1}
+    cf* twr = tw2 + 64;                     // W_N1^{r}, r < N1/2 (radix-2 front stage)
+    cf* bufs = twr + 256;                   // [16][BUF]
+    const int tid = threadIdx.x;
+    const int l = tid & 63, wave = tid >> 6;
+    const int q0 = l & 15, q1 = l >> 4;
+    cf* buf = bufs + wave * BUF;
+    tw1[tid] = tw1g[tid];
+    if (tid < 64) tw2[tid] = tw2g[tid];
+    if (PRE2 && tid < N1 / 2) twr[tid] = twrg[tid];
+
+    auto base_of = [&](size_t tix) { return (tix / TPX) * static_cast<size_t>(N) + (tix % TPX) * C; };
+    cf pre[16];
+    auto fetch = [&](size_t tix) {
+        const cf* src = in + base_of(tix);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const unsigned e = static_cast<unsigned>(tid) + 1024u * u;
+            pre[u] = src[(e / C) * 1024u + (e % C)];
+        }
+    };
+    if (blockIdx.x < n_tiles) fetch(blockIdx.x);
+
+    for (size_t tix = blockIdx.x; tix < n_tiles; tix += gridDim.x) {
+        __syncthreads();  // previous tile fully stored (and the tables are in place)
+        if constexpr (PRE2) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {  // rows r and r + N1/2 of column c: pre[u], pre[u + 8]
+                const unsigned e = static_cast<unsigned>(tid) + 1024u * u;
+                const unsigned r = e / C, c = e % C;
+                cf y0 = pre[u], y1 = pre[u + 8];
+                radix2<DIR>(y0, y1);
+                y1 = tw_mul<DIR>(y1, twr[r]);
+                cf* row = bufs + (c / TPW) * BUF + (2 * (c % TPW)) * SLOT + r;
+                row[0] = y0;
+                row[SLOT] = y1;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const unsigned e = static_cast<unsigned>(tid) + 1024u * u;
+                const unsigned r = e / C, c = e % C;
+                bufs[(c / TPW) * BUF + (c % TPW) * SLOT + r] = pre[u];
+            }
+        }
+        __syncthreads();
+        if (tix + gridDim.x < n_tiles) fetch(tix + gridDim.x);
+        rx_wave_core<DIR, C64, C256>(buf, tw1, tw2, l, q0, q1);
+        __syncthreads();
+        // ---- store transposed back, times W_N^{n2*k1}
+        cf* dst = out + base_of(tix);
+        const unsigned col0 = static_cast<unsigned>(tix % TPX) * C;
+#pragma unroll 8
+        for (int u = 0; u < 16; ++u) {
+            const unsigned e = static_cast<unsigned>(tid) + 1024u * u;
+            const unsigned k1 = e / C, c = e % C, wb = c / TPW, t = c % TPW;
+            unsigned pos;
+            if constexpr (PRE2) {
+                const unsigned kk = k1 & 1u, k2 = k1 >> 1;
+                pos = C64 ? (2 * t + kk) + 17 * k2 : (2 * t + kk) * SLOT + k2;
+            } else {
+                pos = C64 ? t + 17 * k1 : t * SLOT + k1;
+            }
+            cf x = bufs[wb * BUF + pos];
+            const unsigned ee = (col0 + c) * k1;  // < 2^19
+            x = tw_apply<DIR>(x, g_mul(tw_hi[ee >> 12], tw_lo[ee & 4095]));
+            dst[k1 * 1024u + c] = x;
         }
     }
 }
@@ -651,6 +761,9 @@ struct Pow2Plan {
     int rx_rad = 0;           // N = rx_rad * 1024 (2, 4, 8, 16): single-pass fft_rx1024_kernel
     float2* d_rxa = nullptr;  //   W_N^{64*wave*k1} [rad][16]
     float2* d_rxb = nullptr;  //   W_N^{lane*k1}    [rad][64]
+    int col_kind = -1;         // four-step pass 1 on fft_cols_kernel: 0 (N1 = 64), 128, 256, 512; -1: tile kernel
+    float2* d_colw1 = nullptr; //   the core's stage table (W256^{b*ka} for the 256-point form, else unused)
+    float2* d_colr = nullptr;  //   W_N1^{r}, r < N1/2 (radix-2 front stage of 128 / 512)
     int threads[2] = {0, 0};
     size_t lds[2] = {0, 0};
 
@@ -664,7 +777,9 @@ struct Pow2Plan {
         if (d_fw2) (void)hipFree(d_fw2);
         if (d_rxa) (void)hipFree(d_rxa);
         if (d_rxb) (void)hipFree(d_rxb);
-        d_fw1 = d_fw2 = d_rxa = d_rxb = nullptr;
+        if (d_colw1) (void)hipFree(d_colw1);
+        if (d_colr) (void)hipFree(d_colr);
+        d_fw1 = d_fw2 = d_rxa = d_rxb = d_colw1 = d_colr = nullptr;
     }
     bool fast(int i) const { return pass[i].L == 1024 && (pass[i].C == 16 || pass[i].C == 8) && d_fw1 != nullptr; }
 };
@@ -836,6 +951,25 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
             COMMS_HIP_TRY(hipMemcpy(pl.d_fw1, t1.data(), t1.size() * sizeof(float2), hipMemcpyHostToDevice));
         }
     }
+    if (pl.n_pass == 2 && pl.pass[1].L == 1024 && pl.d_fw1 &&
+        (pl.pass[0].L == 64 || pl.pass[0].L == 128 || pl.pass[0].L == 256 || pl.pass[0].L == 512)) {
+        const int n1 = pl.pass[0].L;
+        std::vector<float2> t1(1024, make_float2(1.f, 0.f)), tr(256, make_float2(1.f, 0.f));
+        for (int k = 0; k < 16; ++k)
+            for (int bq = 0; bq < 16; ++bq) {
+                const double a = -2.0 * kPiF * static_cast<double>((bq * k) % 256) / 256.0;
+                t1[k * 16 + bq] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
+            }
+        for (int r = 0; r < n1 / 2; ++r) {
+            const double a = -2.0 * kPiF * static_cast<double>(r) / static_cast<double>(n1);
+            tr[r] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
+        }
+        COMMS_HIP_TRY(hipMalloc(&pl.d_colw1, t1.size() * sizeof(float2)));
+        COMMS_HIP_TRY(hipMalloc(&pl.d_colr, tr.size() * sizeof(float2)));
+        COMMS_HIP_TRY(hipMemcpy(pl.d_colw1, t1.data(), t1.size() * sizeof(float2), hipMemcpyHostToDevice));
+        COMMS_HIP_TRY(hipMemcpy(pl.d_colr, tr.data(), tr.size() * sizeof(float2), hipMemcpyHostToDevice));
+        pl.col_kind = n1 == 64 ? 0 : n1;
+    }
     // tiles above 64 KiB need the dynamic-LDS limit raised (160 KiB per CU on gfx950)
     COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_tile_kernel<1>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -897,6 +1031,32 @@ static comms_status_t launch_rx(Pow2Plan& pl, const float2* src, float2* dst, si
     else
         fft_rx1024_kernel<-1, RAD><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, n_tiles, t1, t2, ta, tb);
     return launch_ok("fft_rx1024_kernel");
+}
+
+template <int KIND>
+static comms_status_t launch_cols(Pow2Plan& pl, const float2* src, float2* dst, size_t batch, bool inverse,
+                                  hipStream_t s) {
+    constexpr size_t lds = ColGeom<KIND>::LDS;
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_cols_kernel<1, KIND>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_cols_kernel<-1, KIND>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    }
+    const size_t n_tiles = batch * (1024 / ColGeom<KIND>::C);
+    const unsigned blocks = static_cast<unsigned>(n_tiles < static_cast<size_t>(kNumCU) ? n_tiles : kNumCU);
+    const cf* a = reinterpret_cast<const cf*>(src);
+    cf* d = reinterpret_cast<cf*>(dst);
+    const cf* t1 = reinterpret_cast<const cf*>(pl.d_colw1);
+    const cf* t2 = reinterpret_cast<const cf*>(pl.d_fw2);
+    const cf* tr = reinterpret_cast<const cf*>(pl.d_colr);
+    const FftTileParams& p = pl.pass[0];
+    if (inverse)
+        fft_cols_kernel<1, KIND><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, n_tiles, static_cast<unsigned>(pl.N), t1, t2, tr, p.tw_lo, p.tw_hi);
+    else
+        fft_cols_kernel<-1, KIND><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, n_tiles, static_cast<unsigned>(pl.N), t1, t2, tr, p.tw_lo, p.tw_hi);
+    return launch_ok("fft_cols_kernel");
 }
 
 static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size_t batch,
@@ -972,6 +1132,19 @@ static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size
                 src = scratch;
             }
             p.n_tiles = batch * p.tiles_per_xform;
+            static const bool no_cols = [] {
+                const char* v = getenv("COMMS_FFT_NO_COLS");
+                return v && *v && *v != '0';
+            }();
+            if (i == 0 && pl.col_kind >= 0 && !no_cols) {
+                switch (pl.col_kind) {
+                    case 0: COMMS_TRY(launch_cols<0>(pl, src, dst, batch, inverse, s)); break;
+                    case 128: COMMS_TRY(launch_cols<128>(pl, src, dst, batch, inverse, s)); break;
+                    case 256: COMMS_TRY(launch_cols<256>(pl, src, dst, batch, inverse, s)); break;
+                    default: COMMS_TRY(launch_cols<512>(pl, src, dst, batch, inverse, s)); break;
+                }
+                continue;
+            }
             if (pl.fast(i)) {
                 COMMS_TRY(launch_fast(pl, src, dst, p, inverse, s));
                 continue;

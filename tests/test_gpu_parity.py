@@ -516,6 +516,19 @@ def test_fft_single_pass_radix_times_1024(c, n, inverse):
             fft_close(t.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("logn", [15, 16, 17, 18, 19])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_fft_four_step_column_pass(c, logn, inverse):
+    """N = N1 x 1024, N1 = 32 ... 512: pass 1 is the column kernel (fft_cols_kernel; the tile kernel at
+    N1 = 32), pass 2 the 1024-point rows with the transposed store."""
+    n = 1 << logn
+    rng = np.random.default_rng(logn + 100 * inverse)
+    batch = 5 if logn < 18 else 3
+    x = rand_c(rng, n * batch)
+    f = (lambda v: np.fft.ifft(v, axis=1) * n) if inverse else (lambda v: np.fft.fft(v, axis=1))
+    fft_close(c.FFTBatchNode(n, inverse).run(x), f(x.astype(np.complex128).reshape(batch, n)).reshape(-1))
+
+
 def test_fft_config4_size_roundtrip(c):
     # BASELINE config 4 length (2^20), small batch: forward vs oracle, then inverse / N == input
     import torch
