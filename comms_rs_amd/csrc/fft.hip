@@ -5,20 +5,18 @@
 // in f64).  Here the transform runs in f32 with twiddles generated in f64 on
 // the host and rounded once.
 //
-// One tile kernel does all power-of-two work.  A workgroup owns a tile of C
-// sub-transforms of length L (C*L <= 16384 points = 128 KiB of LDS), runs
-// radix-4 Stockham passes (radix-2 last when log2 L is odd) in place in LDS
-// -- every lane pulls its 16 points into VGPRs, barrier, butterflies,
-// writes back -- and moves the tile to/from HBM with the contiguous index on
-// the lanes:
-//   * N <= 4096 ............ rows mode: C whole transforms per workgroup;
-//   * N  > 4096 (four-step, N = N1*N2):
-//       pass 1: 16 adjacent columns (128-B row pieces) x N1, FFT over n1,
-//               multiply by W_N^{n2*k1}, store in place;
-//       pass 2: 16 rows x N2, FFT over n2, store transposed (128-B pieces) so
-//               the result is in natural order.
-// Other lengths: exact-index O(N^2) DFT with f64 accumulation (N <= 64) or
-// Bluestein's chirp-z on the power-of-two path (N > 4096).
+// Kernels, by length N:
+//   * 64 ... 16384 (powers of two): fft_rx1024_kernel, ONE pass.  A 16-wave workgroup owns 16 rows
+//     of 1024 points; every wave runs a barrier-free radix-16 register transform on its row
+//     (1024 points, 16 x 64 or 4 x 256), 2048 ... 16384 add a radix-RAD butterfly over the rows on
+//     the way into LDS, 128 / 512 a radix-2 one; loads are one tile ahead, stores fully coalesced.
+//   * 2^16 ... 2^20 (four-step, N = N1 * 1024): pass 1 = fft_cols_kernel (N1 = 64 ... 512: the same
+//     wave forms on columns, x W_N^{n2*k1}) or fft1024x16_kernel (N1 = 1024, config 4);
+//     pass 2 = fft1024x16_kernel on the rows with the transposed store.
+//   * 2 ... 32, 2^15 and > 2^20: fft_tile_kernel -- radix-4 Stockham passes in LDS on tiles of
+//     C sub-transforms of length L (C*L <= 16384 points), one pass or four-step.
+//   * other lengths: exact-index O(N^2) DFT with f64 accumulation (N <= 64) or Bluestein's
+//     chirp-z on the power-of-two kernels (N > 64).
 #include <cmath>
 #include <cstdlib>
 #include <vector>
