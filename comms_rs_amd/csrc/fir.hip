@@ -3,20 +3,18 @@
 // Replaces fir()/batch_fir() (reference src/filter/fir.rs:43-54, :87-102):
 //     y[n] = sum_{k<N} taps[k] * x[n-k],   history persists across calls.
 //
-// Two kernels behind one handle:
-//   * fir_direct_kernel   time-domain.  256 threads x 8 consecutive outputs;
-//                         input tile + taps staged in LDS, a 16-sample sliding
-//                         window per lane in VGPRs, explicit FMAs.  Bound by
-//                         vector FP32 (8N flop/sample for complex taps, 4N for
-//                         real taps) -- used for short filters and short calls.
-//   * fir_os4096_kernel   overlap-save.  One 4096-point segment per workgroup
-//                         pass: three radix-16 stages in registers (16 points
-//                         per lane), two LDS exchanges per transform, spectrum
-//                         multiply in registers, inverse transform, store of the
-//                         valid 4096-H outputs.  Twiddles and the filter
-//                         spectrum live in VGPRs for the life of the persistent
-//                         workgroup.  ~135 flop/sample at 255 taps, so the
-//                         kernel is HBM-bound: 8 B read + 8 B write per sample.
+// Kernels behind one handle (fir_pick chooses from a measured cost model):
+//   * fir_direct_kernel   time domain: 256 lanes x 8 consecutive outputs, input tile + taps in LDS,
+//                         a sliding window per lane in VGPRs, packed FMAs.  Very short filters and
+//                         radio-sized batches of short ones (launch-bound there: ~8 us).
+//   * fir_os1024_kernel   overlap-save, one WAVE per 1024-point segment, barrier-free (<= 257 taps;
+//                         two-row halo up to 129 taps).  The headline kernel; MODE != 0 fuses the
+//                         mixer / decimator / FM demod of comms_chain_* into the same launch.
+//   * fir_os4096_kernel   overlap-save, one workgroup per 4096-point segment (258 ... 2049 taps).
+//   * fir_os16k_kernel    overlap-save, 16384 = 16 x 1024 per 16-wave workgroup (2050 ... 4097 taps,
+//                         config 5; longer filters as 4097-tap partitions).
+//   * pulse_poly_kernel   polyphase pulse shaper (taps in SGPR pairs); pulse_kernel as fallback.
+// (fir_decim.hip holds the time-domain decimating chain kernel.)
 //
 // HBM layout: input/output are plain contiguous float2 streams.  The handle
 // keeps the last N input samples in a small device ring (two buffers,
