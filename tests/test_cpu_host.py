@@ -182,3 +182,12 @@ def test_rust_shim_declares_every_header_symbol():
 
     assert subprocess.call([sys.executable, os.path.join(ROOT, "scripts", "gen_rust_ffi.py"), "--check"]) == 0, \
         "comms_rs_amd/rust_shim/src/ffi.rs is stale: run scripts/gen_rust_ffi.py"
+
+
+def test_header_is_plain_c():
+    """include/comms_hip.h is the drop-in boundary: it must compile as C99 (and C++17) on its own."""
+    import subprocess
+
+    hdr = os.path.join(ROOT, "include", "comms_hip.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
