@@ -731,7 +731,7 @@ def test_time_domain_decimating_chain_kernel(c, rate):
 def test_chain_kernels_agree_on_random_configurations(c):
     """Seeded sweep: the time-domain decimating kernel, the overlap-save fusion and the four
     kernels in series on random (taps, rate, mixer position, FM, phases, lengths, batch cuts)."""
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(2024 + 1000 * int(__import__("os").environ.get("COMMS_TEST_SEED_OFFSET", "0")))
     rates = [2, 3, 4, 5, 6, 8, 10, 12, 16]
     for case in range(48):
         rate = int(rng.choice(rates))

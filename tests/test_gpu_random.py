@@ -10,6 +10,9 @@ from test_gpu_parity import TOL, circ, fft_close, fir_close, lowpass_taps, rand_
 
 pytestmark = pytest.mark.gpu
 
+# COMMS_TEST_SEED_OFFSET=k re-runs the sweeps on other draws (the committed default, 0, is what CI runs)
+SEED_OFFSET = int(__import__("os").environ.get("COMMS_TEST_SEED_OFFSET", "0"))
+
 
 @pytest.fixture(scope="module")
 def c():
@@ -25,7 +28,7 @@ def cuts_of(rng, n, k=2, multiple=1):
 
 
 def test_fir_random_sweep(c):
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(11 + 1000 * SEED_OFFSET)
     algos = [c.FIR_AUTO, c.FIR_DIRECT, c.FIR_OS1024, c.FIR_OS4096, c.FIR_OS16K]
     for case in range(40):
         algo = algos[case % len(algos)]
@@ -51,7 +54,7 @@ def test_fir_random_sweep(c):
 
 
 def test_mixer_decimate_upsample_fm_random_sweep(c):
-    rng = np.random.default_rng(12)
+    rng = np.random.default_rng(12 + 1000 * SEED_OFFSET)
     for case in range(30):
         n = int(rng.integers(1, 50000))
         x = rand_c(rng, n)
@@ -75,7 +78,7 @@ def test_mixer_decimate_upsample_fm_random_sweep(c):
 
 
 def test_fft_random_sweep(c):
-    rng = np.random.default_rng(13)
+    rng = np.random.default_rng(13 + 1000 * SEED_OFFSET)
     sizes = [2 ** k for k in range(1, 18)] + [3, 6, 10, 12, 15, 60, 100, 360, 1000, 1536, 3000, 4097, 6000, 10000]
     for case in range(40):
         n = int(sizes[int(rng.integers(0, len(sizes)))])
@@ -91,7 +94,7 @@ def test_fft_random_sweep(c):
 
 
 def test_pulse_random_sweep(c):
-    rng = np.random.default_rng(14)
+    rng = np.random.default_rng(14 + 1000 * SEED_OFFSET)
     for case in range(30):
         sps = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 10, 16, 20]))
         n_taps = int(rng.integers(1, 400))
