@@ -6,15 +6,16 @@
 // the host and rounded once.
 //
 // Kernels, by length N:
-//   * 64 ... 16384 (powers of two): fft_rx1024_kernel, ONE pass.  A 16-wave workgroup owns 16 rows
+//   * 2 ... 16384 (powers of two): fft_rx1024_kernel, ONE pass.  A 16-wave workgroup owns 16 rows
 //     of 1024 points; every wave runs a barrier-free radix-16 register transform on its row
-//     (1024 points, 16 x 64 or 4 x 256), 2048 ... 16384 add a radix-RAD butterfly over the rows on
-//     the way into LDS, 128 / 512 a radix-2 one; loads are one tile ahead, stores fully coalesced.
-//   * 2^16 ... 2^20 (four-step, N = N1 * 1024): pass 1 = fft_cols_kernel (N1 = 64 ... 512: the same
+//     (1024 points, 16 x 64, 4 x 256, or 16 consecutive points per lane for 2 ... 16), 2048 ... 16384
+//     add a radix-RAD butterfly over the rows on the way into LDS, 32 / 128 / 512 a radix-2 one;
+//     loads are one tile ahead, stores fully coalesced.
+//   * 2^15 ... 2^20 (four-step, N = N1 * 1024): pass 1 = fft_cols_kernel (N1 = 32 ... 512: the same
 //     wave forms on columns, x W_N^{n2*k1}) or fft1024x16_kernel (N1 = 1024, config 4);
 //     pass 2 = fft1024x16_kernel on the rows with the transposed store.
-//   * 2 ... 32, 2^15 and > 2^20: fft_tile_kernel -- radix-4 Stockham passes in LDS on tiles of
-//     C sub-transforms of length L (C*L <= 16384 points), one pass or four-step.
+//   * > 2^20, and the ragged tail of a batch: fft_tile_kernel -- radix-4 Stockham passes in LDS on
+//     tiles of C sub-transforms of length L (C*L <= 16384 points), one pass or four-step.
 //   * other lengths: exact-index O(N^2) DFT with f64 accumulation (N <= 64) or Bluestein's
 //     chirp-z on the power-of-two kernels (N > 64).
 #include <cmath>
@@ -383,9 +384,14 @@ typedef float cf2v __attribute__((ext_vector_type(4)));  // two packed complex v
 constexpr int F256_T = 272;  // 256 + 16: the four transforms of a row start 32 banks apart
 template <int RAD>
 struct RxGeom {
-    static constexpr bool C64 = RAD == 0 || RAD == 128, C256 = RAD == 256 || RAD == 512, PRE2 = RAD == 128 || RAD == 512;
-    static constexpr int R = (C64 || C256) ? 1 : RAD;
-    static constexpr int BUF = C256 ? 1160 : 1088 + 32 / R;  // per-wave buffer stride: rows k1 land 32/RAD slots apart -> conflict-free tile reads
+    // RAD < 0 stands for the tiny lengths N = -RAD = 2 ... 32: a lane holds 16 consecutive points
+    // (18-element rows in LDS) and transforms them in registers (C16N = 2, 4, 8 or 16 points at a
+    // time; 32 = a radix-2 front stage + 16)
+    static constexpr bool C64 = RAD == 0 || RAD == 128, C256 = RAD == 256 || RAD == 512, C16 = RAD < 0;
+    static constexpr bool PRE2 = RAD == 128 || RAD == 512 || RAD == -32;
+    static constexpr int C16N = !C16 ? 0 : (RAD == -32 ? 16 : -RAD);
+    static constexpr int R = (C64 || C256 || C16) ? 1 : RAD;
+    static constexpr int BUF = (C256 || C16) ? 1160 : 1088 + 32 / R;  // per-wave buffer stride: rows k1 land 32/RAD slots apart -> conflict-free tile reads
     static constexpr size_t LDS = (1024 + 64 + R * 16 + R * 64 + 16 * BUF) * sizeof(float2);
 };
 
@@ -394,9 +400,53 @@ struct RxGeom {
 // layout of fft1024x16_kernel), 16 blocks of 64 points (C64: the same without the first radix-16
 // stage; block a at a*66) or 4 transforms of 256 points (C256: at t*272); spectra are left in
 // place in natural order (k + (k >> 4); a + 17 f; t*272 + f).
-template <int DIR, bool C64, bool C256>
+template <int DIR, bool C64, bool C256, int C16N = 0>
 __device__ __forceinline__ void rx_wave_core(cf* buf, const cf* tw1, const cf* tw2, int l, int q0, int q1) {
     cf v[16];
+    if constexpr (C16N != 0) {  // 16 consecutive points per lane: 16/C16N transforms, all in registers
+        cf2v* r = reinterpret_cast<cf2v*>(buf + l * 18);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const cf2v x = r[j];
+            v[2 * j] = cf{x.x, x.y};
+            v[2 * j + 1] = cf{x.z, x.w};
+        }
+        if constexpr (C16N == 16) {
+            radix16<DIR>(v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const cf a = v[R16_POS(2 * j)], b = v[R16_POS(2 * j + 1)];
+                r[j] = cf2v{a.x, a.y, b.x, b.y};
+            }
+        } else {
+            if constexpr (C16N == 8) {
+                cf lo[8], hi[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    lo[j] = v[j];
+                    hi[j] = v[8 + j];
+                }
+                radix8<DIR>(lo);
+                radix8<DIR>(hi);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v[j] = lo[j];
+                    v[8 + j] = hi[j];
+                }
+            }
+            if constexpr (C16N == 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) radix4<DIR>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+            }
+            if constexpr (C16N == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) radix2<DIR>(v[2 * j], v[2 * j + 1]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = cf2v{v[2 * j].x, v[2 * j].y, v[2 * j + 1].x, v[2 * j + 1].y};
+        }
+        return;
+    }
     if constexpr (C256) {
         // this wave's row: four 256-point transforms, lane (t, b) = (q1, q0)
 #pragma unroll
@@ -468,7 +518,9 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
                                                              const cf* __restrict__ tw1g, const cf* __restrict__ tw2g,
                                                              const cf* __restrict__ twag, const cf* __restrict__ twbg) {
     constexpr int R = RxGeom<RAD>::R, N = R * 1024, XPT = 16 / R, BUF = RxGeom<RAD>::BUF;
-    constexpr bool C64 = RxGeom<RAD>::C64, C256 = RxGeom<RAD>::C256, PRE2 = RxGeom<RAD>::PRE2, C1024 = !C64 && !C256;
+    constexpr bool C64 = RxGeom<RAD>::C64, C256 = RxGeom<RAD>::C256, C16 = RxGeom<RAD>::C16, PRE2 = RxGeom<RAD>::PRE2;
+    constexpr bool C1024 = !C64 && !C256 && !C16;
+    constexpr int C16N = RxGeom<RAD>::C16N, SLOTW = C256 ? F256_T : C64 ? FW_S1 : 18;  // slot stride of a half-spectrum (PRE2)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* tw1 = reinterpret_cast<cf*>(smem);  // [16][64]   W1024^{lane*k0}
     cf* tw2 = tw1 + 1024;                   // [16][4]    W64^{c*k1}
@@ -485,7 +537,7 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
     if (tid < R * 64) twb[tid] = twbg[tid];
 
     // PRE2: lane (h, rest) handles rows 2 rp + h; its two halves sit HALF points apart at offset e2
-    constexpr unsigned HALF = RAD == 512 ? 256u : 64u;
+    constexpr unsigned HALF = RAD == 512 ? 256u : RAD == -32 ? 16u : 64u;
     const unsigned h2 = static_cast<unsigned>(tid) >> 9, rest = static_cast<unsigned>(tid) & 511u;
     const unsigned n2 = rest & (HALF - 1), tr = rest / HALF;       // position in the half, transform of the row
     const unsigned e2 = 2 * HALF * tr + n2;
@@ -514,18 +566,17 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
                 radix2<DIR>(y0, y1);
                 y1 = tw_mul<DIR>(y1, w2);
                 cf* row = bufs + (2 * rp + h2) * BUF;
-                if constexpr (C256) {
-                    row[(2 * tr) * F256_T + n2] = y0;
-                    row[(2 * tr + 1) * F256_T + n2] = y1;
-                } else {
-                    row[(2 * tr) * FW_S1 + n2] = y0;
-                    row[(2 * tr + 1) * FW_S1 + n2] = y1;
-                }
+                row[(2 * tr) * SLOTW + n2] = y0;
+                row[(2 * tr + 1) * SLOTW + n2] = y1;
             }
         }
         if constexpr (RAD == 0) {  // 64-point rows: block a = wave of row u goes to exchange-1 row a as it is
 #pragma unroll
             for (int u = 0; u < 16; ++u) bufs[u * BUF + wave * FW_S1 + l] = pre[u];
+        }
+        if constexpr (C16 && !PRE2) {  // 16-point blocks of row u in 18-element rows
+#pragma unroll
+            for (int u = 0; u < 16; ++u) bufs[u * BUF + (tid >> 4) * 18 + (tid & 15)] = pre[u];
         }
         if constexpr (RAD == 256) {  // transform t = tid >> 8 of row u at t*272
 #pragma unroll
@@ -550,7 +601,7 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
         __syncthreads();
         if (tix + gridDim.x < n_tiles) fetch(tix + gridDim.x);
         // ---- this wave's 1024 points: one 1024-point transform, 16 of 64 points or 4 of 256 points
-        rx_wave_core<DIR, C64, C256>(buf, tw1, tw2, l, q0, q1);
+        rx_wave_core<DIR, C64, C256, C16N>(buf, tw1, tw2, l, q0, q1);
         __syncthreads();
         // ---- store: tile element i = j*N + RAD*k2 + k1 is output i
         cf* dst = out + tix * (16u * 1024u);
@@ -559,6 +610,11 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
             const unsigned i = static_cast<unsigned>(tid) + 1024u * u;
             if constexpr (RAD == 0) {  // row u, block a = wave, frequency f = l sits at a + 17 f
                 dst[i] = bufs[u * BUF + wave + 17 * l];
+            } else if constexpr (C16 && !PRE2) {
+                dst[i] = bufs[u * BUF + (tid >> 4) * 18 + (tid & 15)];
+            } else if constexpr (RAD == -32) {  // transform tid >> 5, k = k1 + 2 k2: block 2 tr + k1, point k2
+                const unsigned k = static_cast<unsigned>(tid) & 31u;
+                dst[i] = bufs[u * BUF + (2 * (static_cast<unsigned>(tid) >> 5) + (k & 1u)) * 18 + (k >> 1)];
             } else if constexpr (RAD == 256) {
                 dst[i] = bufs[u * BUF + (tid >> 8) * F256_T + (tid & 255)];
             } else if constexpr (RAD == 128) {  // transform tid >> 7, k = k1 + 2 k2: block 2 tr + k1, frequency k2
@@ -584,12 +640,14 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
 // back through the transposed mapping with the four-step twiddle applied on the way.
 template <int KIND>
 struct ColGeom {
-    static constexpr bool C64 = KIND == 0 || KIND == 128, C256 = !C64, PRE2 = KIND == 128 || KIND == 512;
+    static constexpr bool C16 = KIND == 32, C64 = KIND == 0 || KIND == 128, C256 = KIND == 256 || KIND == 512;
+    static constexpr bool PRE2 = KIND == 128 || KIND == 512 || KIND == 32;
+    static constexpr int C16N = C16 ? 16 : 0;
     static constexpr int N1 = KIND == 0 ? 64 : KIND;
     static constexpr int C = 16384 / N1;    // columns per tile
     static constexpr int TPW = 1024 / N1;   // columns per wave buffer
-    static constexpr int BUF = C256 ? 1160 : 1120;
-    static constexpr int SLOT = C64 ? FW_S1 : F256_T;
+    static constexpr int BUF = C64 ? 1120 : 1160;
+    static constexpr int SLOT = C64 ? FW_S1 : C256 ? F256_T : 18;
     static constexpr size_t LDS = (1024 + 64 + 256 + 16 * BUF) * sizeof(float2);
 };
 
@@ -601,6 +659,7 @@ __global__ __launch_bounds__(1024, 4) void fft_cols_kernel(const cf* in, cf* out
     using G = ColGeom<KIND>;
     constexpr int C = G::C, TPW = G::TPW, BUF = G::BUF, SLOT = G::SLOT, N1 = G::N1;
     constexpr bool C64 = G::C64, C256 = G::C256, PRE2 = G::PRE2;
+    constexpr int C16N = G::C16N;
     constexpr unsigned TPX = 1024 / C;  // tiles per transform
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* tw1 = reinterpret_cast<cf*>(smem);  // the core's stage table (W256^{b*ka} for the 256-point form)
@@ -651,7 +710,7 @@ __global__ __launch_bounds__(1024, 4) void fft_cols_kernel(const cf* in, cf* out
         }
         __syncthreads();
         if (tix + gridDim.x < n_tiles) fetch(tix + gridDim.x);
-        rx_wave_core<DIR, C64, C256>(buf, tw1, tw2, l, q0, q1);
+        rx_wave_core<DIR, C64, C256, C16N>(buf, tw1, tw2, l, q0, q1);
         __syncthreads();
         // ---- store transposed back, times W_N^{n2*k1}
         cf* dst = out + base_of(tix);
@@ -663,7 +722,7 @@ __global__ __launch_bounds__(1024, 4) void fft_cols_kernel(const cf* in, cf* out
             unsigned pos;
             if constexpr (PRE2) {
                 const unsigned kk = k1 & 1u, k2 = k1 >> 1;
-                pos = C64 ? (2 * t + kk) + 17 * k2 : (2 * t + kk) * SLOT + k2;
+                pos = C64 ? (2 * t + kk) + 17 * k2 : (2 * t + kk) * SLOT + k2;  // (256-point slots and 16-point blocks alike)
             } else {
                 pos = C64 ? t + 17 * k1 : t * SLOT + k1;
             }
@@ -883,7 +942,7 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
         pl.threads[i] = T;
         pl.lds[i] = static_cast<size_t>(npts) * sizeof(float2);
     }
-    const bool rx = N == 64 || N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096 || N == 8192 || N == 16384;
+    const bool rx = (N >= 2 && N <= 32) || N == 64 || N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096 || N == 8192 || N == 16384;
     if (pl.pass[0].L == 1024 || (pl.n_pass == 2 && pl.pass[1].L == 1024) || rx) {
         std::vector<float2> t1(1024), t2(64);
         for (int k0 = 0; k0 < 16; ++k0)
@@ -927,9 +986,9 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
         COMMS_HIP_TRY(hipMalloc(&pl.d_rxb, tb.size() * sizeof(float2)));
         COMMS_HIP_TRY(hipMemcpy(pl.d_rxa, ta.data(), ta.size() * sizeof(float2), hipMemcpyHostToDevice));
         COMMS_HIP_TRY(hipMemcpy(pl.d_rxb, tb.data(), tb.size() * sizeof(float2), hipMemcpyHostToDevice));
-        pl.rx_rad = N == 64 ? -1 : N == 256 ? -2 : N == 128 ? -3 : N == 512 ? -4 : rad;  // < 0: the short forms
-        if (N == 128 || N == 512) {  // W_N^{n2}, n2 < N/2, for the radix-2 front stage
-            std::vector<float2> t(N / 2);
+        pl.rx_rad = N == 64 ? -1 : N == 256 ? -2 : N == 128 ? -3 : N == 512 ? -4 : N <= 32 ? -static_cast<int>(N) - 100 : rad;  // < 0: the short forms (-100 - N: the tiny ones)
+        if (N == 128 || N == 512 || N == 32) {  // W_N^{n2}, n2 < N/2, for the radix-2 front stage
+            std::vector<float2> t(N / 2 < 64 ? 64 : N / 2, make_float2(1.f, 0.f));
             for (size_t j = 0; j < N / 2; ++j) {
                 const double a = -2.0 * kPiF * static_cast<double>(j) / static_cast<double>(N);
                 t[j] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
@@ -950,7 +1009,7 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
         }
     }
     if (pl.n_pass == 2 && pl.pass[1].L == 1024 && pl.d_fw1 &&
-        (pl.pass[0].L == 64 || pl.pass[0].L == 128 || pl.pass[0].L == 256 || pl.pass[0].L == 512)) {
+        (pl.pass[0].L == 32 || pl.pass[0].L == 64 || pl.pass[0].L == 128 || pl.pass[0].L == 256 || pl.pass[0].L == 512)) {
         const int n1 = pl.pass[0].L;
         std::vector<float2> t1(1024, make_float2(1.f, 0.f)), tr(256, make_float2(1.f, 0.f));
         for (int k = 0; k < 16; ++k)
@@ -1073,6 +1132,11 @@ static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size
                 case -2: COMMS_TRY(launch_rx<256>(pl, in, out, full, inverse, s)); break;
                 case -3: COMMS_TRY(launch_rx<128>(pl, in, out, full, inverse, s)); break;
                 case -4: COMMS_TRY(launch_rx<512>(pl, in, out, full, inverse, s)); break;
+                case -102: COMMS_TRY(launch_rx<-2>(pl, in, out, full, inverse, s)); break;
+                case -104: COMMS_TRY(launch_rx<-4>(pl, in, out, full, inverse, s)); break;
+                case -108: COMMS_TRY(launch_rx<-8>(pl, in, out, full, inverse, s)); break;
+                case -116: COMMS_TRY(launch_rx<-16>(pl, in, out, full, inverse, s)); break;
+                case -132: COMMS_TRY(launch_rx<-32>(pl, in, out, full, inverse, s)); break;
                 case 1: COMMS_TRY(launch_rx<1>(pl, in, out, full, inverse, s)); break;
                 case 2: COMMS_TRY(launch_rx<2>(pl, in, out, full, inverse, s)); break;
                 case 4: COMMS_TRY(launch_rx<4>(pl, in, out, full, inverse, s)); break;
@@ -1137,6 +1201,7 @@ static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size
             if (i == 0 && pl.col_kind >= 0 && !no_cols) {
                 switch (pl.col_kind) {
                     case 0: COMMS_TRY(launch_cols<0>(pl, src, dst, batch, inverse, s)); break;
+                    case 32: COMMS_TRY(launch_cols<32>(pl, src, dst, batch, inverse, s)); break;
                     case 128: COMMS_TRY(launch_cols<128>(pl, src, dst, batch, inverse, s)); break;
                     case 256: COMMS_TRY(launch_cols<256>(pl, src, dst, batch, inverse, s)); break;
                     default: COMMS_TRY(launch_cols<512>(pl, src, dst, batch, inverse, s)); break;
