@@ -514,7 +514,7 @@ __device__ __forceinline__ void rx_wave_core(cf* buf, const cf* tw1, const cf* t
 }
 
 template <int DIR, int RAD>
-__global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* out, size_t n_tiles,
+__global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* out, size_t n_tiles, size_t n_points,
                                                              const cf* __restrict__ tw1g, const cf* __restrict__ tw2g,
                                                              const cf* __restrict__ twag, const cf* __restrict__ twbg) {
     constexpr int R = RxGeom<RAD>::R, N = R * 1024, XPT = 16 / R, BUF = RxGeom<RAD>::BUF;
@@ -544,14 +544,24 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
     cf w2 = cf{1.f, 0.f};
     if constexpr (PRE2) w2 = twbg[n2];  // W_N^{n2}
     cf pre[16];
+    // the last tile of a batch may be partly past the end (whole transforms only): zeros in, nothing out
     auto fetch = [&](size_t tix) {
         const cf* src = in + tix * (16u * 1024u);
-        if constexpr (PRE2) {
+        const size_t left = n_points - tix * (16u * 1024u);  // > 0
+        if (left >= 16u * 1024u) {
+            if constexpr (PRE2) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) pre[u] = src[1024u * (2 * (u >> 1) + h2) + e2 + HALF * (u & 1)];  // u = 2*rp + n1
+                for (int u = 0; u < 16; ++u) pre[u] = src[1024u * (2 * (u >> 1) + h2) + e2 + HALF * (u & 1)];  // u = 2*rp + n1
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) pre[u] = src[1024u * u + static_cast<unsigned>(tid)];  // u = j*RAD + n1
+            }
         } else {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) pre[u] = src[1024u * u + static_cast<unsigned>(tid)];  // u = j*RAD + n1
+            for (int u = 0; u < 16; ++u) {
+                const unsigned i = PRE2 ? 1024u * (2 * (u >> 1) + h2) + e2 + HALF * (u & 1) : 1024u * u + static_cast<unsigned>(tid);
+                pre[u] = i < left ? src[i] : cf{0.f, 0.f};
+            }
         }
     };
     if (blockIdx.x < n_tiles) fetch(blockIdx.x);
@@ -605,9 +615,11 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
         __syncthreads();
         // ---- store: tile element i = j*N + RAD*k2 + k1 is output i
         cf* dst = out + tix * (16u * 1024u);
+        const size_t left_out = n_points - tix * (16u * 1024u);
 #pragma unroll 8
         for (int u = 0; u < 16; ++u) {
             const unsigned i = static_cast<unsigned>(tid) + 1024u * u;
+            if (i >= left_out) break;  // (uniform per u except in the last, partial row)
             if constexpr (RAD == 0) {  // row u, block a = wave, frequency f = l sits at a + 17 f
                 dst[i] = bufs[u * BUF + wave + 17 * l];
             } else if constexpr (C16 && !PRE2) {
@@ -1066,8 +1078,9 @@ static comms_status_t launch_fast(Pow2Plan& pl, const float2* src, float2* dst, 
 }
 
 template <int RAD>
-static comms_status_t launch_rx(Pow2Plan& pl, const float2* src, float2* dst, size_t n_tiles, bool inverse,
+static comms_status_t launch_rx(Pow2Plan& pl, const float2* src, float2* dst, size_t n_points, bool inverse,
                                 hipStream_t s) {
+    const size_t n_tiles = (n_points + 16383) / 16384;
     constexpr size_t lds = RxGeom<RAD>::LDS;
     static DeviceOnce attr_once;
     if (attr_once.need()) {
@@ -1084,9 +1097,9 @@ static comms_status_t launch_rx(Pow2Plan& pl, const float2* src, float2* dst, si
     const cf* ta = reinterpret_cast<const cf*>(pl.d_rxa);
     const cf* tb = reinterpret_cast<const cf*>(pl.d_rxb);
     if (inverse)
-        fft_rx1024_kernel<1, RAD><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, n_tiles, t1, t2, ta, tb);
+        fft_rx1024_kernel<1, RAD><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, n_tiles, n_points, t1, t2, ta, tb);
     else
-        fft_rx1024_kernel<-1, RAD><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, n_tiles, t1, t2, ta, tb);
+        fft_rx1024_kernel<-1, RAD><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, n_tiles, n_points, t1, t2, ta, tb);
     return launch_ok("fft_rx1024_kernel");
 }
 
@@ -1123,31 +1136,25 @@ static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size
         return v && *v && *v != '0';
     }();
     if (pl.rx_rad && !no_rx) {
-        // whole 16-row tiles go through the single-pass kernel; a ragged tail of transforms
-        // falls through to the tile passes below
-        const size_t xpt = pl.rx_rad < 0 ? 16384 / pl.N : 16 / static_cast<size_t>(pl.rx_rad), full = batch / xpt;
-        if (full) {
-            switch (pl.rx_rad) {
-                case -1: COMMS_TRY(launch_rx<0>(pl, in, out, full, inverse, s)); break;
-                case -2: COMMS_TRY(launch_rx<256>(pl, in, out, full, inverse, s)); break;
-                case -3: COMMS_TRY(launch_rx<128>(pl, in, out, full, inverse, s)); break;
-                case -4: COMMS_TRY(launch_rx<512>(pl, in, out, full, inverse, s)); break;
-                case -102: COMMS_TRY(launch_rx<-2>(pl, in, out, full, inverse, s)); break;
-                case -104: COMMS_TRY(launch_rx<-4>(pl, in, out, full, inverse, s)); break;
-                case -108: COMMS_TRY(launch_rx<-8>(pl, in, out, full, inverse, s)); break;
-                case -116: COMMS_TRY(launch_rx<-16>(pl, in, out, full, inverse, s)); break;
-                case -132: COMMS_TRY(launch_rx<-32>(pl, in, out, full, inverse, s)); break;
-                case 1: COMMS_TRY(launch_rx<1>(pl, in, out, full, inverse, s)); break;
-                case 2: COMMS_TRY(launch_rx<2>(pl, in, out, full, inverse, s)); break;
-                case 4: COMMS_TRY(launch_rx<4>(pl, in, out, full, inverse, s)); break;
-                case 8: COMMS_TRY(launch_rx<8>(pl, in, out, full, inverse, s)); break;
-                default: COMMS_TRY(launch_rx<16>(pl, in, out, full, inverse, s)); break;
-            }
-            in += full * xpt * pl.N;
-            out += full * xpt * pl.N;
-            batch -= full * xpt;
+        // the whole batch goes through the single-pass kernel (its last tile may be partial)
+        const size_t full = batch * pl.N;
+        switch (pl.rx_rad) {
+            case -1: COMMS_TRY(launch_rx<0>(pl, in, out, full, inverse, s)); break;
+            case -2: COMMS_TRY(launch_rx<256>(pl, in, out, full, inverse, s)); break;
+            case -3: COMMS_TRY(launch_rx<128>(pl, in, out, full, inverse, s)); break;
+            case -4: COMMS_TRY(launch_rx<512>(pl, in, out, full, inverse, s)); break;
+            case -102: COMMS_TRY(launch_rx<-2>(pl, in, out, full, inverse, s)); break;
+            case -104: COMMS_TRY(launch_rx<-4>(pl, in, out, full, inverse, s)); break;
+            case -108: COMMS_TRY(launch_rx<-8>(pl, in, out, full, inverse, s)); break;
+            case -116: COMMS_TRY(launch_rx<-16>(pl, in, out, full, inverse, s)); break;
+            case -132: COMMS_TRY(launch_rx<-32>(pl, in, out, full, inverse, s)); break;
+            case 1: COMMS_TRY(launch_rx<1>(pl, in, out, full, inverse, s)); break;
+            case 2: COMMS_TRY(launch_rx<2>(pl, in, out, full, inverse, s)); break;
+            case 4: COMMS_TRY(launch_rx<4>(pl, in, out, full, inverse, s)); break;
+            case 8: COMMS_TRY(launch_rx<8>(pl, in, out, full, inverse, s)); break;
+            default: COMMS_TRY(launch_rx<16>(pl, in, out, full, inverse, s)); break;
         }
-        if (!batch) return COMMS_OK;
+        return COMMS_OK;
     }
     for (int i = 0; i < pl.n_pass; ++i) {
         FftTileParams p = pl.pass[i];
