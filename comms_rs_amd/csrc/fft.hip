@@ -377,6 +377,16 @@ __device__ __forceinline__ void radix8(cf (&v)[8]) {
 // RAD = 256 stands for N = 256: a row is 4 transforms, lane (t, b) does radix-16 over a
 // (m = 16a + b), times W256^{b*ka}, one exchange, radix-16 over b: f = ka + 16 kb.
 typedef float cf2v __attribute__((ext_vector_type(4)));  // two packed complex values (16 B)
+// Bluestein riding on the single-pass kernel (padded length M = the kernel's N, a power of two):
+//   mode 1 (forward transform of the pair): load x[b*n + m] * chirp[m] for m < n, zeros up to M;
+//          store times bspec[m] (the spectrum of the wrapped conjugate chirp, 1/M folded in);
+//   mode 2 (inverse transform): plain load; store only m < n, times chirp[m], compacted to n.
+struct BluArgs {
+    int mode;
+    unsigned n, logM;
+    const cf* chirp;
+    const cf* bspec;
+};
 // RAD = 128 / 512 stand for N = 2 x 64 / 2 x 256: a radix-2 butterfly over the two halves of a
 // transform (x W_N^{n2}) on the way into LDS, then the 64- / 256-point form; lanes load both
 // halves themselves (eight row pairs each), and the interleave k = k1 + 2 k2 is undone by the
@@ -513,10 +523,13 @@ __device__ __forceinline__ void rx_wave_core(cf* buf, const cf* tw1, const cf* t
     }
 }
 
-template <int DIR, int RAD>
-__global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* out, size_t n_tiles, size_t n_points,
+// PART: the launch covers a partly filled tile (whole transforms only): zeros in, nothing out past
+// the end.  Full tiles run the unguarded instantiation.
+template <int DIR, int RAD, int BLU = 0, bool PART = false>
+__global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* out, size_t n_tiles, size_t first_tile, size_t n_points,
                                                              const cf* __restrict__ tw1g, const cf* __restrict__ tw2g,
-                                                             const cf* __restrict__ twag, const cf* __restrict__ twbg) {
+                                                             const cf* __restrict__ twag, const cf* __restrict__ twbg,
+                                                             const BluArgs blu) {
     constexpr int R = RxGeom<RAD>::R, N = R * 1024, XPT = 16 / R, BUF = RxGeom<RAD>::BUF;
     constexpr bool C64 = RxGeom<RAD>::C64, C256 = RxGeom<RAD>::C256, C16 = RxGeom<RAD>::C16, PRE2 = RxGeom<RAD>::PRE2;
     constexpr bool C1024 = !C64 && !C256 && !C16;
@@ -548,7 +561,15 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
     auto fetch = [&](size_t tix) {
         const cf* src = in + tix * (16u * 1024u);
         const size_t left = n_points - tix * (16u * 1024u);  // > 0
-        if (left >= 16u * 1024u) {
+        if constexpr (BLU == 1) {  // gather from the unpadded input, times the chirp
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const unsigned i = PRE2 ? 1024u * (2 * (u >> 1) + h2) + e2 + HALF * (u & 1) : 1024u * u + static_cast<unsigned>(tid);
+                const size_t g = tix * (16u * 1024u) + i;
+                const unsigned m = static_cast<unsigned>(g) & ((1u << blu.logM) - 1u);
+                pre[u] = ((!PART || i < left) && m < blu.n) ? g_mul(in[(g >> blu.logM) * blu.n + m], blu.chirp[m]) : cf{0.f, 0.f};
+            }
+        } else if constexpr (!PART) {
             if constexpr (PRE2) {
 #pragma unroll
                 for (int u = 0; u < 16; ++u) pre[u] = src[1024u * (2 * (u >> 1) + h2) + e2 + HALF * (u & 1)];  // u = 2*rp + n1
@@ -564,9 +585,9 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
             }
         }
     };
-    if (blockIdx.x < n_tiles) fetch(blockIdx.x);
+    if (first_tile + blockIdx.x < n_tiles) fetch(first_tile + blockIdx.x);
 
-    for (size_t tix = blockIdx.x; tix < n_tiles; tix += gridDim.x) {
+    for (size_t tix = first_tile + blockIdx.x; tix < n_tiles; tix += gridDim.x) {
         __syncthreads();  // previous tile fully stored (and the tables are in place)
         // ---- radix-RAD over n1, times W_N^{n2*k1}, row k1 -> buffer j*RAD + k1, position n2 = tid
         if constexpr (PRE2) {  // radix-2 over the halves; half-spectrum k1 of transform tr -> slot 2 tr + k1 of row 2 rp + h
@@ -619,26 +640,40 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
 #pragma unroll 8
         for (int u = 0; u < 16; ++u) {
             const unsigned i = static_cast<unsigned>(tid) + 1024u * u;
-            if (i >= left_out) break;  // (uniform per u except in the last, partial row)
+            if (PART && i >= left_out) break;
+            cf* dp = dst + i;
+            unsigned mb = 0;  // index inside the padded transform (Bluestein modes)
+            if constexpr (BLU != 0) {
+                const size_t g = tix * (16u * 1024u) + i;
+                mb = static_cast<unsigned>(g) & ((1u << blu.logM) - 1u);
+                if constexpr (BLU == 2) {  // keep the first n of every M outputs, compacted
+                    if (mb >= blu.n) continue;
+                    dp = out + (g >> blu.logM) * blu.n + mb;
+                }
+            }
+            cf xo;
             if constexpr (RAD == 0) {  // row u, block a = wave, frequency f = l sits at a + 17 f
-                dst[i] = bufs[u * BUF + wave + 17 * l];
+                xo = bufs[u * BUF + wave + 17 * l];
             } else if constexpr (C16 && !PRE2) {
-                dst[i] = bufs[u * BUF + (tid >> 4) * 18 + (tid & 15)];
+                xo = bufs[u * BUF + (tid >> 4) * 18 + (tid & 15)];
             } else if constexpr (RAD == -32) {  // transform tid >> 5, k = k1 + 2 k2: block 2 tr + k1, point k2
                 const unsigned k = static_cast<unsigned>(tid) & 31u;
-                dst[i] = bufs[u * BUF + (2 * (static_cast<unsigned>(tid) >> 5) + (k & 1u)) * 18 + (k >> 1)];
+                xo = bufs[u * BUF + (2 * (static_cast<unsigned>(tid) >> 5) + (k & 1u)) * 18 + (k >> 1)];
             } else if constexpr (RAD == 256) {
-                dst[i] = bufs[u * BUF + (tid >> 8) * F256_T + (tid & 255)];
+                xo = bufs[u * BUF + (tid >> 8) * F256_T + (tid & 255)];
             } else if constexpr (RAD == 128) {  // transform tid >> 7, k = k1 + 2 k2: block 2 tr + k1, frequency k2
                 const unsigned k = static_cast<unsigned>(tid) & 127u;
-                dst[i] = bufs[u * BUF + 2 * (static_cast<unsigned>(tid) >> 7) + (k & 1u) + 17 * (k >> 1)];
+                xo = bufs[u * BUF + 2 * (static_cast<unsigned>(tid) >> 7) + (k & 1u) + 17 * (k >> 1)];
             } else if constexpr (RAD == 512) {  // transform tid >> 9: slot 2 tr + k1, frequency k2
                 const unsigned k = static_cast<unsigned>(tid) & 511u;
-                dst[i] = bufs[u * BUF + (2 * (static_cast<unsigned>(tid) >> 9) + (k & 1u)) * F256_T + (k >> 1)];
+                xo = bufs[u * BUF + (2 * (static_cast<unsigned>(tid) >> 9) + (k & 1u)) * F256_T + (k >> 1)];
             } else {
                 const unsigned k1 = i % R, k2 = (i / R) & 1023u, j = i / N;
-                dst[i] = bufs[(j * R + k1) * BUF + k2 + (k2 >> 4)];
+                xo = bufs[(j * R + k1) * BUF + k2 + (k2 >> 4)];
             }
+            if constexpr (BLU == 1) xo = g_mul(xo, blu.bspec[mb]);
+            if constexpr (BLU == 2) xo = g_mul(xo, blu.chirp[mb]);
+            *dp = xo;
         }
     }
 }
@@ -1079,27 +1114,48 @@ static comms_status_t launch_fast(Pow2Plan& pl, const float2* src, float2* dst, 
 
 template <int RAD>
 static comms_status_t launch_rx(Pow2Plan& pl, const float2* src, float2* dst, size_t n_points, bool inverse,
-                                hipStream_t s) {
-    const size_t n_tiles = (n_points + 16383) / 16384;
-    constexpr size_t lds = RxGeom<RAD>::LDS;
-    static DeviceOnce attr_once;
-    if (attr_once.need()) {
-        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rx1024_kernel<1, RAD>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rx1024_kernel<-1, RAD>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    }
-    const unsigned blocks = static_cast<unsigned>(n_tiles < static_cast<size_t>(kNumCU) ? n_tiles : kNumCU);
+                                hipStream_t s, const BluArgs& blu = BluArgs{0, 0, 0, nullptr, nullptr}) {
+    const size_t n_full = n_points / 16384, rem = n_points % 16384;
     const cf* a = reinterpret_cast<const cf*>(src);
     cf* d = reinterpret_cast<cf*>(dst);
     const cf* t1 = reinterpret_cast<const cf*>(pl.d_fw1);
     const cf* t2 = reinterpret_cast<const cf*>(pl.d_fw2);
     const cf* ta = reinterpret_cast<const cf*>(pl.d_rxa);
     const cf* tb = reinterpret_cast<const cf*>(pl.d_rxb);
-    if (inverse)
-        fft_rx1024_kernel<1, RAD><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, n_tiles, n_points, t1, t2, ta, tb);
+    constexpr size_t lds = RxGeom<RAD>::LDS;
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
+#define COMMS_RX_ATTR(...)                                                                             \
+    COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rx1024_kernel<__VA_ARGS__>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)))
+        COMMS_RX_ATTR(1, RAD);
+        COMMS_RX_ATTR(-1, RAD);
+        COMMS_RX_ATTR(-1, RAD, 1);
+        COMMS_RX_ATTR(1, RAD, 2);
+        COMMS_RX_ATTR(1, RAD, 0, true);
+        COMMS_RX_ATTR(-1, RAD, 0, true);
+        COMMS_RX_ATTR(-1, RAD, 1, true);
+        COMMS_RX_ATTR(1, RAD, 2, true);
+#undef COMMS_RX_ATTR
+    }
+    // full tiles on the persistent grid; a partly filled last tile as one more workgroup.  In the
+    // Bluestein modes the two launches address in / out by the global element index, so the second
+    // one simply starts at tile n_full.
+    auto go = [&](auto kern_full, auto kern_part) {
+        if (n_full) {
+            const unsigned blocks = static_cast<unsigned>(n_full < static_cast<size_t>(kNumCU) ? n_full : kNumCU);
+            kern_full<<<dim3(blocks), dim3(1024), lds, s>>>(a, d, n_full, 0, n_full * 16384, t1, t2, ta, tb, blu);
+        }
+        if (rem) kern_part<<<dim3(1), dim3(1024), lds, s>>>(a, d, n_full + 1, n_full, n_points, t1, t2, ta, tb, blu);
+    };
+    if (blu.mode == 1)  // Bluestein, first half: always the forward transform
+        go(fft_rx1024_kernel<-1, RAD, 1>, fft_rx1024_kernel<-1, RAD, 1, true>);
+    else if (blu.mode == 2)  // second half: always the inverse
+        go(fft_rx1024_kernel<1, RAD, 2>, fft_rx1024_kernel<1, RAD, 2, true>);
+    else if (inverse)
+        go(fft_rx1024_kernel<1, RAD>, fft_rx1024_kernel<1, RAD, 0, true>);
     else
-        fft_rx1024_kernel<-1, RAD><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, n_tiles, n_points, t1, t2, ta, tb);
+        go(fft_rx1024_kernel<-1, RAD>, fft_rx1024_kernel<-1, RAD, 0, true>);
     return launch_ok("fft_rx1024_kernel");
 }
 
@@ -1129,33 +1185,35 @@ static comms_status_t launch_cols(Pow2Plan& pl, const float2* src, float2* dst, 
     return launch_ok("fft_cols_kernel");
 }
 
+// All of a batch on the single-pass kernel (plain, or as one half of a Bluestein pair).
+static comms_status_t run_rx(Pow2Plan& pl, const float2* in, float2* out, size_t n_points, bool inverse, hipStream_t s,
+                             const BluArgs& blu = BluArgs{0, 0, 0, nullptr, nullptr}) {
+    switch (pl.rx_rad) {
+            case -1: COMMS_TRY(launch_rx<0>(pl, in, out, n_points, inverse, s, blu)); break;
+            case -2: COMMS_TRY(launch_rx<256>(pl, in, out, n_points, inverse, s, blu)); break;
+            case -3: COMMS_TRY(launch_rx<128>(pl, in, out, n_points, inverse, s, blu)); break;
+            case -4: COMMS_TRY(launch_rx<512>(pl, in, out, n_points, inverse, s, blu)); break;
+            case -102: COMMS_TRY(launch_rx<-2>(pl, in, out, n_points, inverse, s, blu)); break;
+            case -104: COMMS_TRY(launch_rx<-4>(pl, in, out, n_points, inverse, s, blu)); break;
+            case -108: COMMS_TRY(launch_rx<-8>(pl, in, out, n_points, inverse, s, blu)); break;
+            case -116: COMMS_TRY(launch_rx<-16>(pl, in, out, n_points, inverse, s, blu)); break;
+            case -132: COMMS_TRY(launch_rx<-32>(pl, in, out, n_points, inverse, s, blu)); break;
+            case 1: COMMS_TRY(launch_rx<1>(pl, in, out, n_points, inverse, s, blu)); break;
+            case 2: COMMS_TRY(launch_rx<2>(pl, in, out, n_points, inverse, s, blu)); break;
+            case 4: COMMS_TRY(launch_rx<4>(pl, in, out, n_points, inverse, s, blu)); break;
+            case 8: COMMS_TRY(launch_rx<8>(pl, in, out, n_points, inverse, s, blu)); break;
+            default: COMMS_TRY(launch_rx<16>(pl, in, out, n_points, inverse, s, blu)); break;
+    }
+    return COMMS_OK;
+}
+
 static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size_t batch,
                                bool inverse, hipStream_t s, float2* scratch) {
     static const bool no_rx = [] {
         const char* v = getenv("COMMS_FFT_NO_RX");
         return v && *v && *v != '0';
     }();
-    if (pl.rx_rad && !no_rx) {
-        // the whole batch goes through the single-pass kernel (its last tile may be partial)
-        const size_t full = batch * pl.N;
-        switch (pl.rx_rad) {
-            case -1: COMMS_TRY(launch_rx<0>(pl, in, out, full, inverse, s)); break;
-            case -2: COMMS_TRY(launch_rx<256>(pl, in, out, full, inverse, s)); break;
-            case -3: COMMS_TRY(launch_rx<128>(pl, in, out, full, inverse, s)); break;
-            case -4: COMMS_TRY(launch_rx<512>(pl, in, out, full, inverse, s)); break;
-            case -102: COMMS_TRY(launch_rx<-2>(pl, in, out, full, inverse, s)); break;
-            case -104: COMMS_TRY(launch_rx<-4>(pl, in, out, full, inverse, s)); break;
-            case -108: COMMS_TRY(launch_rx<-8>(pl, in, out, full, inverse, s)); break;
-            case -116: COMMS_TRY(launch_rx<-16>(pl, in, out, full, inverse, s)); break;
-            case -132: COMMS_TRY(launch_rx<-32>(pl, in, out, full, inverse, s)); break;
-            case 1: COMMS_TRY(launch_rx<1>(pl, in, out, full, inverse, s)); break;
-            case 2: COMMS_TRY(launch_rx<2>(pl, in, out, full, inverse, s)); break;
-            case 4: COMMS_TRY(launch_rx<4>(pl, in, out, full, inverse, s)); break;
-            case 8: COMMS_TRY(launch_rx<8>(pl, in, out, full, inverse, s)); break;
-            default: COMMS_TRY(launch_rx<16>(pl, in, out, full, inverse, s)); break;
-        }
-        return COMMS_OK;
-    }
+    if (pl.rx_rad && !no_rx) return run_rx(pl, in, out, batch * pl.N, inverse, s);
     for (int i = 0; i < pl.n_pass; ++i) {
         FftTileParams p = pl.pass[i];
         const float2* src = in;
@@ -1401,8 +1459,24 @@ comms_status_t comms_fft_run_dev(comms_fft_t* h, const comms_c32* d_in, size_t n
     if (h->plan.n_pass == 2) COMMS_TRY(h->work2.reserve(chunk * M * sizeof(float2)));
     float2* a = static_cast<float2*>(h->work.p);
     float2* sc = static_cast<float2*>(h->work2.p);
+    static const bool no_fuse = [] {
+        const char* v = getenv("COMMS_FFT_BLU_UNFUSED");
+        return v && *v && *v != '0';
+    }();
+    const bool fuse = h->plan.rx_rad != 0 && !no_fuse;  // padded length on the single-pass kernel (M <= 16384)
+    unsigned logM = 0;
+    while ((static_cast<size_t>(1) << logM) < M) ++logM;
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = batch - b0 < chunk ? batch - b0 : chunk;
+        if (fuse) {
+            // two launches: [x * chirp, pad, forward, * bspec] -> work;  [inverse, * chirp, first N] -> out
+            const cf* chirp = reinterpret_cast<const cf*>(h->d_chirp);
+            COMMS_TRY(run_rx(h->plan, in + b0 * h->N, a, nb * M, false, s,
+                             BluArgs{1, static_cast<unsigned>(h->N), logM, chirp, reinterpret_cast<const cf*>(h->d_bspec)}));
+            COMMS_TRY(run_rx(h->plan, a, o + b0 * h->N, nb * M, true, s,
+                             BluArgs{2, static_cast<unsigned>(h->N), logM, chirp, nullptr}));
+            continue;
+        }
         blu_pre_kernel<<<dim3(4 * kNumCU), dim3(256), 0, s>>>(reinterpret_cast<const cf*>(in + b0 * h->N), reinterpret_cast<const cf*>(h->d_chirp), reinterpret_cast<cf*>(a), h->N, M, nb);
         COMMS_TRY(launch_ok("blu_pre_kernel"));
         COMMS_TRY(pow2_run(h->plan, a, a, nb, false, s, sc));
