@@ -782,6 +782,43 @@ __global__ __launch_bounds__(1024, 4) void fft_cols_kernel(const cf* in, cf* out
 }
 
 // Exact-index O(N^2) DFT, one transform per workgroup, f64 accumulation.
+// Short lengths (N <= 128): a 256-lane workgroup takes G = 256 / N transforms at a time, one lane
+// per output bin, so that e.g. a 10-point batch keeps 250 lanes busy instead of 10.
+__global__ __launch_bounds__(256) void dft_small_kernel(const cf* __restrict__ in, cf* __restrict__ out, int N,
+                                                        size_t batch, const cf* __restrict__ twN, int inverse) {
+    __shared__ cf x[256];
+    __shared__ cf w[128];
+    const int G = 256 / N, tid = threadIdx.x;
+    const int t = tid / N, k = tid - t * N;
+    if (tid < N) {
+        const cf tw = twN[tid];
+        w[tid] = inverse ? cf{tw.x, -tw.y} : tw;
+    }
+    const size_t groups = (batch + G - 1) / G;
+    for (size_t g = blockIdx.x; g < groups; g += gridDim.x) {
+        const size_t b = g * G + t;
+        const bool live = t < G && b < batch;
+        __syncthreads();
+        if (live) x[tid] = in[b * N + k];
+        __syncthreads();
+        if (live) {
+            const cf* xt = x + t * N;
+            double sr = 0.0, si = 0.0;
+            int e = 0;
+            for (int j = 0; j < N; ++j) {
+                const double xr = xt[j].x, xi = xt[j].y, wr = w[e].x, wi = w[e].y;
+                sr = fma(xr, wr, sr);
+                sr = fma(-xi, wi, sr);
+                si = fma(xr, wi, si);
+                si = fma(xi, wr, si);
+                e += k;
+                if (e >= N) e -= N;
+            }
+            out[b * N + k] = cf{static_cast<float>(sr), static_cast<float>(si)};
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void dft_direct_kernel(const cf* __restrict__ in,
                                                          cf* __restrict__ out, int N,
                                                          size_t batch,
@@ -1444,6 +1481,14 @@ comms_status_t comms_fft_run_dev(comms_fft_t* h, const comms_c32* d_in, size_t n
     }
     if (h->kind == 1) {
         COMMS_ARG(!ranges_overlap(d_in, n * 8, d_out, n * 8) , "this fft_size cannot run in place");
+        if (h->N <= 128) {
+            const size_t groups = (batch + 256 / h->N - 1) / (256 / h->N);
+            const unsigned gb = static_cast<unsigned>(groups < 8u * kNumCU ? groups : 8u * kNumCU);
+            dft_small_kernel<<<dim3(gb), dim3(256), 0, s>>>(reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(o),
+                                                            static_cast<int>(h->N), batch,
+                                                            reinterpret_cast<const cf*>(h->d_twN), h->inverse ? 1 : 0);
+            return launch_ok("dft_small_kernel");
+        }
         unsigned blocks = static_cast<unsigned>(batch < 4u * kNumCU ? batch : 4u * kNumCU);
         dft_direct_kernel<<<dim3(blocks), dim3(256), 2 * h->N * sizeof(float2), s>>>(
             reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(o), static_cast<int>(h->N), batch,
