@@ -884,3 +884,32 @@ def test_device_buf_refcount_and_roundtrip(c):
     assert np.array_equal(y.download(np.complex64, 1000), x)
     with pytest.raises(c.CommsError):
         b2.download(np.complex64, 1001)
+
+
+def test_handles_create_destroy_many_times(c):
+    """Handle life cycle: thousands of create / run / destroy cycles of every node type neither leak
+    device memory nor break later launches (each FIR / FFT handle owns streams, tables, scratch)."""
+    import torch
+
+    rng = np.random.default_rng(3)
+    x = rand_c(rng, 4096)
+    taps = lowpass_taps(63, 0.1)
+    def cycle(i):
+        nodes = [c.BatchFirNode(taps), c.MixerNode(0.1), c.FMDemodNode(), c.FFTBatchNode(1024, bool(i & 1)),
+                 c.FFTBatchNode(1000, False), c.PulseNode(taps, 4), c.ChainNode(0.1, 0.0, taps, 4, True),
+                 c.TimingEstimatorNode(4, 2, 0.5), c.NcoNode(0.1)]
+        if i % 50 == 0:
+            for nd in nodes[:7]:
+                nd.run(x[:4000] if not isinstance(nd, c.FFTBatchNode) else x[:nd.fft_size])
+        del nodes
+
+    for i in range(51):  # first use grows the runtime's pools once (code objects, heaps): not counted
+        cycle(i)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for i in range(300):
+        cycle(i)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (16 << 20), (free0, free1)
+    assert np.allclose(c.MixerNode(0.0).run(x), x)
