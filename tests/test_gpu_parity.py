@@ -913,3 +913,29 @@ def test_handles_create_destroy_many_times(c):
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (16 << 20), (free0, free1)
     assert np.allclose(c.MixerNode(0.0).run(x), x)
+
+
+def test_nodes_run_concurrently_on_their_own_threads(c):
+    """The reference runs one OS thread per node (src/node/mod.rs:279-281): distinct handles must work
+    concurrently from different threads (ctypes releases the GIL during the calls)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    rng = np.random.default_rng(8)
+    x = rand_c(rng, 20000)
+    taps = lowpass_taps(63, 0.1)
+    makers = [lambda: c.BatchFirNode(taps), lambda: c.MixerNode(0.3), lambda: c.FMDemodNode(),
+              lambda: c.FFTBatchNode(1000, False), lambda: c.FFTBatchNode(4096, True), lambda: c.PulseNode(taps, 4),
+              lambda: c.ChainNode(0.1, 0.0, taps, 4, True), lambda: c.DecimateNode(3)]
+
+    def work(mk):
+        node = mk()
+        n = getattr(node, "fft_size", 0)
+        n = n * 4 if n else 20000
+        return [node.run(x[:n]) for _ in range(40)]
+
+    serial = [work(mk) for mk in makers]
+    with ThreadPoolExecutor(len(makers)) as ex:
+        parallel = list(ex.map(work, makers))
+    for a, b in zip(serial, parallel):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
