@@ -18,7 +18,7 @@ for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
     vals[cnt] = {k: sum(v) / len(v) for k, v in acc.items()}
     for k, v in vals[cnt].items():
         print("%-11s %-60s %.4g KiB/launch" % (cnt, k[:60], v))
-key = [k for k in vals["FETCH_SIZE"] if "fir_os1024_kernel<16, 4, 0>" in k or "fir_os1024_kernel<4, 3, 0>" in k]
+key = [k for k in vals["FETCH_SIZE"] if "fir_os1024_kernel<16, 4, 0" in k or "fir_os1024_kernel<4, 3, 0" in k]
 if key:
     k = key[0]
     fetch, write = vals["FETCH_SIZE"][k] * 1024.0, vals["WRITE_SIZE"][k] * 1024.0
