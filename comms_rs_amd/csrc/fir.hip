@@ -796,7 +796,7 @@ __global__ __launch_bounds__(256) void pulse_kernel(const float2* __restrict__ s
     }
 }
 
-// Polyphase pulse shaper for the usual small sam_per_sym (2, 3, 4, 5, 8, 10, 16):
+// Polyphase pulse shaper for the usual sam_per_sym (2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 32):
 //   out[m*SPS + p] = sum_j taps[p + j*SPS] * sym[m - j]          (k = p + j*SPS ascending, as fir())
 // A lane owns one symbol m and its SPS outputs: each symbol of the window (from LDS, consecutive
 // lanes -> consecutive addresses) feeds SPS packed FMAs whose taps sit in SGPR pairs (kernel
@@ -1474,9 +1474,13 @@ static bool pulse_poly_launch(comms_pulse* h, const float2* sym, size_t n_sym, f
         case 3: return pulse_poly_try<3>(h, sym, n_sym, out, s);
         case 4: return pulse_poly_try<4>(h, sym, n_sym, out, s);
         case 5: return pulse_poly_try<5>(h, sym, n_sym, out, s);
+        case 6: return pulse_poly_try<6>(h, sym, n_sym, out, s);
         case 8: return pulse_poly_try<8>(h, sym, n_sym, out, s);
         case 10: return pulse_poly_try<10>(h, sym, n_sym, out, s);
+        case 12: return pulse_poly_try<12>(h, sym, n_sym, out, s);
         case 16: return pulse_poly_try<16>(h, sym, n_sym, out, s);
+        case 20: return pulse_poly_try<20>(h, sym, n_sym, out, s);
+        case 32: return pulse_poly_try<32>(h, sym, n_sym, out, s);
         default: return false;
     }
 }

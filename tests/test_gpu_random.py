@@ -96,7 +96,7 @@ def test_fft_random_sweep(c):
 def test_pulse_random_sweep(c):
     rng = np.random.default_rng(14 + 1000 * SEED_OFFSET)
     for case in range(30):
-        sps = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 10, 16, 20]))
+        sps = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 32]))
         n_taps = int(rng.integers(1, 400))
         taps = rand_c(rng, n_taps) if rng.integers(0, 2) else rand_c(rng, n_taps).real.astype(np.complex64)
         n = int(rng.integers(1, 4000))
