@@ -98,6 +98,37 @@ def cpu_baseline(n):
         run_chunk(0, True)
         out["one_core_norotate"] = {"value": round(chunk / (time.perf_counter() - t0) / 1e6, 2), "unit": "Msamples/s",
                                     "cores": 1}
+        # one thread per node joined by unbounded queues, as start_nodes! runs the
+        # reference graph (Vec batches of 2^18 samples); the slowest node (the FIR) sets the rate
+        import queue
+        import threading
+
+        batch, q1, q2, got = 1 << 18, queue.Queue(), queue.Queue(), []
+        st, mx = oracle.default_state(taps), oracle.Mixer(0.0, MIX_DPHASE)
+
+        def fir_node():
+            for i in range(0, n, batch):
+                q1.put(oracle.batch_fir(x[i:i + batch], taps, st))
+            q1.put(None)
+
+        def mixer_node():
+            while (v := q1.get()) is not None:
+                q2.put(mx.mix(v))
+            q2.put(None)
+
+        def decimate_node():
+            while (v := q2.get()) is not None:
+                got.append(oracle.decimate(v, DEC_RATE).size)
+
+        nodes = [threading.Thread(target=f) for f in (fir_node, mixer_node, decimate_node)]
+        t0 = time.perf_counter()
+        for t in nodes:
+            t.start()
+        for t in nodes:
+            t.join()
+        dt = time.perf_counter() - t0
+        assert sum(got) == n // DEC_RATE
+        out["thread_per_node"] = {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "cores": 3}
     except Exception as e:  # the single-thread figure above is the contract; these are extras
         out["all_cores"] = {"error": str(e)}
     return out
