@@ -36,13 +36,13 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FIR_BYTES_PER_SAMPLE = 16.0  # 8 B read + 8 B write per sample
 
 
-def pmc_traffic():
+def pmc_traffic(kernel):
     """HBM bytes per FIR launch from the committed rocprofv3 PMC passes (profiles/), or None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        if d.get("kernel") == "fir_os1024_kernel" and d.get("n_samples") == N_SAMPLES:
+        if d.get("kernel") == kernel and d.get("n_samples") == N_SAMPLES:
             return d.get("hbm_bytes_per_launch")
     except Exception:
         pass
@@ -260,8 +260,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         fused_elapsed = float(t.item())
     kernel_ms = float(np.mean(kms)) if kms.size else float("nan")
-    algo = {c.FIR_DIRECT: "fir_direct_kernel", c.FIR_OS1024: "fir_os1024_kernel",
-            c.FIR_OS4096: "fir_os4096_kernel"}[fir.algo_for(n)]
+    algo = fir.kernel_for(n)
 
     if rank == 0:
         total = float(world) * n * args.steps
@@ -286,7 +285,7 @@ def main():
                        "fir_kernel": algo, "sharding": "contiguous stream shards, one-off RCCL halo"},
             "roofline": {"bound": "hbm", "kernel": algo, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic(),
+                         "traffic": pmc_traffic(algo),
                          "kernel_ms": round(kernel_ms, 5), "launches_timed": int(kms.size),
                          "algorithmic_bytes_per_launch": FIR_BYTES_PER_SAMPLE * n},
         }

@@ -61,6 +61,7 @@ _PROTOS = {
     "comms_fir_create": [_vp, _sz, _vp, _sz, _i32, _pp],
     "comms_fir_set_algo": [_vp, _i32],
     "comms_fir_get_algo": [_vp, _sz, C.POINTER(_i32)],
+    "comms_fir_get_kernel": [_vp, _sz, C.c_char_p, _sz],
     "comms_fir_run": [_vp, _vp, _sz, _vp],
     "comms_fir_run_dev": [_vp, _vp, _sz, _vp, _vp],
     "comms_fir_get_state": [_vp, _vp, _sz],

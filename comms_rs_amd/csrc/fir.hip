@@ -27,6 +27,9 @@
 
 #include <hip/hip_ext.h>
 
+#include <atomic>
+#include <cstdio>
+
 #include "common.hpp"
 #include "fft_radix.hpp"
 #include "fir_handle.hpp"
@@ -331,6 +334,7 @@ struct WTables {
 // rotor, and reaches the 16 rows of a segment with the wave-uniform f32 rotors
 // step_a[a] = e^{i*64a*dphi}.
 constexpr int CH_STAMP = 16;  // diagnostic: per-phase cycle stamps into fm_prev_new (scripts/stamp_fir.py)
+constexpr int CH_TRACE = 32;  // diagnostic: per-wave start / set-up / end times, production geometry (scripts/trace_fir.py)
 constexpr int CH_PRE = COMMS_CHAIN_PRE, CH_POST = COMMS_CHAIN_POST, CH_DEC = COMMS_CHAIN_DEC, CH_FM = COMMS_CHAIN_FM;
 struct ChainArgs {
     uint64_t turns0, frac;
@@ -369,6 +373,110 @@ __device__ __forceinline__ void load_rows(const float2* __restrict__ in, size_t 
     }
 }
 
+// One segment through the filter: the 16 rows v[a] (samples 64a + lane of the 1024-point segment)
+// -> forward transform, spectrum multiply, inverse transform -> v[R16_POS(a)] = filtered row a.
+// `lds` is the calling wave's private exchange buffer; stamp(i) marks the diagnostic phases.
+template <class Stamp>
+__device__ __forceinline__ void os1024_core(cf (&v)[16], cf* lds, const cf* tw1, const cf* hsp, const cf* tw2, int l,
+                                            Stamp&& stamp) {
+    const int q0 = l & 15, q1 = l >> 4;  // stage 2: (k0, c) = (q0, q1); stage 3: k1 = q0, k0 = q1 + 4j
+    // ---- forward
+    radix16<-1>(v);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        cf x = v[R16_POS(k)];
+        if (k) x = cmulf(x, tw1[k * 64 + l]);
+        lds[k * W_S1 + l] = x;
+    }
+    wave_lds_sync();
+    stamp(1);  // R16 + twiddle + exchange-1 writes
+#pragma unroll
+    for (int b = 0; b < 16; ++b) v[b] = lds[q0 * W_S1 + 4 * b + q1];
+    wave_lds_sync();
+    stamp(2);  // exchange-1 reads
+    radix16<-1>(v);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        cf x = v[R16_POS(k)];
+        if (k) x = cmulf(x, tw2[k * 4 + q1]);
+        lds[q1 * W_P + 17 * q0 + k] = x;
+    }
+    wave_lds_sync();
+    stamp(3);  // R16 + twiddle + exchange-2 writes
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[4 * j + c] = lds[c * W_P + 17 * (q1 + 4 * j) + q0];
+    wave_lds_sync();
+    stamp(4);  // exchange-2 reads
+    // ---- R4 over c -> k2, spectrum multiply, inverse R4 over k2 -> c
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        radix4<-1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[4 * j + k] = cmulf(v[4 * j + k], hsp[(4 * j + k) * 64 + l]);
+        radix4<1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lds[c * W_P + 17 * (q1 + 4 * j) + q0] = v[4 * j + c];
+    }
+    wave_lds_sync();
+    stamp(5);  // R4 + spectrum + R4 + exchange-3 writes
+    // ---- inverse: lane (k0,c) = (q0,q1): conj W64^{c*k1}, R16 over k1 -> b
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        cf x = lds[q1 * W_P + 17 * q0 + k];
+        v[k] = k ? cmulcf(x, tw2[k * 4 + q1]) : x;
+    }
+    wave_lds_sync();
+    stamp(6);  // exchange-3 reads + twiddle
+    radix16<1>(v);
+#pragma unroll
+    for (int b = 0; b < 16; ++b) lds[q0 * W_S4 + 4 * b + q1] = v[R16_POS(b)];
+    wave_lds_sync();
+    stamp(7);  // R16 + exchange-4 writes
+    // ---- inverse: lane t: conj W1024^{t*k0}, R16 over k0 -> a
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        cf x = lds[k * W_S4 + l];
+        v[k] = k ? cmulcf(x, tw1[k * 64 + l]) : x;
+    }
+    wave_lds_sync();
+    stamp(8);  // exchange-4 reads + twiddle
+    radix16<1>(v);
+}
+
+// Diagnostic builds only: when a wave started, finished the workgroup's set-up and ended
+// (s_memrealtime, 100 MHz), its shader cycles and where it ran; 8 words per wave slot.
+template <bool ON>
+struct WaveTrace {
+    unsigned long long r0 = 0, c0 = 0, r1 = 0;
+    __device__ __forceinline__ WaveTrace() {
+        if (ON) {
+            r0 = __builtin_amdgcn_s_memrealtime();
+            c0 = __builtin_amdgcn_s_memtime();
+        }
+    }
+    __device__ __forceinline__ void setup_done() {
+        if (ON) r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    __device__ __forceinline__ void write(void* buf, size_t slot, int lane, size_t segments) const {
+        if (!ON) return;
+        const unsigned long long r2 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long c2 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            unsigned long long* t = static_cast<unsigned long long*>(buf) + slot * 8;
+            t[0] = r0;
+            t[1] = r1;
+            t[2] = r2;
+            t[3] = c2 - c0;
+            t[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_ID
+            t[5] = __builtin_amdgcn_s_getreg((3 << 11) | 20);  // XCC_ID
+            t[6] = segments;
+            t[7] = slot;
+        }
+    }
+};
+
 // WPB waves per workgroup share the read-only tables in LDS (stage-1 twiddles,
 // filter spectrum, W64 table: 16.5 KiB); every wave has a private 8.5 KiB
 // exchange buffer and runs on its own -- no workgroup barrier after set-up.
@@ -386,6 +494,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
     static_assert(HR == 4 || (HR == 2 && MODE == 0), "the short halo is for the plain FIR only");
     constexpr int WVK = 1024 - 64 * HR, HALO = 64 * HR, NEWR = 16 - HR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    WaveTrace<(MODE & CH_TRACE) != 0> trace;
     hist_advance(hist, in, n, new_hist, hist_len);
     cf* tw1 = reinterpret_cast<cf*>(smem);  // [16][64]
     cf* hsp = tw1 + 1024;                       // [16][64]
@@ -393,7 +502,6 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
     const int l = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     cf* lds = tw2 + 64 + wave * W_LDS;          // this wave's exchange buffer
-    const int q0 = l & 15, q1 = l >> 4;  // stage 2: (k0, c) = (q0, q1); stage 3: k1 = q0, k0 = q1 + 4j
 
     for (int i = threadIdx.x; i < 1024; i += 64 * WPB) {
         tw1[i] = tb.tw1[i];
@@ -401,6 +509,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
     }
     if (threadIdx.x < 64) tw2[threadIdx.x] = tb.tw2[threadIdx.x];
     __syncthreads();
+    trace.setup_done();
 
     // run r of n_runs owns segments [r*nseg/n_runs, (r+1)*nseg/n_runs): equal shares
     // (+-1) for every wave, so every CU carries the same load
@@ -463,70 +572,8 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
         for (int a = 0; a < HR; ++a) carry[a] = v[16 - HR + a];
         OS_STAMP(0)  // global loads landed
 
-        // ---- forward
-        radix16<-1>(v);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            cf x = v[R16_POS(k)];
-            if (k) x = cmulf(x, tw1[k * 64 + l]);
-            lds[k * W_S1 + l] = x;
-        }
-        wave_lds_sync();
-        OS_STAMP(1)  // R16 + twiddle + exchange-1 writes
-#pragma unroll
-        for (int b = 0; b < 16; ++b) v[b] = lds[q0 * W_S1 + 4 * b + q1];
-        wave_lds_sync();
-        OS_STAMP(2)  // exchange-1 reads
-        radix16<-1>(v);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            cf x = v[R16_POS(k)];
-            if (k) x = cmulf(x, tw2[k * 4 + q1]);
-            lds[q1 * W_P + 17 * q0 + k] = x;
-        }
-        wave_lds_sync();
-        OS_STAMP(3)  // R16 + twiddle + exchange-2 writes
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[4 * j + c] = lds[c * W_P + 17 * (q1 + 4 * j) + q0];
-        wave_lds_sync();
-        OS_STAMP(4)  // exchange-2 reads
-        // ---- R4 over c -> k2, spectrum multiply, inverse R4 over k2 -> c
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            radix4<-1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[4 * j + k] = cmulf(v[4 * j + k], hsp[(4 * j + k) * 64 + l]);
-            radix4<1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) lds[c * W_P + 17 * (q1 + 4 * j) + q0] = v[4 * j + c];
-        }
-        wave_lds_sync();
-        OS_STAMP(5)  // R4 + spectrum + R4 + exchange-3 writes
-        // ---- inverse: lane (k0,c) = (q0,q1): conj W64^{c*k1}, R16 over k1 -> b
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            cf x = lds[q1 * W_P + 17 * q0 + k];
-            v[k] = k ? cmulcf(x, tw2[k * 4 + q1]) : x;
-        }
-        wave_lds_sync();
-        OS_STAMP(6)  // exchange-3 reads + twiddle
-        radix16<1>(v);
-#pragma unroll
-        for (int b = 0; b < 16; ++b) lds[q0 * W_S4 + 4 * b + q1] = v[R16_POS(b)];
-        wave_lds_sync();
-        OS_STAMP(7)  // R16 + exchange-4 writes
-        // ---- inverse: lane t: conj W1024^{t*k0}, R16 over k0 -> a
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            cf x = lds[k * W_S4 + l];
-            v[k] = k ? cmulcf(x, tw1[k * 64 + l]) : x;
-        }
-        wave_lds_sync();
-        OS_STAMP(8)  // exchange-4 reads + twiddle
-        radix16<1>(v);
-        if ((MODE & ~CH_STAMP) == 0) {
+        os1024_core(v, lds, tw1, hsp, tw2, l, [&](int i) { OS_STAMP(i) });
+        if ((MODE & ~(CH_STAMP | CH_TRACE)) == 0) {
             if (nb + WVK <= n) {
 #pragma unroll
                 for (int a = HR; a < 16; ++a) out[nb + 64 * (a - HR) + l] = to_f2(v[R16_POS(a)]);
@@ -602,7 +649,109 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
         if (l == 0 && run < n_runs)
             for (int i = 0; i < 10; ++i) reinterpret_cast<unsigned long long*>(ch.fm_prev_new)[run * 10 + i] = st_acc[i];
     }
+    if (MODE & CH_TRACE) trace.write(ch.fm_prev_new, blockIdx.x * WPB + wave, l, seg1 - seg0);
 #undef OS_STAMP
+}
+
+// The plain FIR (no fused stages) with ticketed segments.  One 16-wave workgroup per CU owns a
+// contiguous range of the stream's interior segments; its waves draw them one at a time from a
+// counter in LDS and load all 16 rows of a segment themselves (no halo carried in registers: the
+// halo rows were just read by the neighbouring wave, an L2 hit).  Why: a SIMD issues oldest wave
+// first, so with equal fixed runs its four waves finish staggered -- 29 / 36 / 42 / 48 us of a
+// 55 us launch (scripts/trace_fir.py, profiles/r01_trace_fir_os1024.txt) -- and the tail of every
+// CU runs under-occupied; with tickets the older waves simply take more segments (7.3 / 6.1 /
+// 4.4 / 3.5 at 2^24 samples) and all sixteen end together: 11-12 % less kernel time at 2^24 and 2^26
+// samples (scripts/ab_fir.py, the variants interleaved launch by launch).  The stream's first segment
+// (history) and its partial last one take the guarded path after the loop.
+// (Loading the NEXT segment's rows into spare registers before transforming this one -- the wait
+// then sits after the 16 - HR stores as a counted vmcnt -- was measured too: 3 us SLOWER at 2^24,
+// the 32 register moves per segment cost more than the covered latency.)
+template <int HR, bool TRACE, bool NT = false>
+__global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(const float2* __restrict__ in,
+                                                                 const float2* __restrict__ hist, int hist_len,
+                                                                 float2* __restrict__ out, size_t n, WTables tb,
+                                                                 float2* __restrict__ new_hist, void* trace_buf) {
+    constexpr int WVK = 1024 - 64 * HR, HALO = 64 * HR;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WaveTrace<TRACE> trace;
+    hist_advance(hist, in, n, new_hist, hist_len);
+    cf* tw1 = reinterpret_cast<cf*>(smem);  // [16][64]
+    cf* hsp = tw1 + 1024;                   // [16][64]
+    cf* tw2 = hsp + 1024;                   // [16][4]
+    const int l = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    cf* lds = tw2 + 64 + wave * W_LDS;      // this wave's exchange buffer
+    unsigned* ticket = reinterpret_cast<unsigned*>(tw2 + 64 + 16 * W_LDS);
+    for (int i = threadIdx.x; i < 1024; i += 1024) {
+        tw1[i] = tb.tw1[i];
+        hsp[i] = tb.hdev[i];
+    }
+    if (threadIdx.x < 64) tw2[threadIdx.x] = tb.tw2[threadIdx.x];
+    if (threadIdx.x == 0) *ticket = 0;
+    __syncthreads();
+    trace.setup_done();
+
+    // interior segments 1 .. nfull-1 (all 16 rows inside `in`, all outputs inside `out`), dealt
+    // to the workgroups in equal contiguous shares
+    const size_t nfull = n / WVK;
+    const size_t inner = nfull > 1 ? nfull - 1 : 0;
+    const size_t lo = 1 + blockIdx.x * inner / gridDim.x;
+    const size_t hi = 1 + (blockIdx.x + 1) * inner / gridDim.x;
+    auto draw = [&]() -> size_t {  // one lane draws, the wave follows
+        unsigned t = 0;
+        if (l == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return lo + static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(t)));
+    };
+    auto fetch = [&](size_t sg, cf (&r)[16]) {
+        const float2* p = in + (sg * WVK - HALO + l);
+#pragma unroll
+        for (int a = 0; a < 16; ++a) r[a] = to_cf(p[64 * a]);
+    };
+    auto nostamp = [](int) {};
+
+    size_t count = 0;
+    cf v[16];
+    size_t seg = draw();
+    while (seg < hi) {
+        fetch(seg, v);
+        const size_t seg_next = draw();  // the ticket's LDS round trip hides behind the loads
+        os1024_core(v, lds, tw1, hsp, tw2, l, nostamp);
+        float2* o = out + seg * WVK + l;
+#pragma unroll
+        for (int a = HR; a < 16; ++a) {
+            if (NT)
+                __builtin_nontemporal_store(v[R16_POS(a)], reinterpret_cast<cf*>(o + 64 * (a - HR)));
+            else
+                o[64 * (a - HR)] = to_f2(v[R16_POS(a)]);
+        }
+        seg = seg_next;
+        ++count;
+    }
+
+    // the stream's first segment (halo from the history) and its partial last one: guarded
+    if (wave == 0) {
+        const size_t nseg = (n + WVK - 1) / WVK;
+        for (int e = 0; e < 2; ++e) {
+            const size_t sg = e ? nseg - 1 : 0;
+            if (e ? (blockIdx.x != gridDim.x - 1 || nseg < 2 || nseg == nfull) : blockIdx.x != 0) continue;
+            const size_t nb = sg * WVK;
+#pragma unroll
+            for (int a = 0; a < HR; ++a)
+                v[a] = to_cf(stream_at(in, hist, hist_len, static_cast<long long>(nb) - HALO + 64 * a + l, n));
+            cf nw[16 - HR];
+            load_rows(in, nb, l, n, nw);
+#pragma unroll
+            for (int a = HR; a < 16; ++a) v[a] = nw[a - HR];
+            os1024_core(v, lds, tw1, hsp, tw2, l, nostamp);
+#pragma unroll
+            for (int a = HR; a < 16; ++a) {
+                const size_t i = nb + 64 * (a - HR) + l;
+                if (i < n) out[i] = to_f2(v[R16_POS(a)]);
+            }
+            ++count;
+        }
+    }
+    if (TRACE) trace.write(trace_buf, blockIdx.x * 16 + wave, l, count);
 }
 
 // ---------------------------------------------------------------- overlap-save, F = 16384 (long filters)
@@ -924,6 +1073,44 @@ static size_t os1024_runs(int wpb, size_t nseg, size_t min_run) {
     return runs;
 }
 
+// 0: fixed runs (fir_os1024_kernel), 1: ticketed segments (fir_os1024_dyn_kernel), 2: ... with
+// non-temporal stores.  COMMS_OS1024_DYNAMIC sets it; comms_debug_os1024_dynamic() switches it at run
+// time so that scripts/ab_fir.py can interleave the variants launch by launch.
+static int tune_int(const char* name, int dflt);
+static std::atomic<int> g_os1024_dynamic{-1};
+static int os1024_dynamic_mode() {
+    int m = g_os1024_dynamic.load(std::memory_order_relaxed);
+    if (m < 0) {
+        m = tune_int("COMMS_OS1024_DYNAMIC", 1);
+        g_os1024_dynamic.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+extern "C" void comms_debug_os1024_dynamic(int mode) { g_os1024_dynamic.store(mode, std::memory_order_relaxed); }
+
+// One launch of fir_os1024_dyn_kernel: one 16-wave workgroup per CU (fewer for short inputs).
+template <int HR, bool TRACE = false, bool NT = false>
+static comms_status_t launch_os1024_dyn(hipStream_t s, const float2* in, const float2* hist, int n_eff, float2* o,
+                                        size_t n, const comms::WTables& tb, float2* nh, void* trace_buf = nullptr,
+                                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+    using namespace comms;
+    const size_t lds = (2112 + 16 * W_LDS + 1) * sizeof(float2);  // tables, exchange buffers, ticket counter
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os1024_dyn_kernel<HR, TRACE, NT>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    }
+    const size_t nseg = (n + (1024 - 64 * HR) - 1) / (1024 - 64 * HR);
+    const size_t want = (nseg + 15) / 16;
+    const dim3 grid(static_cast<unsigned>(want < static_cast<size_t>(kNumCU) ? want : kNumCU));
+    if (ev_start)  // timed launch: the events take the kernel's own begin / end timestamps
+        hipExtLaunchKernelGGL((fir_os1024_dyn_kernel<HR, TRACE, NT>), grid, dim3(1024), static_cast<uint32_t>(lds), s, ev_start,
+                              ev_stop, 0u, in, hist, n_eff, o, n, tb, nh, trace_buf);
+    else
+        fir_os1024_dyn_kernel<HR, TRACE, NT><<<grid, dim3(1024), lds, s>>>(in, hist, n_eff, o, n, tb, nh, trace_buf);
+    return COMMS_OK;
+}
+
 static const double kPi = 3.14159265358979323846264338327950288;
 
 static float2 unit_root_os(long long e, int denom) {
@@ -1214,6 +1401,46 @@ comms_status_t comms_fir_set_algo(comms_fir_t* h, int32_t algo) {
     return COMMS_OK;
 }
 
+// How comms_fir_run_dev launches the 1024-point overlap-save FIR for n samples.
+struct Os1024Plan {
+    bool hr2;     // two halo rows (<= 129 taps): 896 new samples per segment instead of 768
+    bool dyn;     // ticketed segments (fir_os1024_dyn_kernel) rather than fixed runs (fir_os1024_kernel)
+    bool nt;      // ... with non-temporal stores (experiment: COMMS_OS1024_DYNAMIC=2)
+    int wpb;      // waves per workgroup of the fixed-run kernel
+    size_t min_run, nseg;
+};
+static Os1024Plan os1024_plan(const comms_fir* h, size_t n) {
+    static const bool short_halo_ok = tune_int("COMMS_OS1024_SHORT_HALO", 1) != 0;
+    static const int wpb = tune_int("COMMS_OS1024_WPB", 16);
+    static const int min_run = tune_int("COMMS_OS1024_MINRUN", 1);
+    // ticketed segments pay once there are a few segments per wave slot (they trim the tail of the launch):
+    // measured -5 % at 2^22 samples, -11 % at 2^24, -9 % at 2^26, +3 % at 2^21 (scripts/ab_fir.py)
+    static const size_t dyn_minseg = static_cast<size_t>(tune_int("COMMS_OS1024_DYN_MINSEG", 4096));
+    Os1024Plan p{};
+    p.hr2 = short_halo_ok && h->n_eff <= 129;
+    p.wpb = wpb;
+    p.min_run = static_cast<size_t>(min_run);
+    const size_t wv = p.hr2 ? 896 : comms::WV;
+    p.nseg = (n + wv - 1) / wv;
+    const int mode = os1024_dynamic_mode();
+    p.dyn = mode != 0 && wpb == 16 && p.nseg >= dyn_minseg;
+    p.nt = mode == 2;
+    return p;
+}
+
+comms_status_t comms_fir_get_kernel(const comms_fir_t* h, size_t n, char* name, size_t name_len) {
+    COMMS_ARG(h && name && name_len, "NULL argument");
+    const char* k = "fir_direct_kernel";
+    switch (fir_pick(h, n)) {
+        case COMMS_FIR_OS1024: k = os1024_plan(h, n).dyn ? "fir_os1024_dyn_kernel" : "fir_os1024_kernel"; break;
+        case COMMS_FIR_OS4096: k = "fir_os4096_kernel"; break;
+        case COMMS_FIR_OS16K: k = "fir_os16k_kernel"; break;
+        default: break;
+    }
+    std::snprintf(name, name_len, "%s", k);
+    return COMMS_OK;
+}
+
 comms_status_t comms_fir_get_algo(const comms_fir_t* h, size_t n, int32_t* out_algo) {
     COMMS_ARG(h && out_algo, "NULL argument");
     *out_algo = fir_pick(h, n);
@@ -1250,23 +1477,23 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
         COMMS_TRY(launch_ok("fir_direct_kernel"));
     } else if (algo == COMMS_FIR_OS1024) {
         COMMS_TRY(fir_prepare_os1024(h));
-        // up to 129 taps the halo is two rows, not four: 896 new samples per 1024-point segment
-        static const bool short_halo_ok = tune_int("COMMS_OS1024_SHORT_HALO", 1) != 0;
-        const bool hr2 = short_halo_ok && h->n_eff <= 129;
-        const size_t wv = hr2 ? 896 : WV;
-        const size_t nseg = (n + wv - 1) / wv;
-        // one wave per run of consecutive segments
-        static const int wpb = tune_int("COMMS_OS1024_WPB", 16);
-        static const int min_run = tune_int("COMMS_OS1024_MINRUN", 1);
-        const size_t runs = os1024_runs(wpb, nseg, min_run);
+        const Os1024Plan pl = os1024_plan(h, n);
+        const size_t nseg = pl.nseg;
+        const size_t runs = os1024_runs(pl.wpb, nseg, pl.min_run);
         WTables tb{reinterpret_cast<const cf*>(h->d_wtw1), reinterpret_cast<const cf*>(h->d_wtw2), reinterpret_cast<const cf*>(h->d_whdev)};
         hipEvent_t ea = nullptr, eb = nullptr;
-        if (h->timed() && wpb == 16) h->next_events(ea, eb);
+        if (h->timed() && pl.wpb == 16) h->next_events(ea, eb);
         if (!ea) h->tic(s);
-        if (hr2)
-            COMMS_TRY((launch_os1024<0, 2>(wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb)));
+        if (pl.dyn && pl.nt && !pl.hr2)
+            COMMS_TRY((launch_os1024_dyn<4, false, true>(s, in, hist, h->n_eff, o, n, tb, nh, nullptr, ea, eb)));
+        else if (pl.hr2 && pl.dyn)
+            COMMS_TRY((launch_os1024_dyn<2>(s, in, hist, h->n_eff, o, n, tb, nh, nullptr, ea, eb)));
+        else if (pl.hr2)
+            COMMS_TRY((launch_os1024<0, 2>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb)));
+        else if (pl.dyn)
+            COMMS_TRY((launch_os1024_dyn<4>(s, in, hist, h->n_eff, o, n, tb, nh, nullptr, ea, eb)));
         else
-            COMMS_TRY(launch_os1024<0>(wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb));
+            COMMS_TRY(launch_os1024<0>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb));
         if (!ea) h->toc(s);
         COMMS_TRY(launch_ok("fir_os1024_kernel"));
     } else if (algo == COMMS_FIR_OS16K) {
@@ -1400,6 +1627,12 @@ comms_status_t comms_fir_run_fused_dev(comms_fir_t* h, const comms_c32* d_in, si
             break;
         case CH_POST | CH_DEC | CH_FM:
             COMMS_TRY(launch_os1024<CH_POST | CH_DEC | CH_FM>(wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ch));
+            break;
+        case CH_TRACE:  // diagnostic build: production geometry, per-wave times into fm_prev_new
+            if (os1024_dynamic_mode() != 0)
+                COMMS_TRY((launch_os1024_dyn<4, true>(s, in, hist, h->n_eff, o, n, tb, nh, fm_prev_new)));
+            else
+                COMMS_TRY(launch_os1024<CH_TRACE>(16, os1024_runs(16, nseg, 1), s, in, hist, h->n_eff, o, n, nseg, tb, nh, ch));
             break;
         case CH_STAMP:  // diagnostic build: 4-wave workgroups, stamps into fm_prev_new
             COMMS_TRY(launch_os1024<CH_STAMP>(4, os1024_runs(4, nseg, 4), s, in, hist, h->n_eff, o, n, nseg, tb, nh, ch));

@@ -120,6 +120,12 @@ class BatchFirNode(_Handle):
         check(lib().comms_fir_get_algo(self._h, n, C.byref(a)))
         return a.value
 
+    def kernel_for(self, n):
+        """Name of the kernel a batch of n samples is run by (diagnostics)."""
+        buf = C.create_string_buffer(64)
+        check(lib().comms_fir_get_kernel(self._h, n, buf, 64))
+        return buf.value.decode()
+
     def run(self, x):
         x = _as_c64(x)
         out = np.empty_like(x)

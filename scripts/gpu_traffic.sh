@@ -18,14 +18,14 @@ for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
     vals[cnt] = {k: sum(v) / len(v) for k, v in acc.items()}
     for k, v in vals[cnt].items():
         print("%-11s %-60s %.4g KiB/launch" % (cnt, k[:60], v))
-key = [k for k in vals["FETCH_SIZE"] if "fir_os1024_kernel<16, 4, 0" in k or "fir_os1024_kernel<4, 3, 0" in k]
+key = [k for k in vals["FETCH_SIZE"] if "fir_os1024_dyn_kernel<" in k or "fir_os1024_kernel<16, 4, 0" in k or "fir_os1024_kernel<4, 3, 0" in k]
 if key:
     k = key[0]
     fetch, write = vals["FETCH_SIZE"][k] * 1024.0, vals["WRITE_SIZE"][k] * 1024.0
-    d = {"kernel": "fir_os1024_kernel", "n_samples": 1 << 24,
+    d = {"kernel": k.split("::")[-1].split("<")[0], "n_samples": 1 << 24,
          "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
          "hbm_bytes_per_launch": 2.0 * fetch + write,
-         "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 50`; "
+         "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --steps 50; "
                  "counters are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of a "
                  "wide coalesced streaming read); algorithmic bytes per launch = 268435456"}
     json.dump(d, open("$OUT/pmc_traffic.json", "w"), indent=1)

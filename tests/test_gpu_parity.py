@@ -227,6 +227,45 @@ def test_fir_auto_selection_and_errors(c):
         c.BatchFirNode(np.ones(5000, np.complex64)).set_algo(c.FIR_DIRECT)
 
 
+@pytest.mark.parametrize("n_taps", [255, 100])
+def test_fir_os1024_ticketed_and_fixed_run_kernels_agree(c, n_taps):
+    """Long batches run fir_os1024_dyn_kernel (waves draw segments from a ticket counter), short ones
+    fir_os1024_kernel (fixed runs): the same transforms per segment, so bit-identical outputs -- across two
+    calls (carried state), with a partial last segment, for both halo widths (255 taps: 4 rows, 100: 2)."""
+    import ctypes
+    import torch
+
+    setm = c.lib().comms_debug_os1024_dynamic
+    setm.argtypes, setm.restype = [ctypes.c_int], None
+    wv = 768 if n_taps > 129 else 896
+    n1, n2 = 4200 * wv + 333, 4100 * wv  # both above the 4096-segment threshold; n1 ends inside a segment
+    taps = (oracle.rrc_taps(n_taps, 8.0, 0.35) * np.exp(0.3j * np.arange(n_taps))).astype(np.complex64)
+    x = torch.empty(n1 + n2, dtype=torch.complex64, device="cuda:0")
+    c.synth_iq_dev(x.data_ptr(), n1 + n2, 0, 77)
+    s = torch.cuda.current_stream().cuda_stream
+    ys = {}
+    try:
+        for mode in (0, 1):
+            setm(mode)
+            node = c.BatchFirNode(taps).set_algo(c.FIR_OS1024)
+            assert node.kernel_for(n1) == ("fir_os1024_dyn_kernel" if mode else "fir_os1024_kernel")
+            y = torch.empty_like(x)
+            node.run_dev(x.data_ptr(), n1, y.data_ptr(), s)
+            node.run_dev(x.data_ptr() + 8 * n1, n2, y.data_ptr() + 8 * n1, s)
+            torch.cuda.synchronize()
+            ys[mode] = y
+    finally:
+        setm(1)
+    assert torch.equal(ys[0].view(torch.float32), ys[1].view(torch.float32))
+    # and against the oracle: stream start (default state), the call boundary, the partial segment, the end
+    for a in (0, n1 - 3000, n1 - 100, n1 + n2 - 4096):
+        lo = max(0, a - (n_taps - 1))
+        xs = c.synth_iq(a + 4096 - lo, lo, 77)
+        want = oracle.batch_fir(xs, taps, oracle.default_state(taps), norotate=True)[a - lo:]
+        fir_close(ys[1][a:a + 4096].cpu().numpy(), want, taps, xs)
+    assert c.BatchFirNode(taps).set_algo(c.FIR_OS1024).kernel_for(1 << 20) == "fir_os1024_kernel"
+
+
 def test_fir_full_size_config2_properties(c):
     """BASELINE config 2: 255 taps on 2^24 samples, device-resident, both kernels.
     Size-independent checks: (1) linearity via an impulse train: y == taps laid at
