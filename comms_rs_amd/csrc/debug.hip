@@ -162,12 +162,51 @@ __global__ __launch_bounds__(256) void probe_pk_kernel(float* out, int iters, fl
     for (int i = 0; i < 16; ++i) s += r[i].x + r[i].y;
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+// KIND 5: v_permlane32_swap_b32, KIND 6: v_permlane16_swap_b32 (8 swaps of register pairs per 16 "ops")
+template <int KIND>
+__global__ __launch_bounds__(256) void probe_swap_kernel(float* out, int iters) {
+    unsigned r[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = threadIdx.x * 16 + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            // the builtins, not inline asm: the compiler then inserts the wait states these need
+            // after a VALU write of their operands (raw asm right after a v_mov read stale lanes)
+            const auto q = KIND == 5 ? __builtin_amdgcn_permlane32_swap(r[i], r[i + 1], false, false)
+                                     : __builtin_amdgcn_permlane16_swap(r[i], r[i + 1], false, false);
+            r[i] = q[0];
+            r[i + 1] = q[1];
+        }
+    }
+    unsigned s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += r[i];
+    out[blockIdx.x * 256 + threadIdx.x] = static_cast<float>(s & 0xffff);
+}
+// what the swaps do: out[0..63] / [64..127] = (a, b) after v_permlane32_swap of a = lane, b = 100 + lane;
+// out[128..255] the same for v_permlane16_swap
+__global__ void probe_swap_semantics_kernel(unsigned* out) {
+    const unsigned a = threadIdx.x, b = 100 + threadIdx.x;
+    const auto p = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    out[threadIdx.x] = p[0];
+    out[64 + threadIdx.x] = p[1];
+    const auto q = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    out[128 + threadIdx.x] = q[0];
+    out[192 + threadIdx.x] = q[1];
+}
 }  // namespace comms
+extern "C" comms_status_t comms_debug_swap_semantics(unsigned* d_out, void* stream) {
+    comms::probe_swap_semantics_kernel<<<dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream)>>>(d_out);
+    return comms::launch_ok("probe_swap_semantics");
+}
 extern "C" comms_status_t comms_debug_valu(float* d_out, int kind, int iters, int blocks, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (kind == 0) comms::probe_valu_kernel<0><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 1.0001f, 0.5f);
     else if (kind == 1) comms::probe_valu_kernel<1><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 1.0001f, 0.5f);
     else if (kind == 2) comms::probe_valu_kernel<2><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 1.0001f, 0.5f);
+    else if (kind == 5) comms::probe_swap_kernel<5><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters);
+    else if (kind == 6) comms::probe_swap_kernel<6><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters);
     else if (kind == 3) comms::probe_pk_kernel<3><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 0.9999f, 0.01f);
     else comms::probe_pk_kernel<4><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 0.9999f, 0.01f);
     return comms::launch_ok("probe_valu");

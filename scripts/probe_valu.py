@@ -6,13 +6,20 @@ l = c.lib()
 f = l.comms_debug_valu; f.restype = C.c_int32; f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
 out = torch.empty(256 * 8 * 256, dtype=torch.float32, device="cuda:0")
 iters = 20000
-for kind, nm in [(0, "v_fma_f32"), (3, "v_pk_fma_f32"), (4, "cmul=pk_mul+pk_fma (2 instr)")]:
+for kind, nm in [(0, "v_fma_f32"), (3, "v_pk_fma_f32"), (4, "cmul=pk_mul+pk_fma (2 instr)"), (5, "v_permlane32_swap (8 per 16 slots)"), (6, "v_permlane16_swap (8 per 16 slots)")]:
     for wps in (1, 2, 4, 8):   # waves per SIMD
         blocks = 256 * wps
         f(out.data_ptr(), kind, 100, blocks, None)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); f(out.data_ptr(), kind, iters, blocks, None); b.record(); torch.cuda.synchronize()
         ms = a.elapsed_time(b)
-        instr_per_simd = iters * 16 * wps * (2 if kind == 4 else 1)
+        instr_per_simd = iters * 16 * wps * (2 if kind == 4 else 0.5 if kind >= 5 else 1)
         print("%s waves/SIMD=%d: %.2f ms -> %.2f ns per wave-instr per SIMD = %.2f cycles @2.4GHz" %
               (nm, wps, ms, ms * 1e6 / instr_per_simd, ms * 1e6 / instr_per_simd * 2.4))
+
+g = l.comms_debug_swap_semantics; g.restype = C.c_int32; g.argtypes = [C.c_void_p, C.c_void_p]
+o = torch.zeros(256, dtype=torch.int32, device="cuda:0")
+g(o.data_ptr(), None); torch.cuda.synchronize()
+o = o.cpu().numpy()
+print("v_permlane32_swap a:", o[:64].tolist()); print("                  b:", o[64:128].tolist())
+print("v_permlane16_swap a:", o[128:192].tolist()); print("                  b:", o[192:].tolist())
