@@ -70,6 +70,8 @@ _PROTOS = {
     "comms_pulse_create": [_vp, _sz, _sz, _i32, _pp],
     "comms_pulse_run": [_vp, _vp, _sz, _vp],
     "comms_pulse_run_dev": [_vp, _vp, _sz, _vp, _vp],
+    "comms_pulse_set_mixer": [_vp, _f64, _f64],
+    "comms_pulse_get_phase": [_vp, C.POINTER(_f64)],
     "comms_pulse_destroy": [_vp],
     "comms_mixer_create": [_f64, _f64, _i32, _pp],
     "comms_mixer_run": [_vp, _vp, _sz, _vp],

@@ -37,17 +37,6 @@
 
 namespace comms {
 
-// ---------------------------------------------------------------- history
-// new_hist = last HL samples of concat(old_hist[HL], in[n])
-__global__ void fir_hist_update_kernel(const float2* __restrict__ old_hist,
-                                       const float2* __restrict__ in, size_t n,
-                                       float2* __restrict__ new_hist, int HL) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= HL) return;
-    size_t p = n + static_cast<size_t>(j);  // index into the concatenation
-    new_hist[j] = p < static_cast<size_t>(HL) ? old_hist[p] : in[p - HL];
-}
-
 // ---------------------------------------------------------------- direct form
 constexpr int DT = 8;             // consecutive outputs per lane
 constexpr int DTILE = 256 * DT;   // outputs per workgroup
@@ -916,17 +905,33 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(const float2* __rest
 // ---------------------------------------------------------------- pulse shaping (polyphase)
 // Reference: PulseNode::run (src/pulse.rs:82-92) = zero-stuff by sps, then FIR.
 //   out[m*sps + p] = sum_j taps[p + j*sps] * sym[m - j]
+// Output mixer fused into the pulse kernels (comms_pulse_set_mixer): out[i] *= rot(turns0 + i*frac),
+// the MixerNode that follows the PulseNode in a transmit chain (BASELINE config 1).  Phases are the
+// mixer node's 64-bit turns; a lane evaluates its first rotor with one f64 sincos and steps it per
+// grid sweep with a constant f64 rotor; inside a symbol the sps outputs use f32 step rotors.
+struct PulseMix {
+    uint64_t turns0, frac;
+    double sweep_c, sweep_s;  // rot(outputs per grid sweep * frac)
+    int on;
+};
+__device__ __forceinline__ void pulse_rotor_at(uint64_t turns, double& c, double& s) {
+    sincos(static_cast<double>(turns >> 11) * (kTwoPiF * 0x1.0p-53), &s, &c);
+}
+
 __global__ __launch_bounds__(256) void pulse_kernel(const float2* __restrict__ sym,
                                                     const float2* __restrict__ hist, int hist_len,
                                                     const float2* __restrict__ taps, int n_taps,
                                                     int sps, float2* __restrict__ out,
-                                                    size_t n_sym) {
+                                                    size_t n_sym, float2* __restrict__ new_hist, PulseMix mx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    hist_advance(hist, sym, n_sym, new_hist, hist_len);
     float2* tp = reinterpret_cast<float2*>(smem);
     for (int k = threadIdx.x; k < n_taps; k += 256) tp[k] = taps[k];
     __syncthreads();
     const size_t n_out = n_sym * static_cast<size_t>(sps);
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    double rc = 1.0, rs = 0.0;
+    if (mx.on) pulse_rotor_at(mx.turns0 + (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * mx.frac, rc, rs);
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_out;
          i += stride) {
         const size_t m = i / sps;
@@ -940,6 +945,13 @@ __global__ __launch_bounds__(256) void pulse_kernel(const float2* __restrict__ s
             acc.x = __builtin_fmaf(-h.y, x.y, acc.x);
             acc.y = __builtin_fmaf(h.x, x.y, acc.y);
             acc.y = __builtin_fmaf(h.y, x.x, acc.y);
+        }
+        if (mx.on) {  // Mixer::mix arithmetic: f64 product rounded once (src/mixer.rs:77-78)
+            const double yr = acc.x, yi = acc.y;
+            acc = make_float2(static_cast<float>(yr * rc - yi * rs), static_cast<float>(yr * rs + yi * rc));
+            const double nc = rc * mx.sweep_c - rs * mx.sweep_s;
+            rs = rc * mx.sweep_s + rs * mx.sweep_c;
+            rc = nc;
         }
         out[i] = acc;
     }
@@ -959,19 +971,25 @@ struct PulseArgs {
     const float2* sym;
     const float2* hist;
     float2* out;
+    float2* new_hist;
     size_t n_sym;
+    PulseMix mx;           // sweep = rot(gridDim.x * 256 * SPS * frac)
+    float2 step[32];       // rot(p * frac), p < SPS: the outputs of one symbol
     int hist_len, J;       // J rows of taps (multiple of PP_JB, zero rows appended)
     float are[PP_AMAX];    // A[j*SPSP + p] = Re taps[p + j*SPS]
     float aim[PP_AMAX];
 };
 
-template <int SPS, bool REAL>
+template <int SPS, bool REAL, bool MIX>
 __global__ __launch_bounds__(256) void pulse_poly_kernel(const PulseArgs a) {
     constexpr int SPSP = SPS + (SPS & 1);
     __shared__ cf sh[256 + PP_JMAX];
     const int tid = threadIdx.x;
     const int halo = a.J - 1;
     const size_t ntiles = (a.n_sym + 255) / 256;
+    hist_advance(a.hist, a.sym, a.n_sym, a.new_hist, a.hist_len);
+    double rc = 1.0, rs = 0.0;  // rotor of this lane's first output of the current tile
+    if (MIX) pulse_rotor_at(a.mx.turns0 + (static_cast<uint64_t>(blockIdx.x) * 256 + tid) * SPS * a.mx.frac, rc, rs);
     for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const long long m0 = static_cast<long long>(t) * 256;
         __syncthreads();
@@ -1001,6 +1019,14 @@ __global__ __launch_bounds__(256) void pulse_poly_kernel(const PulseArgs a) {
                 }
         }
         const size_t m = static_cast<size_t>(m0) + tid;
+        if (MIX) {
+            const cf r0 = cf{static_cast<float>(rc), static_cast<float>(rs)};
+#pragma unroll
+            for (int p = 0; p < SPS; ++p) acc[p] = cmulf(acc[p], p ? cmulf(r0, to_cf(a.step[p])) : r0);
+            const double nc = rc * a.mx.sweep_c - rs * a.mx.sweep_s;
+            rs = rc * a.mx.sweep_s + rs * a.mx.sweep_c;
+            rc = nc;
+        }
         if (m < a.n_sym) {
             float2* o = a.out + m * SPS;
 #pragma unroll
@@ -1664,6 +1690,9 @@ struct comms_pulse : Handle {
     int cur = 0;
     std::vector<comms_c32> taps;  // host copy (kernel-argument taps of the polyphase kernel)
     bool real_taps = false;
+    // fused output mixer (comms_pulse_set_mixer): phase of the next output, step per output
+    bool mix = false;
+    uint64_t turns = 0, frac = 0;
 };
 
 // Launches pulse_poly_kernel if (sps, taps) fit it; false -> the caller runs the generic kernel.
@@ -1676,6 +1705,7 @@ static bool pulse_poly_try(comms_pulse* h, const float2* sym, size_t n_sym, floa
     comms::PulseArgs a{};
     a.sym = sym;
     a.hist = h->d_hist[h->cur];
+    a.new_hist = h->d_hist[h->cur ^ 1];
     a.out = out;
     a.n_sym = n_sym;
     a.hist_len = h->hist_len;
@@ -1690,10 +1720,25 @@ static bool pulse_poly_try(comms_pulse* h, const float2* sym, size_t n_sym, floa
         }
     const size_t ntiles = (n_sym + 255) / 256;
     const unsigned blocks = static_cast<unsigned>(ntiles < 8u * comms::kNumCU ? ntiles : 8u * comms::kNumCU);
-    if (h->real_taps)
-        comms::pulse_poly_kernel<SPS, true><<<dim3(blocks), dim3(256), 0, s>>>(a);
-    else
-        comms::pulse_poly_kernel<SPS, false><<<dim3(blocks), dim3(256), 0, s>>>(a);
+    if (h->mix) {
+        a.mx.on = 1;
+        a.mx.turns0 = h->turns;
+        a.mx.frac = h->frac;
+        mix_host_rotor(static_cast<uint64_t>(blocks) * 256u * SPS * h->frac, a.mx.sweep_c, a.mx.sweep_s);
+        for (int p = 0; p < SPS; ++p) {
+            double c, sn;
+            mix_host_rotor(static_cast<uint64_t>(p) * h->frac, c, sn);
+            a.step[p] = make_float2(static_cast<float>(c), static_cast<float>(sn));
+        }
+        if (h->real_taps)
+            comms::pulse_poly_kernel<SPS, true, true><<<dim3(blocks), dim3(256), 0, s>>>(a);
+        else
+            comms::pulse_poly_kernel<SPS, false, true><<<dim3(blocks), dim3(256), 0, s>>>(a);
+    } else if (h->real_taps) {
+        comms::pulse_poly_kernel<SPS, true, false><<<dim3(blocks), dim3(256), 0, s>>>(a);
+    } else {
+        comms::pulse_poly_kernel<SPS, false, false><<<dim3(blocks), dim3(256), 0, s>>>(a);
+    }
     return true;
 }
 static bool pulse_poly_launch(comms_pulse* h, const float2* sym, size_t n_sym, float2* out, hipStream_t s) {
@@ -1780,16 +1825,39 @@ comms_status_t comms_pulse_run_dev(comms_pulse_t* h, const comms_c32* d_sym, siz
     if (!pulse_poly_launch(h, sym, n_sym, reinterpret_cast<float2*>(d_out), s)) {
         size_t blocks = (n_out + 255) / 256;
         if (blocks > 8u * kNumCU) blocks = 8u * kNumCU;
+        PulseMix mx{};
+        if (h->mix) {
+            mx.on = 1;
+            mx.turns0 = h->turns;
+            mx.frac = h->frac;
+            mix_host_rotor(static_cast<uint64_t>(blocks) * 256u * h->frac, mx.sweep_c, mx.sweep_s);
+        }
         pulse_kernel<<<dim3(static_cast<unsigned>(blocks)), dim3(256), h->n_taps * sizeof(float2), s>>>(
             sym, h->d_hist[h->cur], h->hist_len, h->d_taps, h->n_taps, h->sps,
-            reinterpret_cast<float2*>(d_out), n_sym);
+            reinterpret_cast<float2*>(d_out), n_sym, h->d_hist[h->cur ^ 1], mx);
     }
     h->toc(s);
-    COMMS_TRY(launch_ok("pulse kernel"));
-    fir_hist_update_kernel<<<dim3((h->hist_len + 255) / 256), dim3(256), 0, s>>>(
-        h->d_hist[h->cur], sym, n_sym, h->d_hist[h->cur ^ 1], h->hist_len);
-    COMMS_TRY(launch_ok("fir_hist_update_kernel"));
+    COMMS_TRY(launch_ok("pulse kernel"));  // (workgroup 0 of the same launch advanced the history)
     h->cur ^= 1;
+    if (h->mix) h->turns += static_cast<uint64_t>(n_out) * h->frac;
+    return COMMS_OK;
+}
+
+// Fuses the MixerNode that follows a PulseNode into the same launch: every later run() returns
+// Mixer::new(phase, dphase) applied to the shaped samples, the phase carried across calls.
+comms_status_t comms_pulse_set_mixer(comms_pulse_t* h, double dphase, double phase) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG(std::isfinite(dphase) && std::isfinite(phase), "dphase/phase must be finite");
+    h->mix = true;
+    h->frac = mix_to_turns(mix_wrap_dphase(dphase));  // Mixer::new wraps dphase (src/mixer.rs:43-51)
+    h->turns = mix_to_turns(phase);
+    return COMMS_OK;
+}
+
+comms_status_t comms_pulse_get_phase(const comms_pulse_t* h, double* out_phase) {
+    COMMS_ARG(h && out_phase, "NULL argument");
+    COMMS_ARG(h->mix, "no mixer is fused into this pulse node");
+    *out_phase = static_cast<double>(h->turns >> 11) * (comms::kMixT * 0x1.0p-53);
     return COMMS_OK;
 }
 

@@ -153,6 +153,12 @@ public:
     PulseNode(PulseNode&& o) noexcept : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), sps_(o.sps_) { o.h_ = nullptr; }
     ~PulseNode() { comms_pulse_destroy(h_); }
 
+    // transmit chain in one launch: the MixerNode::new(dphase, phase) that follows is fused in
+    PulseNode& with_mixer(double dphase, std::optional<double> phase = std::nullopt) {
+        throw_on(comms_pulse_set_mixer(h_, dphase, phase.value_or(0.0)), "PulseNode::with_mixer");
+        return *this;
+    }
+
     Result<std::vector<Complex32>> run(const Complex32& sym) {
         std::vector<Complex32> out(sps_);
         comms_status_t st = comms_pulse_run(h_, c32(&sym), 1, c32(out.data()));
@@ -582,6 +588,10 @@ public:
     BatchPulseNodeDev(BatchPulseNodeDev&& o) noexcept
         : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), sps_(o.sps_), device_(o.device_) { o.h_ = nullptr; }
     ~BatchPulseNodeDev() { comms_pulse_destroy(h_); }
+    BatchPulseNodeDev& with_mixer(double dphase, std::optional<double> phase = std::nullopt) {
+        throw_on(comms_pulse_set_mixer(h_, dphase, phase.value_or(0.0)), "BatchPulseNodeDev::with_mixer");
+        return *this;
+    }
     Result<DeviceBuf<Complex32>> run(const DeviceBuf<Complex32>& sym) {
         DeviceBuf<Complex32> out(sym.size() * sps_, device_);
         comms_status_t st = comms_pulse_run_dev(h_, c32(sym.ptr()), sym.size(), c32(out.ptr()), nullptr);

@@ -162,6 +162,18 @@ class PulseNode(_Handle):
         self.sam_per_sym = int(sam_per_sym)
         check(lib().comms_pulse_create(_ptr(taps), taps.size, self.sam_per_sym, device, C.byref(self._h)))
 
+    def set_mixer(self, dphase, phase=None):
+        """Fuse the MixerNode::new(dphase, phase) that follows this node into its launch (transmit chain)."""
+        check(lib().comms_pulse_set_mixer(self._h, float(dphase), 0.0 if phase is None else float(phase)))
+        return self
+
+    @property
+    def phase(self):
+        """Oscillator phase of the fused mixer for the next output sample."""
+        p = C.c_double()
+        check(lib().comms_pulse_get_phase(self._h, C.byref(p)))
+        return p.value
+
     def run(self, sym):
         """One symbol (scalar) -> sam_per_sym samples, or a batch of symbols."""
         scalar = np.isscalar(sym) or np.ndim(sym) == 0

@@ -122,6 +122,12 @@ impl PulseNode {
         assert_eq!(st, COMMS_OK, "comms_pulse_create failed");
         PulseNode { input: Default::default(), h, sam_per_sym, output: Default::default() }
     }
+    /// Transmit chain in one launch: fuses the `MixerNode::new(dphase, phase)` that follows.
+    pub fn with_mixer(self, dphase: f64, phase: Option<f64>) -> Self {
+        let st = unsafe { comms_pulse_set_mixer(self.h, dphase, phase.unwrap_or(0.0)) };
+        assert_eq!(st, COMMS_OK, "comms_pulse_set_mixer failed");
+        self
+    }
     pub fn run(&mut self, input: &Complex<f32>) -> Result<Vec<Complex<f32>>, NodeError> {
         let mut out = vec![Complex::new(0.0f32, 0.0); self.sam_per_sym];
         let st = unsafe { comms_pulse_run(self.h, input, 1, out.as_mut_ptr()) };

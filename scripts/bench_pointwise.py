@@ -56,6 +56,19 @@ taps = c.rrc_taps(63, 4.0, 0.25)
 p = c.PulseNode(taps, 4)
 m = n // 4
 report("pulse 63 taps x4 (2 B rd + 8 B wr per output)", timeit(lambda: p.run_dev(x.data_ptr(), m, y.data_ptr(), s)), 10 * n, n)
+pm = c.PulseNode(taps, 4).set_mixer(2 * np.pi * 0.1)
+report("pulse x4 + fused mixer (transmit chain, one launch)", timeit(lambda: pm.run_dev(x.data_ptr(), m, y.data_ptr(), s)), 10 * n, n)
+y2 = torch.empty_like(y)
+def two_nodes():
+    p.run_dev(x.data_ptr(), m, y.data_ptr(), s)
+    mx.run_dev(y.data_ptr(), n, y2.data_ptr(), s)
+report("pulse x4 -> mixer as two nodes", timeit(two_nodes), 10 * n, n)
+m1 = (1 << 20) // 4  # BASELINE config 1: 262144 symbols -> 2^20 samples
+report("config 1 size: pulse x4 + fused mixer, 2^20 samples", timeit(lambda: pm.run_dev(x.data_ptr(), m1, y.data_ptr(), s)), 10 * (1 << 20), 1 << 20)
+def two_nodes_c1():
+    p.run_dev(x.data_ptr(), m1, y.data_ptr(), s)
+    mx.run_dev(y.data_ptr(), 1 << 20, y2.data_ptr(), s)
+report("config 1 size: pulse x4 -> mixer as two nodes", timeit(two_nodes_c1), 10 * (1 << 20), 1 << 20)
 # raw IQ formats
 L = lib()
 i16 = torch.zeros(n * 2, dtype=torch.int16, device=dev)

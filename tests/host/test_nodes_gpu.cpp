@@ -316,6 +316,17 @@ static void test_device_resident_chain_and_fft() {
     bool held = true;
     for (size_t i = 0; i < shaped.size(); ++i) held = held && shaped[i] == sym[i / 4];
     CHECK(held);
+    // the transmit chain as one launch: the shaped block times the mixer's oscillator (phase 0.25 + 0.3 i)
+    BatchPulseNodeDev tx(rect_taps(4), 4);
+    tx.with_mixer(0.3, 0.25);
+    std::vector<C> mixed = tx.run(DeviceBuf<C>::from_host(sym)).value().to_host();
+    double mworst = 0.0;
+    for (size_t i = 0; i < mixed.size(); ++i) {
+        const double ph = 0.25 + 0.3 * static_cast<double>(i);
+        const std::complex<double> want = std::complex<double>(sym[i / 4]) * std::complex<double>(std::cos(ph), std::sin(ph));
+        mworst = std::fmax(mworst, std::abs(std::complex<double>(mixed[i]) - want));
+    }
+    CHECK(mworst < 1e-5);
     UpsampleNodeDev up(4);
     std::vector<C> stuffed = up.run(DeviceBuf<C>::from_host(sym)).value().to_host();
     bool zs = stuffed.size() == 4000;

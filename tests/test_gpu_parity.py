@@ -342,6 +342,32 @@ def test_pulse_vs_oracle(c, n_taps, sps, cplx):
         c.PulseNode(taps, 0)
 
 
+@pytest.mark.parametrize("n_taps,sps,cplx", [(63, 4, False), (63, 4, True), (255, 8, False), (17, 3, True), (32, 2, False),
+                                             (100, 5, False), (64, 32, True), (63, 7, False), (400, 2, True), (5, 1, False)])
+def test_pulse_with_fused_mixer_is_pulse_node_then_mixer_node(c, n_taps, sps, cplx):
+    """comms_pulse_set_mixer: PulseNode -> MixerNode (the transmit chain of BASELINE config 1) as one launch, on the
+    polyphase kernel and on the generic one (sps 7 / 1, 400 taps); phase and filter state carried across calls."""
+    rng = np.random.default_rng(3 * n_taps + sps)
+    taps = oracle.rrc_taps(n_taps, float(max(sps, 2)), 0.25)
+    if cplx:
+        taps = (taps * np.exp(0.3j * np.arange(n_taps))).astype(np.complex64)
+    n_sym = 40000
+    sym = rand_c(rng, n_sym)
+    dphase, phase = 2 * np.pi * 0.1 + 7 * 2 * np.pi, 0.4  # dphase beyond 2 pi: wrapped as Mixer::new does
+    node = c.PulseNode(taps, sps).set_mixer(dphase, phase)
+    cuts = [0, 1, 999, 20000, n_sym]
+    got = np.concatenate([node.run(sym[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+    omix = oracle.Mixer(phase, dphase)
+    want = omix.mix(oracle.pulse(sym, taps, sps, oracle.default_state(taps)))
+    fir_close(got, want, taps, sym)
+    # the same through the two reference nodes on the GPU, and the oscillator phase afterwards
+    two = c.MixerNode(dphase, phase).run(c.PulseNode(taps, sps).run(sym))
+    fir_close(got, two, taps, sym)
+    assert circ(np.array([node.phase - omix.phase.value]))[0] < 1e-6
+    with pytest.raises(c.CommsError):
+        c.PulseNode(taps, sps).phase  # no mixer fused
+
+
 # ------------------------------------------------------------------ mixer
 @pytest.mark.parametrize("key", ["mixer_phase0", "mixer_phase0p1"])
 def test_mixer_reference_golden(c, kats, key):
@@ -628,6 +654,8 @@ def test_config1_prbs_bpsk_rrc_mixer_chain(c, kats):
     got = c.MixerNode(dphase).run(shaped)
     assert got.size == 1 << 20
     fir_close(got, want, taps_o, sym)
+    # the same transmit chain as one launch (mixer fused into the pulse node)
+    fir_close(c.PulseNode(taps_g, 4).set_mixer(dphase).run(sym), want, taps_o, sym)
     # the literal example: 32 taps, upsample then batch_fir, no mixer (single_thread_bpsk.rs:17-39)
     taps32 = c.rrc_taps(32, 4.0, 0.25)
     up = c.UpsampleNode(4).run(sym[:4096])

@@ -102,8 +102,14 @@ def test_pulse_random_sweep(c):
         n = int(rng.integers(1, 4000))
         sym = rand_c(rng, n)
         node, st = c.PulseNode(taps, sps), oracle.default_state(taps)
+        mixed = rng.integers(0, 2) == 1  # half the cases with the mixer fused in (transmit chain)
+        if mixed:
+            dphase, phase = float(rng.uniform(-20, 20)), float(rng.uniform(-10, 10))
+            node.set_mixer(dphase, phase)
+            omix = oracle.Mixer(phase, dphase)
         got, want = [], []
         for a, b in zip(*(lambda cs: (cs[:-1], cs[1:]))(cuts_of(rng, n))):
             got.append(node.run(sym[a:b]))
-            want.append(oracle.pulse(sym[a:b], taps, sps, st))
+            w = oracle.pulse(sym[a:b], taps, sps, st)
+            want.append(omix.mix(w) if mixed else w)
         fir_close(np.concatenate(got), np.concatenate(want), taps, sym)
