@@ -1355,7 +1355,8 @@ static int fir_pick(const comms_fir* h, size_t n) {
         } else {
             const double t = static_cast<double>(h->n_eff), nn = static_cast<double>(n);
             const double direct_ps = 6.5e6 + 0.025e6 * t + nn * (3.3 + 0.038 * t);
-            const double os_ps = 12.4e6 + nn * 2.0;
+            // (4-wave workgroups, used up to 1024 segments, take about 1.1 us off the fixed part)
+            const double os_ps = (nn <= 768.0 * 4 * kNumCU ? 11.3e6 : 12.4e6) + nn * 2.0;
             algo = direct_ps < os_ps ? COMMS_FIR_DIRECT : COMMS_FIR_OVERLAP_SAVE;
         }
     }
@@ -1437,17 +1438,20 @@ struct Os1024Plan {
 };
 static Os1024Plan os1024_plan(const comms_fir* h, size_t n) {
     static const bool short_halo_ok = tune_int("COMMS_OS1024_SHORT_HALO", 1) != 0;
-    static const int wpb = tune_int("COMMS_OS1024_WPB", 16);
+    static const int wpb_env = tune_int("COMMS_OS1024_WPB", 0);
     static const int min_run = tune_int("COMMS_OS1024_MINRUN", 1);
     // ticketed segments pay once there are a few segments per wave slot (they trim the tail of the launch):
     // measured -5 % at 2^22 samples, -11 % at 2^24, -9 % at 2^26, +3 % at 2^21 (scripts/ab_fir.py)
     static const size_t dyn_minseg = static_cast<size_t>(tune_int("COMMS_OS1024_DYN_MINSEG", 4096));
     Os1024Plan p{};
     p.hr2 = short_halo_ok && h->n_eff <= 129;
-    p.wpb = wpb;
     p.min_run = static_cast<size_t>(min_run);
     const size_t wv = p.hr2 ? 896 : comms::WV;
     p.nseg = (n + wv - 1) / wv;
+    // up to one segment per SIMD of the chip, 4-wave workgroups spread the batch over four times as many
+    // CUs, one wave per SIMD (8.6-9.3 us instead of 9.8-10.4 up to 2^19 samples; slower from 2^20 on)
+    const int wpb = wpb_env ? wpb_env : p.nseg <= 4u * kNumCU ? 4 : 16;
+    p.wpb = wpb;
     const int mode = os1024_dynamic_mode();
     p.dyn = mode != 0 && wpb == 16 && p.nseg >= dyn_minseg;
     p.nt = mode == 2;
