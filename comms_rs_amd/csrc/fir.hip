@@ -655,7 +655,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
 // (Loading the NEXT segment's rows into spare registers before transforming this one -- the wait
 // then sits after the 16 - HR stores as a counted vmcnt -- was measured too: 3 us SLOWER at 2^24,
 // the 32 register moves per segment cost more than the covered latency.)
-template <int HR, bool TRACE, bool NT = false>
+template <int HR, bool TRACE>
 __global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(const float2* __restrict__ in,
                                                                  const float2* __restrict__ hist, int hist_len,
                                                                  float2* __restrict__ out, size_t n, WTables tb,
@@ -707,12 +707,7 @@ __global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(const float2* _
         os1024_core(v, lds, tw1, hsp, tw2, l, nostamp);
         float2* o = out + seg * WVK + l;
 #pragma unroll
-        for (int a = HR; a < 16; ++a) {
-            if (NT)
-                __builtin_nontemporal_store(v[R16_POS(a)], reinterpret_cast<cf*>(o + 64 * (a - HR)));
-            else
-                o[64 * (a - HR)] = to_f2(v[R16_POS(a)]);
-        }
+        for (int a = HR; a < 16; ++a) o[64 * (a - HR)] = to_f2(v[R16_POS(a)]);
         seg = seg_next;
         ++count;
     }
@@ -1099,9 +1094,9 @@ static size_t os1024_runs(int wpb, size_t nseg, size_t min_run) {
     return runs;
 }
 
-// 0: fixed runs (fir_os1024_kernel), 1: ticketed segments (fir_os1024_dyn_kernel), 2: ... with
-// non-temporal stores.  COMMS_OS1024_DYNAMIC sets it; comms_debug_os1024_dynamic() switches it at run
-// time so that scripts/ab_fir.py can interleave the variants launch by launch.
+// 0: fixed runs (fir_os1024_kernel), 1: ticketed segments (fir_os1024_dyn_kernel).  COMMS_OS1024_DYNAMIC
+// sets it; comms_debug_os1024_dynamic() switches it at run time so that scripts/ab_fir.py can interleave
+// the variants launch by launch.
 static int tune_int(const char* name, int dflt);
 static std::atomic<int> g_os1024_dynamic{-1};
 static int os1024_dynamic_mode() {
@@ -1115,7 +1110,7 @@ static int os1024_dynamic_mode() {
 extern "C" void comms_debug_os1024_dynamic(int mode) { g_os1024_dynamic.store(mode, std::memory_order_relaxed); }
 
 // One launch of fir_os1024_dyn_kernel: one 16-wave workgroup per CU (fewer for short inputs).
-template <int HR, bool TRACE = false, bool NT = false>
+template <int HR, bool TRACE = false>
 static comms_status_t launch_os1024_dyn(hipStream_t s, const float2* in, const float2* hist, int n_eff, float2* o,
                                         size_t n, const comms::WTables& tb, float2* nh, void* trace_buf = nullptr,
                                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
@@ -1123,17 +1118,17 @@ static comms_status_t launch_os1024_dyn(hipStream_t s, const float2* in, const f
     const size_t lds = (2112 + 16 * W_LDS + 1) * sizeof(float2);  // tables, exchange buffers, ticket counter
     static DeviceOnce attr_once;
     if (attr_once.need()) {
-        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os1024_dyn_kernel<HR, TRACE, NT>),
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os1024_dyn_kernel<HR, TRACE>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     }
     const size_t nseg = (n + (1024 - 64 * HR) - 1) / (1024 - 64 * HR);
     const size_t want = (nseg + 15) / 16;
     const dim3 grid(static_cast<unsigned>(want < static_cast<size_t>(kNumCU) ? want : kNumCU));
     if (ev_start)  // timed launch: the events take the kernel's own begin / end timestamps
-        hipExtLaunchKernelGGL((fir_os1024_dyn_kernel<HR, TRACE, NT>), grid, dim3(1024), static_cast<uint32_t>(lds), s, ev_start,
+        hipExtLaunchKernelGGL((fir_os1024_dyn_kernel<HR, TRACE>), grid, dim3(1024), static_cast<uint32_t>(lds), s, ev_start,
                               ev_stop, 0u, in, hist, n_eff, o, n, tb, nh, trace_buf);
     else
-        fir_os1024_dyn_kernel<HR, TRACE, NT><<<grid, dim3(1024), lds, s>>>(in, hist, n_eff, o, n, tb, nh, trace_buf);
+        fir_os1024_dyn_kernel<HR, TRACE><<<grid, dim3(1024), lds, s>>>(in, hist, n_eff, o, n, tb, nh, trace_buf);
     return COMMS_OK;
 }
 
@@ -1432,7 +1427,6 @@ comms_status_t comms_fir_set_algo(comms_fir_t* h, int32_t algo) {
 struct Os1024Plan {
     bool hr2;     // two halo rows (<= 129 taps): 896 new samples per segment instead of 768
     bool dyn;     // ticketed segments (fir_os1024_dyn_kernel) rather than fixed runs (fir_os1024_kernel)
-    bool nt;      // ... with non-temporal stores (experiment: COMMS_OS1024_DYNAMIC=2)
     int wpb;      // waves per workgroup of the fixed-run kernel
     size_t min_run, nseg;
 };
@@ -1454,7 +1448,6 @@ static Os1024Plan os1024_plan(const comms_fir* h, size_t n) {
     p.wpb = wpb;
     const int mode = os1024_dynamic_mode();
     p.dyn = mode != 0 && wpb == 16 && p.nseg >= dyn_minseg;
-    p.nt = mode == 2;
     return p;
 }
 
@@ -1514,9 +1507,7 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
         hipEvent_t ea = nullptr, eb = nullptr;
         if (h->timed() && pl.wpb == 16) h->next_events(ea, eb);
         if (!ea) h->tic(s);
-        if (pl.dyn && pl.nt && !pl.hr2)
-            COMMS_TRY((launch_os1024_dyn<4, false, true>(s, in, hist, h->n_eff, o, n, tb, nh, nullptr, ea, eb)));
-        else if (pl.hr2 && pl.dyn)
+        if (pl.hr2 && pl.dyn)
             COMMS_TRY((launch_os1024_dyn<2>(s, in, hist, h->n_eff, o, n, tb, nh, nullptr, ea, eb)));
         else if (pl.hr2)
             COMMS_TRY((launch_os1024<0, 2>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb)));

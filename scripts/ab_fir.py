@@ -1,5 +1,5 @@
 """A/B timing of fir_os1024 variants, interleaved launch by launch so that clock and box drift cancel.
-usage: python scripts/ab_fir.py [n_taps] [log2 n] [reps]   (modes: 0 fixed runs, 1 ticketed, 2 ticketed + nt stores)"""
+usage: python scripts/ab_fir.py [n_taps] [log2 n] [reps]   (modes: 0 fixed runs, 1 ticketed segments)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -7,7 +7,7 @@ import comms_rs_amd as c
 n_taps = int(sys.argv[1]) if len(sys.argv) > 1 else 255
 n = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 24)
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 300
-modes = [int(m) for m in os.environ.get("MODES", "0,1,2").split(",")]
+modes = [int(m) for m in os.environ.get("MODES", "0,1").split(",")]
 setm = c.lib().comms_debug_os1024_dynamic; setm.argtypes = [C.c_int]; setm.restype = None
 x = torch.empty(n, dtype=torch.complex64, device="cuda:0"); y = torch.empty_like(x)
 c.synth_iq_dev(x.data_ptr(), n, 0)
