@@ -470,7 +470,8 @@ struct WaveTrace {
 // filter spectrum, W64 table: 16.5 KiB); every wave has a private 8.5 KiB
 // exchange buffer and runs on its own -- no workgroup barrier after set-up.
 // HR = halo rows of 64 samples: 4 (up to 257 taps, 768 new samples per segment) or, for the plain
-// FIR with up to 129 taps, 2 (896 new samples per segment: the same transforms yield 1/6 more).
+// FIR, as few as the taps need: 3 / 2 / 1 rows for <= 193 / 129 / 65 taps (832 / 896 / 960 new samples
+// per segment from the same two transforms).
 template <int WPB, int MINW, int MODE, int HR = 4>
 __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2* __restrict__ in,
                                                                     const float2* __restrict__ hist,
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
                                                                     WTables tb,
                                                                     float2* __restrict__ new_hist,
                                                                     ChainArgs ch) {
-    static_assert(HR == 4 || (HR == 2 && MODE == 0), "the short halo is for the plain FIR only");
+    static_assert(HR == 4 || (HR >= 1 && HR < 4 && (MODE & ~CH_TRACE) == 0), "the short halos are for the plain FIR only");
     constexpr int WVK = 1024 - 64 * HR, HALO = 64 * HR, NEWR = 16 - HR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WaveTrace<(MODE & CH_TRACE) != 0> trace;
@@ -1425,7 +1426,7 @@ comms_status_t comms_fir_set_algo(comms_fir_t* h, int32_t algo) {
 
 // How comms_fir_run_dev launches the 1024-point overlap-save FIR for n samples.
 struct Os1024Plan {
-    bool hr2;     // two halo rows (<= 129 taps): 896 new samples per segment instead of 768
+    int hr;       // halo rows of 64 samples: 1 / 2 / 3 / 4 for <= 65 / 129 / 193 / 257 taps, 1024 - 64 hr new samples per segment
     bool dyn;     // ticketed segments (fir_os1024_dyn_kernel) rather than fixed runs (fir_os1024_kernel)
     int wpb;      // waves per workgroup of the fixed-run kernel
     size_t min_run, nseg;
@@ -1438,9 +1439,9 @@ static Os1024Plan os1024_plan(const comms_fir* h, size_t n) {
     // measured -5 % at 2^22 samples, -11 % at 2^24, -9 % at 2^26, +3 % at 2^21 (scripts/ab_fir.py)
     static const size_t dyn_minseg = static_cast<size_t>(tune_int("COMMS_OS1024_DYN_MINSEG", 4096));
     Os1024Plan p{};
-    p.hr2 = short_halo_ok && h->n_eff <= 129;
+    p.hr = !short_halo_ok ? 4 : h->n_eff <= 65 ? 1 : h->n_eff <= 129 ? 2 : h->n_eff <= 193 ? 3 : 4;
     p.min_run = static_cast<size_t>(min_run);
-    const size_t wv = p.hr2 ? 896 : comms::WV;
+    const size_t wv = 1024 - 64 * static_cast<size_t>(p.hr);
     p.nseg = (n + wv - 1) / wv;
     // up to one segment per SIMD of the chip, 4-wave workgroups spread the batch over four times as many
     // CUs, one wave per SIMD (8.6-9.3 us instead of 9.8-10.4 up to 2^19 samples; slower from 2^20 on)
@@ -1507,14 +1508,16 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
         hipEvent_t ea = nullptr, eb = nullptr;
         if (h->timed() && pl.wpb == 16) h->next_events(ea, eb);
         if (!ea) h->tic(s);
-        if (pl.hr2 && pl.dyn)
-            COMMS_TRY((launch_os1024_dyn<2>(s, in, hist, h->n_eff, o, n, tb, nh, nullptr, ea, eb)));
-        else if (pl.hr2)
-            COMMS_TRY((launch_os1024<0, 2>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb)));
-        else if (pl.dyn)
-            COMMS_TRY((launch_os1024_dyn<4>(s, in, hist, h->n_eff, o, n, tb, nh, nullptr, ea, eb)));
-        else
-            COMMS_TRY(launch_os1024<0>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb));
+        switch (pl.dyn ? pl.hr : -pl.hr) {
+            case 1: COMMS_TRY((launch_os1024_dyn<1>(s, in, hist, h->n_eff, o, n, tb, nh, nullptr, ea, eb))); break;
+            case 2: COMMS_TRY((launch_os1024_dyn<2>(s, in, hist, h->n_eff, o, n, tb, nh, nullptr, ea, eb))); break;
+            case 3: COMMS_TRY((launch_os1024_dyn<3>(s, in, hist, h->n_eff, o, n, tb, nh, nullptr, ea, eb))); break;
+            case 4: COMMS_TRY((launch_os1024_dyn<4>(s, in, hist, h->n_eff, o, n, tb, nh, nullptr, ea, eb))); break;
+            case -1: COMMS_TRY((launch_os1024<0, 1>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb))); break;
+            case -2: COMMS_TRY((launch_os1024<0, 2>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb))); break;
+            case -3: COMMS_TRY((launch_os1024<0, 3>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb))); break;
+            default: COMMS_TRY((launch_os1024<0, 4>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb))); break;
+        }
         if (!ea) h->toc(s);
         COMMS_TRY(launch_ok("fir_os1024_kernel"));
     } else if (algo == COMMS_FIR_OS16K) {

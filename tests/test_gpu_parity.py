@@ -227,17 +227,18 @@ def test_fir_auto_selection_and_errors(c):
         c.BatchFirNode(np.ones(5000, np.complex64)).set_algo(c.FIR_DIRECT)
 
 
-@pytest.mark.parametrize("n_taps", [255, 100])
+@pytest.mark.parametrize("n_taps", [255, 160, 100, 40])
 def test_fir_os1024_ticketed_and_fixed_run_kernels_agree(c, n_taps):
     """Long batches run fir_os1024_dyn_kernel (waves draw segments from a ticket counter), short ones
     fir_os1024_kernel (fixed runs): the same transforms per segment, so bit-identical outputs -- across two
-    calls (carried state), with a partial last segment, for both halo widths (255 taps: 4 rows, 100: 2)."""
+    calls (carried state), with a partial last segment, for every halo width (255 / 160 / 100 / 40 taps: 4 / 3 / 2 / 1
+    rows of 64 samples, i.e. 768 / 832 / 896 / 960 new samples per 1024-point segment)."""
     import ctypes
     import torch
 
     setm = c.lib().comms_debug_os1024_dynamic
     setm.argtypes, setm.restype = [ctypes.c_int], None
-    wv = 768 if n_taps > 129 else 896
+    wv = 1024 - 64 * (1 if n_taps <= 65 else 2 if n_taps <= 129 else 3 if n_taps <= 193 else 4)
     n1, n2 = 4200 * wv + 333, 4100 * wv  # both above the 4096-segment threshold; n1 ends inside a segment
     taps = (oracle.rrc_taps(n_taps, 8.0, 0.35) * np.exp(0.3j * np.arange(n_taps))).astype(np.complex64)
     x = torch.empty(n1 + n2, dtype=torch.complex64, device="cuda:0")

@@ -129,7 +129,7 @@ def test_fir_ticketed_kernel_random_sweep(c):
     try:
         for case in range(6):
             n_taps = int(rng.integers(9, 258))
-            wv = 768 if n_taps > 129 else 896
+            wv = 1024 - 64 * (1 if n_taps <= 65 else 2 if n_taps <= 129 else 3 if n_taps <= 193 else 4)
             n1 = int(rng.integers(4096, 5200)) * wv + (0 if case % 3 == 0 else int(rng.integers(1, wv)))
             n2 = int(rng.integers(4096, 4500)) * wv + int(rng.integers(0, 2)) * int(rng.integers(1, wv))
             taps = rand_c(rng, n_taps) if case % 2 else rand_c(rng, n_taps).real.astype(np.complex64)
