@@ -40,6 +40,8 @@ COMMS_PK2(csub, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]")
 COMMS_PK2(cadd_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")
 // a + (+i)*b = (a.re - b.im, a.im + b.re)
 COMMS_PK2(cadd_pi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")
+// i*(a - b) = (b.im - a.im, a.re - b.re)
+COMMS_PK2(crot_sub, "v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[1,0] neg_hi:[0,1]")
 // (a.re*b.re, a.re*b.im)  and  (a.re*b.re, -a.re*b.im): first halves of a*b and a*conj(b)
 COMMS_PK2(cmul_lo, "v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]")
 COMMS_PK2(cmulc_lo, "v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[1,0]")

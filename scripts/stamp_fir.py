@@ -18,8 +18,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().reshape(runs, 10).astype(np.float64)
 segs = 21846 / runs
-names = ["global loads landed", "R16+tw+E1 writes", "E1 reads", "R16+tw+E2 writes", "E2 reads", "R4+H+R4+E3 writes",
-         "E3 reads+tw", "R16+E4 writes", "E4 reads+tw", "R16+stores retired"]
+names = ["global loads landed", "R16+tw+E1 writes", "E1 reads", "R16+tw (stage 2)", "R4 across lanes", "H + inverse R4 across lanes",
+         "conj tw (stage 2)", "R16+E4 writes", "E4 reads+tw", "R16+stores retired"]
 tot = d.sum(1).mean()
 print("cycles per segment per wave: %.0f (s_memtime ticks)" % (tot / segs))
 for i, nm in enumerate(names):
