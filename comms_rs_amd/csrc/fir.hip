@@ -387,7 +387,9 @@ __device__ __forceinline__ void lane_swap16(cf& a, cf& b) {
 // One segment through the filter: the 16 rows v[a] (samples 64a + lane of the 1024-point segment)
 // -> forward transform, spectrum multiply, inverse transform -> v[R16_POS(a)] = filtered row a.
 // `lds` is the calling wave's private exchange buffer; stamp(i) marks the diagnostic phases.
-template <class Stamp>
+// hsp[i * HS + l] is the spectrum factor of register i (LDS table, HS = 64; or global memory, HS = 1024: the
+// 16384-point kernel, whose 16 waves each filter one 1024-point slice with their own part of the spectrum).
+template <int HS = 64, class Stamp>
 __device__ __forceinline__ void os1024_core(cf (&v)[16], cf* lds, const cf* tw1, const cf* hsp, const cf* tw2, int l,
                                             Stamp&& stamp) {
     const int q0 = l & 15, q1 = l >> 4;  // stage 2 and 3: lane (k0, c) = (q0, q1)
@@ -439,7 +441,7 @@ __device__ __forceinline__ void os1024_core(cf (&v)[16], cf* lds, const cf* tw1,
     }
     stamp(4);  // radix-4 across lanes
 #pragma unroll
-    for (int i = 0; i < 16; ++i) z[i] = cmulf(z[i], hsp[i * 64 + l]);
+    for (int i = 0; i < 16; ++i) z[i] = cmulf(z[i], hsp[i * HS + l]);
     // ---- the mirror image
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -803,67 +805,8 @@ struct XTables {
     const cf* tw2;   // [16][4]    W64^{c*k1}
     const cf* ta;    // [16][16]   W256^{wave*k0}           (stage-1 twiddle, high part)
     const cf* tb;    // [16][64]   W16384^{lane*k0}         (stage-1 twiddle, low part), index [k0][lane]
-    const cf* hdev;  // [16][1024] H[k0 + 16 k']/16384 at [4j + k2][tid], k0 = tid>>6, k' = (q1+4j) + 16 q0 + 256 k2
+    const cf* hdev;  // [16][1024] H[k0 + 16 k']/16384 at [4t + m][tid], k0 = tid>>6, k' = the bin os1024_core leaves in register 4t + m of lane tid&63
 };
-
-// in: v[a] = z[64a + l];  out: v[4j + k2] = Z[(q1 + 4j) + 16 q0 + 256 k2]   (forward)
-__device__ __forceinline__ void wave_fft1024_fwd(cf (&v)[16], cf* lds, const cf* tw1, const cf* tw2, int l, int q0,
-                                                 int q1) {
-    radix16<-1>(v);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        cf x = v[R16_POS(k)];
-        if (k) x = cmulf(x, tw1[k * 64 + l]);
-        lds[k * W_S1 + l] = x;
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int b = 0; b < 16; ++b) v[b] = lds[q0 * W_S1 + 4 * b + q1];
-    wave_lds_sync();
-    radix16<-1>(v);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        cf x = v[R16_POS(k)];
-        if (k) x = cmulf(x, tw2[k * 4 + q1]);
-        lds[q1 * W_P + 17 * q0 + k] = x;
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[4 * j + c] = lds[c * W_P + 17 * (q1 + 4 * j) + q0];
-    wave_lds_sync();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) radix4<-1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-}
-// in: v[4j + k2] = Z[...] as above;  out: v[R16_POS(a)] = z[64a + l]   (unnormalised inverse)
-__device__ __forceinline__ void wave_fft1024_inv(cf (&v)[16], cf* lds, const cf* tw1, const cf* tw2, int l, int q0,
-                                                 int q1) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        radix4<1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) lds[c * W_P + 17 * (q1 + 4 * j) + q0] = v[4 * j + c];
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        cf x = lds[q1 * W_P + 17 * q0 + k];
-        v[k] = k ? cmulcf(x, tw2[k * 4 + q1]) : x;
-    }
-    wave_lds_sync();
-    radix16<1>(v);
-#pragma unroll
-    for (int b = 0; b < 16; ++b) lds[q0 * W_S4 + 4 * b + q1] = v[R16_POS(b)];
-    wave_lds_sync();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        cf x = lds[k * W_S4 + l];
-        v[k] = k ? cmulcf(x, tw1[k * 64 + l]) : x;
-    }
-    wave_lds_sync();
-    radix16<1>(v);
-}
 
 __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(const float2* __restrict__ in,
                                                             const float2* __restrict__ hist, int hist_len,
@@ -878,7 +821,6 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(const float2* __rest
     cf* bufs = tbl + 1024;                  // [16][X_BUF]
     const int tid = threadIdx.x;
     const int l = tid & 63, wave = tid >> 6;
-    const int q0 = l & 15, q1 = l >> 4;
     cf* buf = bufs + wave * X_BUF;
     if (!accumulate) hist_advance(hist, in, n, new_hist, hist_len);
     tw1[tid] = tb.tw1[tid];
@@ -919,10 +861,7 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(const float2* __rest
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = buf[64 * a + l];
         wave_lds_sync();
-        wave_fft1024_fwd(v, buf, tw1, tw2, l, q0, q1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = cmulf(v[r], tb.hdev[r * 1024 + tid]);
-        wave_fft1024_inv(v, buf, tw1, tw2, l, q0, q1);
+        os1024_core<1024>(v, buf, tw1, tb.hdev + 64 * wave, tw2, l, [](int) {});
 #pragma unroll
         for (int a = 0; a < 16; ++a) buf[64 * a + l] = v[R16_POS(a)];
         __syncthreads();
@@ -1349,12 +1288,13 @@ static comms_status_t fir_prepare_os16k(comms_fir* h) {
         const int count = N - first < X_PART ? N - first : X_PART;
         tap_spectrum_range(h, first, count, XF, re, im);
         for (int tid = 0; tid < 1024; ++tid) {
-            const int k0 = tid >> 6, l = tid & 63, q0 = l & 15, q1 = l >> 4;
-            for (int j = 0; j < 4; ++j)
-                for (int k2 = 0; k2 < 4; ++k2) {
-                    const int kp = (q1 + 4 * j) + 16 * q0 + 256 * k2;  // index inside the slice transform
+            const int k0 = tid >> 6, l = tid & 63;
+            for (int t = 0; t < 4; ++t)
+                for (int m = 0; m < 4; ++m) {
+                    // bin of the slice transform in register 4t + m of lane l (os1024_core, stage 3)
+                    const int kp = (l & 15) + 16 * (2 * m + 8 * ((l >> 4) & 1) + (l >> 5)) + 256 * t;
                     const int k = k0 + 16 * kp;
-                    hdev[(4 * j + k2) * 1024 + tid] =
+                    hdev[(4 * t + m) * 1024 + tid] =
                         make_float2(static_cast<float>(re[k] / XF), static_cast<float>(im[k] / XF));
                 }
         }
