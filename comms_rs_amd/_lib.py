@@ -9,11 +9,12 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcomms_hip.so")
+# COMMS_HIP_LIB selects another build of the same ABI (e.g. lib/libcomms_hip_diag.so, `make diag`)
+LIB_PATH = os.environ.get("COMMS_HIP_LIB") or os.path.join(_HERE, "lib", "libcomms_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 COMMS_OK, COMMS_ERR_ARG, COMMS_ERR_DEVICE = 0, 1, 2
-FIR_AUTO, FIR_DIRECT, FIR_OVERLAP_SAVE, FIR_OS1024, FIR_OS4096, FIR_OS16K = 0, 1, 2, 3, 4, 5
+FIR_AUTO, FIR_DIRECT, FIR_OVERLAP_SAVE, FIR_OS1024, FIR_OS4096, FIR_OS16K, FIR_OS1024_FIXED = 0, 1, 2, 3, 4, 5, 6
 STREAM_HANDLE = C.c_void_p(-1).value  # COMMS_STREAM_HANDLE: the handle's own stream
 
 
@@ -77,6 +78,7 @@ _PROTOS = {
     "comms_mixer_run": [_vp, _vp, _sz, _vp],
     "comms_mixer_run_dev": [_vp, _vp, _sz, _vp, _vp],
     "comms_mixer_get_phase": [_vp, C.POINTER(_f64)],
+    "comms_mixer_set_phase": [_vp, _f64],
     "comms_mixer_destroy": [_vp],
     "comms_decimate_out_len": [_sz, _sz, _psz],
     "comms_upsample_out_len": [_sz, _sz, _psz],
@@ -87,6 +89,8 @@ _PROTOS = {
     "comms_fmdemod_create": [_i32, _pp],
     "comms_fmdemod_run": [_vp, _vp, _sz, _vp],
     "comms_fmdemod_run_dev": [_vp, _vp, _sz, _vp, _vp],
+    "comms_fmdemod_get_prev": [_vp, _vp],
+    "comms_fmdemod_set_prev": [_vp, _vp],
     "comms_fmdemod_destroy": [_vp],
     "comms_fft_create": [_sz, _i32, _i32, _pp],
     "comms_fft_run": [_vp, _vp, _sz, _vp],
@@ -102,6 +106,11 @@ _PROTOS = {
     "comms_chain_run_dev": [_vp, _vp, _sz, _vp, _vp],
     "comms_chain_run": [_vp, _vp, _sz, _vp],
     "comms_chain_set_fir_state": [_vp, _vp, _sz],
+    "comms_chain_get_fir_state": [_vp, _vp, _sz],
+    "comms_chain_get_phase": [_vp, C.POINTER(_f64)],
+    "comms_chain_set_phase": [_vp, _f64],
+    "comms_chain_get_fm_prev": [_vp, _vp],
+    "comms_chain_set_fm_prev": [_vp, _vp],
     "comms_chain_destroy": [_vp],
     "comms_iq_i16_to_c32": [_vp, _sz, C.c_float, _vp, _i32],
     "comms_iq_c32_to_i16": [_vp, _sz, C.c_float, _vp, _i32],

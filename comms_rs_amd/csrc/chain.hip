@@ -15,8 +15,17 @@
 #include <vector>
 
 #include "common.hpp"
+#include "fir_handle.hpp"
 
 using namespace comms;
+
+// four-kernel path with the mixer in front: the FIR node's own history holds MIXED samples, so the
+// chain keeps the last N RAW input samples beside it (what comms_chain_{get,set}_fir_state speak)
+__global__ __launch_bounds__(256) void chain_raw_hist_kernel(const float2* __restrict__ old_hist,
+                                                             const float2* __restrict__ in, size_t n,
+                                                             float2* __restrict__ new_hist, int HL) {
+    hist_advance(old_hist, in, n, new_hist, HL);
+}
 
 struct comms_chain : Handle {
     bool fused = false;
@@ -34,6 +43,8 @@ struct comms_chain : Handle {
     double dphase = 0.0;  // wrapped, as the mixer steps it
     bool fm_demod = false, mixer_after = false;
     Scratch t1, t2, t3;
+    float2* raw_hist[2] = {nullptr, nullptr};  // unfused + mixer first: last n_eff raw inputs, time order
+    int raw_cur = 0;
 };
 
 static void free_chain(comms_chain* h) {
@@ -43,6 +54,8 @@ static void free_chain(comms_chain* h) {
     (void)use_device(h->device);
     if (h->d_prev[0]) (void)hipFree(h->d_prev[0]);
     if (h->d_prev[1]) (void)hipFree(h->d_prev[1]);
+    if (h->raw_hist[0]) (void)hipFree(h->raw_hist[0]);
+    if (h->raw_hist[1]) (void)hipFree(h->raw_hist[1]);
     h->t1.release();
     h->t2.release();
     h->t3.release();
@@ -90,6 +103,12 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
     } else if (st == COMMS_OK) {
         st = comms_mixer_create(dphase, phase, device, &h->mixer);
         if (st == COMMS_OK && h->fm_demod) st = comms_fmdemod_create(device, &h->fm);
+        for (int i = 0; i < 2 && st == COMMS_OK && !h->mixer_after; ++i) {
+            const size_t bytes = static_cast<size_t>(h->fir->n_eff) * sizeof(float2);
+            hipError_t e = hipMalloc(&h->raw_hist[i], bytes);
+            if (e == hipSuccess) e = hipMemset(h->raw_hist[i], 0, bytes);
+            if (e != hipSuccess) st = fail(COMMS_ERR_DEVICE, "chain state alloc: %s", hipGetErrorString(e));
+        }
     }
     if (st != COMMS_OK) {
         free_chain(h);
@@ -118,7 +137,12 @@ comms_status_t comms_chain_run_dev(comms_chain_t* h, const comms_c32* d_in, size
     COMMS_ARG(n % h->rate == 0, "n (%zu) must be a multiple of the decimation rate %zu", n, h->rate);
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
-    void* s = stream == COMMS_STREAM_HANDLE ? static_cast<void*>(h->stream) : stream;
+    COMMS_ARG(!ranges_overlap(d_in, n * sizeof(comms_c32), d_out,
+                              (n / h->rate) * (h->fm_demod ? sizeof(float) : sizeof(comms_c32))),
+              "the chain cannot run in place");
+    hipStream_t hs = nullptr;
+    COMMS_TRY(h->enter(stream, &hs));  // the stages' state (history, prev) advances in stream order
+    void* s = static_cast<void*>(hs);
     if (h->fused) {
         COMMS_TRY((h->decim ? comms_fir_run_decim_dev : comms_fir_run_fused_dev)(
             h->fir, d_in, n, d_out, h->mode, h->turns, h->frac, static_cast<uint32_t>(h->rate), h->d_prev[h->cur],
@@ -138,6 +162,10 @@ comms_status_t comms_chain_run_dev(comms_chain_t* h, const comms_c32* d_in, size
     } else {
         COMMS_TRY(comms_mixer_run_dev(h->mixer, d_in, n, a, s));
         COMMS_TRY(comms_fir_run_dev(h->fir, a, n, b, s));
+        chain_raw_hist_kernel<<<dim3(1), dim3(256), 0, hs>>>(h->raw_hist[h->raw_cur], reinterpret_cast<const float2*>(d_in), n,
+                                                             h->raw_hist[h->raw_cur ^ 1], h->fir->n_eff);
+        COMMS_TRY(launch_ok("chain_raw_hist_kernel"));
+        h->raw_cur ^= 1;
     }
     if (!h->fm_demod)
         return comms_decimate_run_dev(b, n, sizeof(comms_c32), h->rate, d_out, nullptr, h->device, s);
@@ -167,7 +195,15 @@ comms_status_t comms_chain_set_timer(comms_chain_t* h, comms_timer_t* t) {
 comms_status_t comms_chain_set_fir_state(comms_chain_t* h, const comms_c32* state, size_t n_state) {
     COMMS_ARG(h != nullptr, "handle is NULL");
     COMMS_ARG(state || !n_state, "state is NULL");
+    COMMS_TRY(use_device(h->device));
+    COMMS_TRY(h->quiesce());
     if (h->fused || h->mixer_after) return comms_fir_set_state(h->fir, state, n_state);
+    COMMS_ARG(n_state == static_cast<size_t>(h->fir->n_eff), "state must hold exactly the %d effective taps", h->fir->n_eff);
+    {
+        std::vector<float2> ring(n_state);
+        for (size_t k = 0; k < n_state; ++k) ring[n_state - 1 - k] = make_float2(state[k].re, state[k].im);
+        COMMS_HIP_TRY(hipMemcpy(h->raw_hist[h->raw_cur], ring.data(), n_state * sizeof(float2), hipMemcpyHostToDevice));
+    }
     // four-kernel path with the mixer in front: its FIR node keeps MIXED samples, so the raw
     // history is mixed here with the phases the oscillator had at samples -1, -2, ...
     // (Mixer::mix arithmetic: f64 product rounded once, src/mixer.rs:77-78)
@@ -182,6 +218,60 @@ comms_status_t comms_chain_set_fir_state(comms_chain_t* h, const comms_c32* stat
         mixed[k].im = static_cast<float>(re * s + im * c);
     }
     return comms_fir_set_state(h->fir, mixed.data(), n_state);
+}
+
+comms_status_t comms_chain_get_fir_state(comms_chain_t* h, comms_c32* state, size_t n_state) {
+    COMMS_ARG(h && state, "NULL argument");
+    COMMS_TRY(use_device(h->device));
+    COMMS_TRY(h->quiesce());
+    if (h->fused || h->mixer_after) return comms_fir_get_state(h->fir, state, n_state);
+    const size_t N = static_cast<size_t>(h->fir->n_eff);
+    COMMS_ARG(n_state <= N, "n_state %zu exceeds the %zu effective taps", n_state, N);
+    std::vector<float2> ring(N);
+    COMMS_HIP_TRY(hipMemcpy(ring.data(), h->raw_hist[h->raw_cur], N * sizeof(float2), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < n_state; ++k) {
+        state[k].re = ring[N - 1 - k].x;
+        state[k].im = ring[N - 1 - k].y;
+    }
+    return COMMS_OK;
+}
+
+// Oscillator phase of the next input sample (radians, as comms_mixer_get_phase).
+comms_status_t comms_chain_get_phase(comms_chain_t* h, double* out_phase) {
+    COMMS_ARG(h && out_phase, "NULL argument");
+    if (!h->fused) return comms_mixer_get_phase(h->mixer, out_phase);
+    *out_phase = static_cast<double>(h->turns >> 11) * (kMixT * 0x1.0p-53);
+    return COMMS_OK;
+}
+
+comms_status_t comms_chain_set_phase(comms_chain_t* h, double phase) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG(std::isfinite(phase), "phase must be finite");
+    if (!h->fused) return comms_mixer_set_phase(h->mixer, phase);
+    h->turns = mix_to_turns(phase);
+    return COMMS_OK;
+}
+
+// FM.prev of the chain's demodulator (src/modulation/analog.rs:9,31): the last DECIMATED filter
+// output of the previous batch.  COMMS_ERR_ARG for a chain without FM demod.
+comms_status_t comms_chain_get_fm_prev(comms_chain_t* h, comms_c32* out_prev) {
+    COMMS_ARG(h && out_prev, "NULL argument");
+    COMMS_ARG(h->fm_demod, "this chain has no FM demodulator");
+    if (!h->fused) return comms_fmdemod_get_prev(h->fm, out_prev);
+    COMMS_TRY(use_device(h->device));
+    COMMS_TRY(h->quiesce());
+    COMMS_HIP_TRY(hipMemcpy(out_prev, h->d_prev[h->cur], sizeof(float2), hipMemcpyDeviceToHost));
+    return COMMS_OK;
+}
+
+comms_status_t comms_chain_set_fm_prev(comms_chain_t* h, const comms_c32* prev) {
+    COMMS_ARG(h && prev, "NULL argument");
+    COMMS_ARG(h->fm_demod, "this chain has no FM demodulator");
+    if (!h->fused) return comms_fmdemod_set_prev(h->fm, prev);
+    COMMS_TRY(use_device(h->device));
+    COMMS_TRY(h->quiesce());
+    COMMS_HIP_TRY(hipMemcpy(h->d_prev[h->cur], prev, sizeof(float2), hipMemcpyHostToDevice));
+    return COMMS_OK;
 }
 
 comms_status_t comms_chain_destroy(comms_chain_t* h) {

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -17,13 +18,18 @@
 #define COMMS_CHAIN_POST 2 /* mixer after the FIR */
 #define COMMS_CHAIN_DEC 4
 #define COMMS_CHAIN_FM 8
-extern "C" comms_status_t comms_fir_run_fused_dev(comms_fir_t* h, const comms_c32* d_in, size_t n, void* d_out,
+#ifdef COMMS_DIAG  // the diagnostic build lets scripts/trace_fir.py, stamp_fir.py reach these
+#define COMMS_INTERNAL
+#else
+#define COMMS_INTERNAL __attribute__((visibility("hidden")))
+#endif
+extern "C" COMMS_INTERNAL comms_status_t comms_fir_run_fused_dev(comms_fir_t* h, const comms_c32* d_in, size_t n, void* d_out,
                                                   int32_t mode, uint64_t turns0, uint64_t frac, uint32_t rate,
                                                   const void* fm_prev, void* fm_prev_new, void* stream);
 
 // the same chain on the time-domain decimating kernel (fir_decim.hip), where it applies
-extern "C" int32_t comms_fir_decim_supported(const comms_fir_t* h, uint32_t rate);
-extern "C" comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const comms_c32* d_in, size_t n, void* d_out,
+extern "C" COMMS_INTERNAL int32_t comms_fir_decim_supported(const comms_fir_t* h, uint32_t rate);
+extern "C" COMMS_INTERNAL comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const comms_c32* d_in, size_t n, void* d_out,
                                                   int32_t mode, uint64_t turns0, uint64_t frac, uint32_t rate,
                                                   const void* fm_prev, void* fm_prev_new, void* stream);
 
@@ -76,14 +82,14 @@ inline comms_status_t launch_ok(const char* what) {
 
 // hipFuncSetAttribute applies to the current device only: a `static DeviceOnce` per call site
 // remembers which devices have had it (a process may drive several GPUs through the C ABI).
+// Node threads of one process reach the same call site concurrently, hence atomics; two threads
+// racing on the first use both set the (idempotent) attribute, which is harmless.
 struct DeviceOnce {
-    bool done[64] = {};
+    std::atomic<bool> done[64] = {};
     bool need() {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
-        if (done[dev]) return false;
-        done[dev] = true;
-        return true;
+        return !done[dev].exchange(true, std::memory_order_acq_rel);
     }
 };
 
@@ -192,6 +198,26 @@ struct Handle {
     // legacy default stream; COMMS_STREAM_HANDLE selects the handle's own stream.
     hipStream_t pick(void* s) const {
         return s == COMMS_STREAM_HANDLE ? stream : reinterpret_cast<hipStream_t>(s);
+    }
+    // Device-resident node state (FIR history ping-pong, FM prev, FFT work buffers) is advanced by
+    // the launches themselves, in stream order.  A handle therefore follows ONE stream at a time:
+    // `enter` is the stream pick of every stateful run_dev -- when the caller moves the node to a
+    // different stream, the work still pending on the previous one is drained first (host wait,
+    // rare) so that launches on the two streams can never race on the state; `quiesce` is what
+    // the state getters / setters call before touching the state from the host.
+    hipStream_t last_stream = nullptr;
+    bool launched = false;
+    comms_status_t enter(void* s_arg, hipStream_t* out) {
+        hipStream_t s = pick(s_arg);
+        if (launched && s != last_stream) COMMS_HIP_TRY(hipStreamSynchronize(last_stream));
+        last_stream = s;
+        launched = true;
+        *out = s;
+        return COMMS_OK;
+    }
+    comms_status_t quiesce() {
+        if (launched) COMMS_HIP_TRY(hipStreamSynchronize(last_stream));
+        return COMMS_OK;
     }
     // The host-pointer form of a node: `launch(d_in, d_out)` runs the device form on this handle's
     // stream.  Short calls work on host-mapped pinned staging (two CPU copies instead of two DMA

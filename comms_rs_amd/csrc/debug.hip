@@ -1,4 +1,7 @@
 // debug.hip -- memory-pattern probes used while tuning (not part of the public ABI).
+// Compiled only into the diagnostic build (`make diag` -> lib/libcomms_hip_diag.so, -DCOMMS_DIAG);
+// the product library exports exactly include/comms_hip.h.
+#ifdef COMMS_DIAG
 #include "common.hpp"
 
 namespace comms {
@@ -211,3 +214,4 @@ extern "C" comms_status_t comms_debug_valu(float* d_out, int kind, int iters, in
     else comms::probe_pk_kernel<4><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 0.9999f, 0.01f);
     return comms::launch_ok("probe_valu");
 }
+#endif  // COMMS_DIAG

@@ -292,7 +292,8 @@ comms_status_t comms_timing_push_dev(comms_timing_t* h, const double* d_samples,
     COMMS_ARG(d_samples || !len, "NULL device pointer");
     COMMS_ARG((reinterpret_cast<uintptr_t>(d_samples) & 15) == 0, "samples must be 16-byte aligned");
     COMMS_TRY(use_device(h->device));
-    hipStream_t s = h->pick(stream);
+    hipStream_t s = nullptr;
+    COMMS_TRY(h->enter(stream, &s));
     double re = 0.0, im = 0.0;
     if (len) {
         size_t blocks = (len + TE_T - 1) / TE_T;
@@ -369,7 +370,8 @@ comms_status_t comms_nco_run_dev(comms_nco_t* h, const double* d_perr, size_t n,
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
     COMMS_ARG(!ranges_overlap(d_perr, n * 8, d_out, n * 16), "nco cannot run in place");
-    hipStream_t s = h->pick(stream);
+    hipStream_t s = nullptr;
+    COMMS_TRY(h->enter(stream, &s));
     const size_t ntiles = (n + NCO_TILE - 1) / NCO_TILE;
     COMMS_ARG(ntiles <= 0x7fffffffu, "block too long");
     COMMS_TRY(h->tiles.reserve(ntiles * sizeof(uint64_t)));

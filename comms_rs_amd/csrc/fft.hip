@@ -1443,8 +1443,10 @@ comms_status_t comms_fft_run_dev(comms_fft_t* h, const comms_c32* d_in, size_t n
     COMMS_ARG(n > 0 && n % h->N == 0,
               "input length %zu is not a multiple of fft_size %zu (the reference panics)", n, h->N);
     COMMS_ARG(d_in && d_out, "NULL device pointer");
+    COMMS_ARG(d_in == d_out || !ranges_overlap(d_in, n * 8, d_out, n * 8), "input and output overlap without being the same buffer");
     COMMS_TRY(use_device(h->device));
-    hipStream_t s = h->pick(stream);
+    hipStream_t s = nullptr;
+    COMMS_TRY(h->enter(stream, &s));
     const float2* in = reinterpret_cast<const float2*>(d_in);
     float2* o = reinterpret_cast<float2*>(d_out);
     const size_t batch = n / h->N;

@@ -1094,7 +1094,9 @@ static int os1024_dynamic_mode() {
     }
     return m;
 }
+#ifdef COMMS_DIAG
 extern "C" void comms_debug_os1024_dynamic(int mode) { g_os1024_dynamic.store(mode, std::memory_order_relaxed); }
+#endif
 
 // One launch of fir_os1024_dyn_kernel: one 16-wave workgroup per CU (fewer for short inputs).
 template <int HR, bool TRACE = false>
@@ -1402,7 +1404,9 @@ comms_status_t comms_fir_create(const comms_c32* taps, size_t n_taps, const comm
 
 comms_status_t comms_fir_set_algo(comms_fir_t* h, int32_t algo) {
     COMMS_ARG(h != nullptr, "handle is NULL");
-    COMMS_ARG(algo >= COMMS_FIR_AUTO && algo <= COMMS_FIR_OS16K, "unknown algo %d", algo);
+    COMMS_ARG(algo >= COMMS_FIR_AUTO && algo <= COMMS_FIR_OS1024_FIXED, "unknown algo %d", algo);
+    h->os1024_fixed = algo == COMMS_FIR_OS1024_FIXED;
+    if (h->os1024_fixed) algo = COMMS_FIR_OS1024;
     COMMS_ARG(algo != COMMS_FIR_OS1024 || h->n_eff <= 257,
               "the 1024-point overlap-save kernel supports at most 257 taps");
     COMMS_ARG(algo != COMMS_FIR_DIRECT || h->n_eff <= DIRECT_MAX_TAPS,
@@ -1436,7 +1440,7 @@ static Os1024Plan os1024_plan(const comms_fir* h, size_t n) {
     const int wpb = wpb_env ? wpb_env : p.nseg <= 4u * kNumCU ? 4 : 16;
     p.wpb = wpb;
     const int mode = os1024_dynamic_mode();
-    p.dyn = mode != 0 && wpb == 16 && p.nseg >= dyn_minseg;
+    p.dyn = mode != 0 && !h->os1024_fixed && wpb == 16 && p.nseg >= dyn_minseg;
     return p;
 }
 
@@ -1468,7 +1472,8 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
     COMMS_ARG(!ranges_overlap(d_in, n * 8, d_out, n * 8), "FIR cannot run in place");
     COMMS_ARG((reinterpret_cast<uintptr_t>(d_in) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 7) == 0,
               "device pointers must be 8-byte aligned");
-    hipStream_t s = h->pick(stream);
+    hipStream_t s = nullptr;
+    COMMS_TRY(h->enter(stream, &s));
     const float2* in = reinterpret_cast<const float2*>(d_in);
     float2* o = reinterpret_cast<float2*>(d_out);
     const float2* hist = h->d_hist[h->cur];
@@ -1563,7 +1568,7 @@ comms_status_t comms_fir_get_state(comms_fir_t* h, comms_c32* state, size_t n_st
     COMMS_ARG(h && state, "NULL argument");
     COMMS_ARG(n_state <= static_cast<size_t>(h->n_eff), "n_state %zu exceeds the %d effective taps", n_state, h->n_eff);
     COMMS_TRY(use_device(h->device));
-    COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
+    COMMS_TRY(h->quiesce());  // the history is advanced by the launches, on whatever stream they ran
     std::vector<float2> ring(h->n_eff);
     COMMS_HIP_TRY(hipMemcpy(ring.data(), h->d_hist[h->cur], ring.size() * sizeof(float2), hipMemcpyDeviceToHost));
     for (size_t k = 0; k < n_state; ++k) {
@@ -1577,7 +1582,7 @@ comms_status_t comms_fir_set_state(comms_fir_t* h, const comms_c32* state, size_
     COMMS_ARG(h && state, "NULL argument");
     COMMS_ARG(n_state == static_cast<size_t>(h->n_eff), "state must hold exactly the %d effective taps", h->n_eff);
     COMMS_TRY(use_device(h->device));
-    COMMS_HIP_TRY(hipStreamSynchronize(h->stream));
+    COMMS_TRY(h->quiesce());  // no pending launch may still read the buffer that is overwritten
     return fir_upload_state(h, state, n_state);
 }
 
@@ -1599,8 +1604,10 @@ comms_status_t comms_fir_run_fused_dev(comms_fir_t* h, const comms_c32* d_in, si
               "fused FM demod needs rate <= 64 and taps + rate <= 257");
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
+    COMMS_ARG(!ranges_overlap(d_in, n * 8, d_out, (n / rate) * ((mode & CH_FM) ? 4 : 8)), "the fused chain cannot run in place");
     COMMS_TRY(fir_prepare_os1024(h));
-    hipStream_t s = h->pick(stream);
+    hipStream_t s = nullptr;
+    COMMS_TRY(h->enter(stream, &s));
     const float2* in = reinterpret_cast<const float2*>(d_in);
     float2* o = reinterpret_cast<float2*>(d_out);
     const float2* hist = h->d_hist[h->cur];
@@ -1805,7 +1812,8 @@ comms_status_t comms_pulse_run_dev(comms_pulse_t* h, const comms_c32* d_sym, siz
     COMMS_ARG(n_sym <= SIZE_MAX / 8 / h->sps, "n_sym * sam_per_sym overflows");
     const size_t n_out = n_sym * h->sps;
     COMMS_ARG(!ranges_overlap(d_sym, n_sym * 8, d_out, n_out * 8), "pulse shaping cannot run in place");
-    hipStream_t s = h->pick(stream);
+    hipStream_t s = nullptr;
+    COMMS_TRY(h->enter(stream, &s));
     const float2* sym = reinterpret_cast<const float2*>(d_sym);
     h->tic(s);
     if (!pulse_poly_launch(h, sym, n_sym, reinterpret_cast<float2*>(d_out), s)) {

@@ -340,8 +340,10 @@ static unsigned long long* g_decim_stamps = nullptr;
 
 extern "C" {
 
-// diagnostic hook (not in the public header): device buffer of 8 u64 per wave, or NULL
+#ifdef COMMS_DIAG
+// diagnostic hook (diagnostic build only): device buffer of 8 u64 per wave, or NULL
 void comms_debug_decim_stamps(void* d_buf) { g_decim_stamps = static_cast<unsigned long long*>(d_buf); }
+#endif
 
 // Whether (taps, rate) runs on the decimating kernel: 0 = no (no instantiation for the rate, or
 // taps beyond the kernel-argument budget), 1 = it can, 2 = and with few enough MACs per input
@@ -371,7 +373,10 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const comms_c32* d_in, si
     COMMS_ARG((mode & COMMS_CHAIN_DEC) && !((mode & COMMS_CHAIN_PRE) && (mode & COMMS_CHAIN_POST)), "bad chain mode");
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
-    hipStream_t s = h->pick(stream);
+    COMMS_ARG(!ranges_overlap(d_in, n * 8, d_out, (n / rate) * ((mode & COMMS_CHAIN_FM) ? 4 : 8)),
+              "the decimating chain cannot run in place");
+    hipStream_t s = nullptr;
+    COMMS_TRY(h->enter(stream, &s));
     const int R = static_cast<int>(rate), PR = 2 * R, N = h->n_eff;
     DecimArgs a{};
     a.in = reinterpret_cast<const float2*>(d_in);

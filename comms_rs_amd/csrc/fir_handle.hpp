@@ -42,6 +42,7 @@ struct comms_fir : comms::Handle {
     int n_eff = 0;       // taps that take part: min(n_taps, n_state)
     bool real_taps = false;
     int algo = COMMS_FIR_AUTO;
+    bool os1024_fixed = false;  // COMMS_FIR_OS1024_FIXED: never the ticketed kernel
     // direct form
     int NP = 0;          // taps padded to a multiple of 8
     float2* d_taps_pad = nullptr;

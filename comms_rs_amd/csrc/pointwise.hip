@@ -228,6 +228,15 @@ comms_status_t comms_mixer_get_phase(const comms_mixer_t* h, double* out_phase) 
     return COMMS_OK;
 }
 
+// Checkpoint / shard hand-over hook: the oscillator phase of the NEXT sample (any finite angle;
+// reduced modulo fl(2*pi) as Mixer::new leaves `phase` and the per-sample wrap then treats it).
+comms_status_t comms_mixer_set_phase(comms_mixer_t* h, double phase) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG(std::isfinite(phase), "phase must be finite");
+    h->turns = to_turns(phase);
+    return COMMS_OK;
+}
+
 comms_status_t comms_mixer_set_timer(comms_mixer_t* h, comms_timer_t* t) {
     COMMS_ARG(h != nullptr, "handle is NULL");
     h->timer = t;
@@ -287,6 +296,7 @@ comms_status_t comms_decimate_run_dev(const void* d_in, size_t n, size_t elem, s
             COMMS_HIP_TRY(hipMemcpyAsync(d_out, d_in, n * elem, hipMemcpyDeviceToDevice, s));
         return COMMS_OK;
     }
+    COMMS_ARG(!ranges_overlap(d_in, n * elem, d_out, n_out * elem), "decimate cannot run in place");
     unsigned blocks = grid_for(n_out, 256, 8 * kNumCU);
     COMMS_RESAMPLE_DISPATCH(decimate_kernel, elem, n_out, rate)
     return launch_ok("decimate_kernel");
@@ -378,7 +388,8 @@ comms_status_t comms_fmdemod_run_dev(comms_fmdemod_t* h, const comms_c32* d_in, 
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
     COMMS_ARG(!ranges_overlap(d_in, n * 8, d_out, n * 4), "fmdemod cannot run in place");
-    hipStream_t s = h->pick(stream);
+    hipStream_t s = nullptr;
+    COMMS_TRY(h->enter(stream, &s));  // d_prev is read and advanced in stream order
     const float2* in = reinterpret_cast<const float2*>(d_in);
     unsigned blocks = grid_for((n + 3) / 4, 256, 8 * kNumCU);
     bool aligned = ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0;
@@ -401,6 +412,24 @@ comms_status_t comms_fmdemod_run(comms_fmdemod_t* h, const comms_c32* in, size_t
     return h->run_host(in, n * sizeof(comms_c32), out, n * sizeof(float), [&](void* d_in, void* d_out) {
         return comms_fmdemod_run_dev(h, static_cast<const comms_c32*>(d_in), n, static_cast<float*>(d_out), COMMS_STREAM_HANDLE);
     });
+}
+
+// FM.prev (src/modulation/analog.rs:9,31): the last input sample of the previous batch.  Getter and
+// setter are the checkpoint hook and the 1-sample halo of a sharded stream.
+comms_status_t comms_fmdemod_get_prev(comms_fmdemod_t* h, comms_c32* out_prev) {
+    COMMS_ARG(h && out_prev, "NULL argument");
+    COMMS_TRY(use_device(h->device));
+    COMMS_TRY(h->quiesce());
+    COMMS_HIP_TRY(hipMemcpy(out_prev, h->d_prev, sizeof(float2), hipMemcpyDeviceToHost));
+    return COMMS_OK;
+}
+
+comms_status_t comms_fmdemod_set_prev(comms_fmdemod_t* h, const comms_c32* prev) {
+    COMMS_ARG(h && prev, "NULL argument");
+    COMMS_TRY(use_device(h->device));
+    COMMS_TRY(h->quiesce());
+    COMMS_HIP_TRY(hipMemcpy(h->d_prev, prev, sizeof(float2), hipMemcpyHostToDevice));
+    return COMMS_OK;
 }
 
 comms_status_t comms_fmdemod_set_timer(comms_fmdemod_t* h, comms_timer_t* t) {

@@ -157,11 +157,16 @@ comms_status_t comms_timer_create(size_t n_pairs, int32_t device, comms_timer_t*
     COMMS_ARG(t != nullptr, "out of host memory");
     t->device = device;
     t->n = n_pairs;
-    t->start = new (std::nothrow) hipEvent_t[n_pairs];
-    t->stop = new (std::nothrow) hipEvent_t[n_pairs];
-    for (size_t i = 0; i < n_pairs; ++i) {
-        COMMS_HIP_TRY(hipEventCreate(&t->start[i]));
-        COMMS_HIP_TRY(hipEventCreate(&t->stop[i]));
+    t->start = new (std::nothrow) hipEvent_t[n_pairs]();
+    t->stop = new (std::nothrow) hipEvent_t[n_pairs]();
+    hipError_t e = (t->start && t->stop) ? hipSuccess : hipErrorOutOfMemory;
+    for (size_t i = 0; i < n_pairs && e == hipSuccess; ++i) {
+        e = hipEventCreate(&t->start[i]);
+        if (e == hipSuccess) e = hipEventCreate(&t->stop[i]);
+    }
+    if (e != hipSuccess) {  // undo what exists: no events, arrays or timer may leak
+        comms_timer_destroy(t);
+        return fail(COMMS_ERR_DEVICE, "timer of %zu event pairs: %s", n_pairs, hipGetErrorString(e));
     }
     *out = t;
     return COMMS_OK;
@@ -189,8 +194,8 @@ comms_status_t comms_timer_destroy(comms_timer_t* t) {
     if (!t) return COMMS_OK;
     (void)use_device(t->device);
     for (size_t i = 0; i < t->n; ++i) {
-        (void)hipEventDestroy(t->start[i]);
-        (void)hipEventDestroy(t->stop[i]);
+        if (t->start && t->start[i]) (void)hipEventDestroy(t->start[i]);
+        if (t->stop && t->stop[i]) (void)hipEventDestroy(t->stop[i]);
     }
     delete[] t->start;
     delete[] t->stop;

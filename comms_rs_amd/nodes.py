@@ -211,6 +211,11 @@ class MixerNode(_Handle):
         check(lib().comms_mixer_get_phase(self._h, C.byref(p)))
         return p.value
 
+    @phase.setter
+    def phase(self, value):
+        """Phase of the next sample (checkpoint restore / start phase of a stream shard)."""
+        check(lib().comms_mixer_set_phase(self._h, float(value)))
+
 
 # ------------------------------------------------------------------ resampling
 class DecimateNode:
@@ -286,6 +291,18 @@ class FMDemodNode(_Handle):
 
     def run_dev(self, in_ptr, n, out_ptr, stream=0):
         check(lib().comms_fmdemod_run_dev(self._h, in_ptr, n, out_ptr, stream))
+
+    @property
+    def prev(self):
+        """FM.prev (analog.rs:9,31): the last input sample of the previous batch."""
+        p = np.zeros(1, np.complex64)
+        check(lib().comms_fmdemod_get_prev(self._h, _ptr(p)))
+        return p[0]
+
+    @prev.setter
+    def prev(self, value):
+        p = np.array([value], np.complex64)
+        check(lib().comms_fmdemod_set_prev(self._h, _ptr(p)))
 
 
 # ------------------------------------------------------------------ FFT
@@ -370,6 +387,34 @@ class ChainNode(_Handle):
         st = _as_c64(state)
         check(lib().comms_chain_set_fir_state(self._h, _ptr(st), st.size))
         return self
+
+    def fir_state(self, n_state):
+        st = np.empty(int(n_state), np.complex64)
+        check(lib().comms_chain_get_fir_state(self._h, _ptr(st), st.size))
+        return st
+
+    @property
+    def phase(self):
+        """Oscillator phase of the next input sample."""
+        p = C.c_double()
+        check(lib().comms_chain_get_phase(self._h, C.byref(p)))
+        return p.value
+
+    @phase.setter
+    def phase(self, value):
+        check(lib().comms_chain_set_phase(self._h, float(value)))
+
+    @property
+    def fm_prev(self):
+        """FM.prev of the chain's demodulator: the last decimated filter output of the previous batch."""
+        p = np.zeros(1, np.complex64)
+        check(lib().comms_chain_get_fm_prev(self._h, _ptr(p)))
+        return p[0]
+
+    @fm_prev.setter
+    def fm_prev(self, value):
+        p = np.array([value], np.complex64)
+        check(lib().comms_chain_set_fm_prev(self._h, _ptr(p)))
 
 
 # ------------------------------------------------------------------ tap design

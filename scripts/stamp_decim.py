@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase cycle stamps of fir_decim_kernel on config 3 (diagnostic; every stamp drains the
 memory counters, so read the SHARES, not the total)."""
+import os as _os; _os.environ.setdefault("COMMS_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "comms_rs_amd", "lib", "libcomms_hip_diag.so"))  # diagnostic build (`make -C comms_rs_amd/csrc diag`)
 import ctypes as C
 import os
 import sys

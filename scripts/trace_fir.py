@@ -1,5 +1,6 @@
 """Diagnostic: when do the waves of fir_os1024_kernel start, finish set-up and end?  (traced build,
 production geometry: 256 workgroups of 16 waves, 255 taps, 2^24 samples).  s_memrealtime ticks at 100 MHz."""
+import os as _os; _os.environ.setdefault("COMMS_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "comms_rs_amd", "lib", "libcomms_hip_diag.so"))  # diagnostic build (`make -C comms_rs_amd/csrc diag`)
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

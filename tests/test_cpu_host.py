@@ -134,10 +134,11 @@ sys.path.insert(0, sys.argv[1])
 import numpy as np, torch, torch.distributed as dist
 import oracle
 from comms_rs_amd import synth_iq
-from comms_rs_amd.sharding import shard_range, halo_exchange, state_from_halo, shard_mixer_phase
+from comms_rs_amd.sharding import (chain_prefix_len, gather_shards, halo_exchange, scatter_shards, shard_range,
+                                   state_from_halo, shard_mixer_phase)
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-total, n_taps = 50000, 255
+total, n_taps, rate = 50000, 255, 8
 taps = oracle.rrc_taps(n_taps, 8.0, 0.35)
 a, b = shard_range(total, world, rank)
 x = synth_iq(b - a, a)                                   # shard generated in place
@@ -153,7 +154,33 @@ dphase = 2 * np.pi * 0.1
 ym = oracle.Mixer(shard_mixer_phase(0.3, dphase, a), dphase).mix(y)
 fullm = oracle.Mixer(0.3, dphase).mix(full)
 same_mix = np.max(np.abs(ym - fullm[a:b])) <= 1e-6 * np.max(np.abs(fullm))
-ok = torch.tensor([1.0 if (np.array_equal(y, full[a:b]) and same_mix) else 0.0])
+ok = np.array_equal(y, full[a:b]) and same_mix
+
+# ---- secondary variant: scatter from the root, FM chain primed by a prefix, gather on the root
+W = chain_prefix_len(n_taps, rate, True)
+assert W % rate == 0 and W >= n_taps - 1 + rate and chain_prefix_len(n_taps, rate, False) == 256
+whole = synth_iq(total, 0, 5)
+shard = torch.empty(b - a, 2)
+scatter_shards(dist, torch.view_as_real(torch.from_numpy(whole)) if rank == 0 else None, shard, rank, world)
+xs = torch.view_as_complex(shard).numpy()
+ok = ok and np.array_equal(xs, whole[a:b])
+pre = halo_exchange(dist, torch.view_as_real(torch.from_numpy(xs[-W:].copy())), rank, world)
+def chain(start):   # MixerNode -> BatchFirNode -> DecimateNode -> FMDemodNode, reference arithmetic
+    mx, st, fm = oracle.Mixer(shard_mixer_phase(0.0, dphase, start), dphase), oracle.default_state(taps), oracle.FM()
+    return lambda v: fm.demod(oracle.decimate(oracle.batch_fir(mx.mix(v), taps, st, norotate=True), rate))
+node = chain(a - W if rank else a)
+if rank:
+    node(torch.view_as_complex(pre).numpy())             # prime: outputs thrown away
+out = node(xs)
+res = torch.empty(total // rate) if rank == 0 else None
+gather_shards(dist, torch.from_numpy(out), res, rank, world)
+if rank == 0:
+    ref = chain(0)(whole)
+    d = np.abs(res.numpy().astype(np.float64) - ref); d = np.minimum(d, 2 * np.pi - d)
+    y_dec = oracle.decimate(oracle.batch_fir(oracle.Mixer(0.0, dphase).mix(whole), taps, oracle.default_state(taps), norotate=True), rate)
+    mag = np.minimum(np.abs(y_dec), np.abs(np.concatenate([[0.0], y_dec[:-1]])))
+    ok = ok and np.max(d * mag) <= 1e-5                  # the primed FIR restarts its rounding: not bit-equal
+ok = torch.tensor([1.0 if ok else 0.0])
 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
 dist.destroy_process_group()
 sys.exit(0 if ok.item() == 1.0 else 3)
@@ -162,7 +189,9 @@ sys.exit(0 if ok.item() == 1.0 else 3)
 
 def test_sharded_stream_equals_unsharded_gloo_world2(tmp_path):
     """Two CPU ranks (gloo): contiguous shards + one halo hand-over reproduce the
-    un-sharded filter output exactly -- the N>1 path of bench.py, minus the GPU."""
+    un-sharded filter output exactly; scatter -> prefix-primed FM chain -> gather reproduces the
+    un-sharded chain -- the N>1 logic of bench.py and sharding.py, minus the GPU (the same logic
+    with the product nodes: tests/test_gpu_sharding.py)."""
     import __graft_entry__ as g
 
     g.build()
@@ -182,6 +211,21 @@ def test_rust_shim_declares_every_header_symbol():
 
     assert subprocess.call([sys.executable, os.path.join(ROOT, "scripts", "gen_rust_ffi.py"), "--check"]) == 0, \
         "comms_rs_amd/rust_shim/src/ffi.rs is stale: run scripts/gen_rust_ffi.py"
+
+
+def test_library_exports_exactly_the_header():
+    """The product .so exports every comms_* symbol of include/comms_hip.h and nothing else: probes,
+    stamps and kernel selectors live in the diagnostic build only (`make -C comms_rs_amd/csrc diag`)."""
+    import re
+    import subprocess
+
+    import comms_rs_amd as c
+
+    hdr = open(os.path.join(ROOT, "include", "comms_hip.h")).read()
+    declared = set(re.findall(r"\b(comms_[a-z0-9_]+)\s*\(", hdr))
+    out = subprocess.check_output(["nm", "-D", "--defined-only", c.LIB_PATH], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith("comms_")}
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
 
 
 def test_header_is_plain_c():

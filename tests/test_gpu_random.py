@@ -119,39 +119,32 @@ def test_fir_ticketed_kernel_random_sweep(c):
     """Long batches (>= 4096 segments) run fir_os1024_dyn_kernel: random tap counts (both halo widths), batch lengths
     that end on and off a segment boundary, two calls with carried state -- bit-identical to the fixed-run kernel, and
     equal to the oracle on windows at the start, the call boundary and the end."""
-    import ctypes
     import torch
 
-    setm = c.lib().comms_debug_os1024_dynamic
-    setm.argtypes, setm.restype = [ctypes.c_int], None
     rng = np.random.default_rng(15 + 1000 * SEED_OFFSET)
     s = torch.cuda.current_stream().cuda_stream
-    try:
-        for case in range(6):
-            n_taps = int(rng.integers(9, 258))
-            wv = 1024 - 64 * (1 if n_taps <= 65 else 2 if n_taps <= 129 else 3 if n_taps <= 193 else 4)
-            n1 = int(rng.integers(4096, 5200)) * wv + (0 if case % 3 == 0 else int(rng.integers(1, wv)))
-            n2 = int(rng.integers(4096, 4500)) * wv + int(rng.integers(0, 2)) * int(rng.integers(1, wv))
-            taps = rand_c(rng, n_taps) if case % 2 else rand_c(rng, n_taps).real.astype(np.complex64)
-            seed = int(rng.integers(1, 1 << 30))
-            x = torch.empty(n1 + n2, dtype=torch.complex64, device="cuda:0")
-            c.synth_iq_dev(x.data_ptr(), n1 + n2, 0, seed)
-            ys = []
-            for mode in (0, 1):
-                setm(mode)
-                node = c.BatchFirNode(taps).set_algo(c.FIR_OS1024)
-                assert node.kernel_for(n1) == ("fir_os1024_dyn_kernel" if mode else "fir_os1024_kernel"), case
-                y = torch.empty_like(x)
-                node.run_dev(x.data_ptr(), n1, y.data_ptr(), s)
-                node.run_dev(x.data_ptr() + 8 * n1, n2, y.data_ptr() + 8 * n1, s)
-                torch.cuda.synchronize()
-                ys.append(y)
-            assert torch.equal(torch.view_as_real(ys[0]), torch.view_as_real(ys[1])), (case, n_taps, n1, n2)
-            for a in (0, n1 - 2000, n1 + n2 - 3000):
-                lo = max(0, a - (n_taps - 1))
-                xs = c.synth_iq(a + 3000 - lo, lo, seed)
-                want = oracle.batch_fir(xs, taps, oracle.default_state(taps), norotate=True)[a - lo:]
-                fir_close(ys[1][a:a + 3000].cpu().numpy(), want, taps, xs)
-            del x, ys
-    finally:
-        setm(1)
+    for case in range(6):
+        n_taps = int(rng.integers(9, 258))
+        wv = 1024 - 64 * (1 if n_taps <= 65 else 2 if n_taps <= 129 else 3 if n_taps <= 193 else 4)
+        n1 = int(rng.integers(4096, 5200)) * wv + (0 if case % 3 == 0 else int(rng.integers(1, wv)))
+        n2 = int(rng.integers(4096, 4500)) * wv + int(rng.integers(0, 2)) * int(rng.integers(1, wv))
+        taps = rand_c(rng, n_taps) if case % 2 else rand_c(rng, n_taps).real.astype(np.complex64)
+        seed = int(rng.integers(1, 1 << 30))
+        x = torch.empty(n1 + n2, dtype=torch.complex64, device="cuda:0")
+        c.synth_iq_dev(x.data_ptr(), n1 + n2, 0, seed)
+        ys = []
+        for mode in (0, 1):
+            node = c.BatchFirNode(taps).set_algo(c.FIR_OS1024 if mode else c.FIR_OS1024_FIXED)
+            assert node.kernel_for(n1) == ("fir_os1024_dyn_kernel" if mode else "fir_os1024_kernel"), case
+            y = torch.empty_like(x)
+            node.run_dev(x.data_ptr(), n1, y.data_ptr(), s)
+            node.run_dev(x.data_ptr() + 8 * n1, n2, y.data_ptr() + 8 * n1, s)
+            torch.cuda.synchronize()
+            ys.append(y)
+        assert torch.equal(torch.view_as_real(ys[0]), torch.view_as_real(ys[1])), (case, n_taps, n1, n2)
+        for a in (0, n1 - 2000, n1 + n2 - 3000):
+            lo = max(0, a - (n_taps - 1))
+            xs = c.synth_iq(a + 3000 - lo, lo, seed)
+            want = oracle.batch_fir(xs, taps, oracle.default_state(taps), norotate=True)[a - lo:]
+            fir_close(ys[1][a:a + 3000].cpu().numpy(), want, taps, xs)
+        del x, ys
