@@ -439,8 +439,8 @@ def run_config2(ctx):
             "fused_chain_value": round(st["total"] * st["steps"] / st["fused_elapsed"] / 1e6, 1),
             "fir_kernel": st["algo"], "fir_kernel_ms": round(st["kernel_ms"], 5),
             "fir_hbm_GBps": round(ach, 1), "fir_frac_of_peak": round(ach / HBM_PEAK_GBS, 4),
-            "note": "HBM-resident: %.1f GiB of FIR input + output per GPU, far past the 256 MiB Infinity Cache"
-                    % (16.0 * st["per"] / 2 ** 30)}
+            "note": "%.2f GiB of FIR input + output per GPU (HBM-resident once this is far past the 256 MiB "
+                    "Infinity Cache)" % (16.0 * st["per"] / 2 ** 30)}
         if st["transfer"]:
             out["stream_2p30"]["transfer"] = st["transfer"]
     if head["transfer"]:

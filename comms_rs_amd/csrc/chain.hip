@@ -45,7 +45,29 @@ struct comms_chain : Handle {
     Scratch t1, t2, t3;
     float2* raw_hist[2] = {nullptr, nullptr};  // unfused + mixer first: last n_eff raw inputs, time order
     int raw_cur = 0;
+    std::vector<comms_c32> pending_raw;        // a user state not yet mixed into the FIR node's history
 };
+
+// four-kernel path with the mixer in front: the FIR node keeps MIXED samples, so a raw user history is
+// mixed with the phases the oscillator had at samples -1, -2, ... (Mixer::mix arithmetic: f64 product
+// rounded once, src/mixer.rs:77-78).  Done at the next run, so that set_fir_state and set_phase may
+// come in either order.
+static comms_status_t chain_flush_raw_state(comms_chain* h) {
+    if (h->pending_raw.empty()) return COMMS_OK;
+    double ph = 0.0;
+    COMMS_TRY(comms_mixer_get_phase(h->mixer, &ph));
+    const size_t n_state = h->pending_raw.size();
+    std::vector<comms_c32> mixed(n_state);
+    for (size_t k = 0; k < n_state; ++k) {
+        const double a = ph - static_cast<double>(k + 1) * h->dphase;
+        const double c = std::cos(a), s = std::sin(a);
+        const double re = h->pending_raw[k].re, im = h->pending_raw[k].im;
+        mixed[k].re = static_cast<float>(re * c - im * s);
+        mixed[k].im = static_cast<float>(re * s + im * c);
+    }
+    h->pending_raw.clear();
+    return comms_fir_set_state(h->fir, mixed.data(), n_state);
+}
 
 static void free_chain(comms_chain* h) {
     if (h->mixer) comms_mixer_destroy(h->mixer);
@@ -160,6 +182,7 @@ comms_status_t comms_chain_run_dev(comms_chain_t* h, const comms_c32* d_in, size
         COMMS_TRY(comms_fir_run_dev(h->fir, d_in, n, a, s));
         COMMS_TRY(comms_mixer_run_dev(h->mixer, a, n, b, s));
     } else {
+        COMMS_TRY(chain_flush_raw_state(h));
         COMMS_TRY(comms_mixer_run_dev(h->mixer, d_in, n, a, s));
         COMMS_TRY(comms_fir_run_dev(h->fir, a, n, b, s));
         chain_raw_hist_kernel<<<dim3(1), dim3(256), 0, hs>>>(h->raw_hist[h->raw_cur], reinterpret_cast<const float2*>(d_in), n,
@@ -204,20 +227,8 @@ comms_status_t comms_chain_set_fir_state(comms_chain_t* h, const comms_c32* stat
         for (size_t k = 0; k < n_state; ++k) ring[n_state - 1 - k] = make_float2(state[k].re, state[k].im);
         COMMS_HIP_TRY(hipMemcpy(h->raw_hist[h->raw_cur], ring.data(), n_state * sizeof(float2), hipMemcpyHostToDevice));
     }
-    // four-kernel path with the mixer in front: its FIR node keeps MIXED samples, so the raw
-    // history is mixed here with the phases the oscillator had at samples -1, -2, ...
-    // (Mixer::mix arithmetic: f64 product rounded once, src/mixer.rs:77-78)
-    double ph = 0.0;
-    COMMS_TRY(comms_mixer_get_phase(h->mixer, &ph));
-    std::vector<comms_c32> mixed(n_state);
-    for (size_t k = 0; k < n_state; ++k) {
-        const double a = ph - static_cast<double>(k + 1) * h->dphase;
-        const double c = std::cos(a), s = std::sin(a);
-        const double re = state[k].re, im = state[k].im;
-        mixed[k].re = static_cast<float>(re * c - im * s);
-        mixed[k].im = static_cast<float>(re * s + im * c);
-    }
-    return comms_fir_set_state(h->fir, mixed.data(), n_state);
+    h->pending_raw.assign(state, state + n_state);  // mixed into the FIR node's history at the next run
+    return COMMS_OK;
 }
 
 comms_status_t comms_chain_get_fir_state(comms_chain_t* h, comms_c32* state, size_t n_state) {
