@@ -50,6 +50,14 @@ _PROTOS = {
     "comms_buf_release": [_vp],
     "comms_buf_upload": [_vp, _sz, _vp, _sz],
     "comms_buf_download": [_vp, _sz, _vp, _sz],
+    "comms_buf_pool_trim": [_i32],
+    "comms_buf_record_ready": [_vp, _vp],
+    "comms_buf_wait_ready": [_vp, _vp],
+    "comms_buf_record_use": [_vp, _vp],
+    "comms_buf_sync": [_vp],
+    "comms_stream_create": [_i32, _pp],
+    "comms_stream_synchronize": [_i32, _vp],
+    "comms_stream_destroy": [_i32, _vp],
     "comms_timer_create": [_sz, _i32, _pp],
     "comms_timer_reset": [_vp],
     "comms_timer_read": [_vp, _vp, _sz, _psz],

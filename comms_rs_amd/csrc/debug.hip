@@ -165,6 +165,87 @@ __global__ __launch_bounds__(256) void probe_pk_kernel(float* out, int iters, fl
     for (int i = 0; i < 16; ++i) s += r[i].x + r[i].y;
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+// The decimating chain's MAC: acc += u * tap with the real tap in one half of a 64-bit pair that is either an
+// SGPR pair (kernel argument, as fir_decim.hip does) or a VGPR pair; NA accumulators = NA dependent chains.
+struct MacProbeArgs {
+    float t[32];
+};
+template <bool SGPR, int NA>
+__global__ __launch_bounds__(256) void probe_mac_kernel(float* out, int iters, const MacProbeArgs a) {
+    v2f acc[NA], u[8];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = v2f{threadIdx.x * 0.001f + i, 1.0f + i};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = v2f{threadIdx.x * 0.002f + i, 2.0f - i};
+    v2f tv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tv[i] = v2f{a.t[2 * i], a.t[2 * i + 1]};
+    if (!SGPR) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(tv[i]));  // pin the pairs in VGPRs
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            v2f& ac = acc[i % NA];
+            if (SGPR) {
+                if (i & 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(ac) : "v"(u[i & 7]), "s"(tv[i >> 1]));
+                else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(ac) : "v"(u[i & 7]), "s"(tv[i >> 1]));
+            } else {
+                if (i & 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(ac) : "v"(u[i & 7]), "v"(tv[i >> 1]));
+                else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(ac) : "v"(u[i & 7]), "v"(tv[i >> 1]));
+            }
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) s += acc[i].x + acc[i].y;
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+// Operand-form matrix for the packed MAC (16 chains): which part of `acc += u * tap` costs the second pass?
+template <int V>
+__global__ __launch_bounds__(256) void probe_mac_form_kernel(float* out, int iters, const MacProbeArgs a) {
+    v2f acc[16], u[8], tv[8];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = v2f{threadIdx.x * 0.001f + i, 1.0f + i};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = v2f{threadIdx.x * 0.002f + i, 2.0f - i};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tv[i] = v2f{a.t[2 * i], a.t[2 * i + 1]};
+    if (V != 5 && V != 6) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(tv[i]));
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            v2f& ac = acc[i];
+            const v2f& uu = u[i & 7];
+            const v2f& tt = tv[i >> 1];
+            if (V == 0) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(ac) : "v"(uu), "v"(tt));
+            if (V == 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(ac) : "v"(uu), "v"(tt));
+            if (V == 2) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(ac) : "v"(uu), "v"(tt));
+            if (V == 3) asm volatile("v_pk_fma_f32 %0, %0, %2, %1" : "+v"(ac) : "v"(uu), "v"(tt));
+            if (V == 4) asm volatile("v_pk_fma_f32 %0, %0, %2, %1 op_sel_hi:[1,0,1]" : "+v"(ac) : "v"(uu), "v"(tt));
+            if (V == 5) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(ac) : "v"(uu), "s"(tt));
+            if (V == 6) {
+                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(ac.x) : "v"(uu.x), "s"(tt.x));
+                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(ac.y) : "v"(uu.y), "s"(tt.x));
+            }
+            if (V == 7) {
+                v2f p;
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(uu), "v"(tt));
+                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(ac) : "v"(p));
+            }
+            if (V == 8) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(ac) : "v"(uu));        // two distinct VGPR pairs only
+            if (V == 9) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(ac) : "v"(uu), "v"(tt));  // no accumulate
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i].x + acc[i].y;
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
 // KIND 5: v_permlane32_swap_b32, KIND 6: v_permlane16_swap_b32 (8 swaps of register pairs per 16 "ops")
 template <int KIND>
 __global__ __launch_bounds__(256) void probe_swap_kernel(float* out, int iters) {
@@ -210,7 +291,22 @@ extern "C" comms_status_t comms_debug_valu(float* d_out, int kind, int iters, in
     else if (kind == 2) comms::probe_valu_kernel<2><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 1.0001f, 0.5f);
     else if (kind == 5) comms::probe_swap_kernel<5><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters);
     else if (kind == 6) comms::probe_swap_kernel<6><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters);
-    else if (kind == 3) comms::probe_pk_kernel<3><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 0.9999f, 0.01f);
+    else if (kind >= 20 && kind <= 29) {
+        comms::MacProbeArgs a;
+        for (int i = 0; i < 32; ++i) a.t[i] = 1e-3f * (i + 1);
+#define COMMS_PF(V) if (kind == 20 + V) comms::probe_mac_form_kernel<V><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, a);
+        COMMS_PF(0) COMMS_PF(1) COMMS_PF(2) COMMS_PF(3) COMMS_PF(4) COMMS_PF(5) COMMS_PF(6) COMMS_PF(7) COMMS_PF(8) COMMS_PF(9)
+#undef COMMS_PF
+    } else if (kind >= 7 && kind <= 12) {
+        comms::MacProbeArgs a;
+        for (int i = 0; i < 32; ++i) a.t[i] = 1e-3f * (i + 1);
+        if (kind == 7) comms::probe_mac_kernel<true, 2><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, a);
+        if (kind == 8) comms::probe_mac_kernel<false, 2><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, a);
+        if (kind == 9) comms::probe_mac_kernel<true, 16><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, a);
+        if (kind == 10) comms::probe_mac_kernel<false, 16><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, a);
+        if (kind == 11) comms::probe_mac_kernel<true, 4><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, a);
+        if (kind == 12) comms::probe_mac_kernel<false, 4><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, a);
+    } else if (kind == 3) comms::probe_pk_kernel<3><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 0.9999f, 0.01f);
     else comms::probe_pk_kernel<4><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 0.9999f, 0.01f);
     return comms::launch_ok("probe_valu");
 }

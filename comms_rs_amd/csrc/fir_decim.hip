@@ -105,7 +105,12 @@ __device__ __forceinline__ void lds_barrier() {  // (kept light: nothing global 
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int R, bool REAL>
+// PRE: the mixer sits in front of the FIR (samples are mixed on their way into LDS); otherwise it
+// follows the FIR (or is absent).  PF: the next tile's global loads are issued right after this
+// tile has been staged, so that they fly during the filter loop (costs the 2R + 2 staging
+// registers across the loop; the PRE form then derives its row rotors on the fly instead of
+// keeping 2R of them in VGPRs).
+template <int R, bool REAL, bool PRE, bool PF>
 __global__ __launch_bounds__(DC_WG, DcGeom<R>::WGPC) void fir_decim_kernel(const DecimArgs a) {
     using G = DcGeom<R>;
     constexpr int PR = G::PR, S = G::S;
@@ -115,7 +120,8 @@ __global__ __launch_bounds__(DC_WG, DcGeom<R>::WGPC) void fir_decim_kernel(const
     hist_advance(a.hist, a.in, a.n, a.new_hist, a.hist_len);
 
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-    const bool pre = (a.mode & COMMS_CHAIN_PRE) != 0, post = (a.mode & COMMS_CHAIN_POST) != 0;
+    constexpr bool pre = PRE;
+    const bool post = !PRE && (a.mode & COMMS_CHAIN_POST) != 0;
     const bool fm = (a.mode & COMMS_CHAIN_FM) != 0;
     const int ovl = fm ? 1 : 0;           // FM tiles recompute the previous tile's last output
     const long long ts = DC_TILE - ovl;   // stored outputs per tile
@@ -130,7 +136,8 @@ __global__ __launch_bounds__(DC_WG, DcGeom<R>::WGPC) void fir_decim_kernel(const
     // two outputs after the filter -- the filter is linear), and a part that never changes,
     // lrow[m] = e^{i (tid + 256 m) dphi} (f32, set up once): one multiply per staged sample.
     //   mixer after the FIR: ro = rot(R (jb + 2 tid)) is this lane's first output's rotor.
-    cf lrow[PR], lhalo[2];
+    constexpr int NROW = PRE && !PF ? PR : 1;
+    cf lrow[NROW], lhalo[2];
     double tt_c = 1.0, tt_s = 0.0, ro_c = 1.0, ro_s = 0.0;
     {
         const long long jb0 = static_cast<long long>(t0) * ts - ovl;
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(DC_WG, DcGeom<R>::WGPC) void fir_decim_kernel(const
             rotor_at(static_cast<uint64_t>(static_cast<long long>(tid) - hl) * a.frac, c, sn);
             const cf h0 = cf{static_cast<float>(c), static_cast<float>(sn)};
 #pragma unroll
-            for (int m = 0; m < PR; ++m) lrow[m] = m ? cmulf(l0, to_cf(a.step[m])) : l0;
+            for (int m = 0; m < NROW; ++m) lrow[m] = m ? cmulf(l0, to_cf(a.step[m])) : l0;
 #pragma unroll
             for (int m = 0; m < 2; ++m) lhalo[m] = m ? cmulf(h0, to_cf(a.step[m])) : h0;
             rotor_at(a.turns0 + static_cast<uint64_t>(R * jb0) * a.frac, tt_c, tt_s);
@@ -197,14 +204,16 @@ __global__ __launch_bounds__(DC_WG, DcGeom<R>::WGPC) void fir_decim_kernel(const
     }
     if (a.stamps) st_prev = __builtin_amdgcn_s_memtime();
 
+    if (PF) load_tile(t0);
     for (size_t t = t0; t < t1; ++t) {
         const long long jb = static_cast<long long>(t) * ts - ovl;  // first output computed by this tile
         // ---- stage the tile: 2R rows of new samples, then the halo (<= 2 rows)
-        load_tile(t);
+        if (!PF) load_tile(t);
         DC_STAMP(0)  // global loads landed
         if (pre) {
 #pragma unroll
-            for (int m = 0; m < PR; ++m) x[m] = cmulf(x[m], lrow[m]);
+            for (int m = 0; m < PR; ++m)
+                x[m] = cmulf(x[m], PF ? (m ? cmulf(lrow[0], to_cf(a.step[m])) : lrow[0]) : lrow[m < NROW ? m : 0]);
 #pragma unroll
             for (int m = 0; m < 2; ++m) xh[m] = cmulf(xh[m], lhalo[m]);
         }
@@ -216,6 +225,7 @@ __global__ __launch_bounds__(DC_WG, DcGeom<R>::WGPC) void fir_decim_kernel(const
         DC_STAMP(1)  // mixer + LDS writes
         lds_barrier();
         DC_STAMP(2)
+        if (PF && t + 1 < t1) load_tile(t + 1);  // in flight during the filter loop
 
         // ---- outputs j = jb + 2 tid + c:  y_c = sum_k h[k] u[R j - k]
         // tile sample index of u[R j - k] is 2R (tid + hlq) + (R c - k) = 2R (tid + hlq - d) + p with
@@ -312,24 +322,43 @@ __global__ __launch_bounds__(DC_WG, DcGeom<R>::WGPC) void fir_decim_kernel(const
 #undef DC_STAMP
 }
 
+template <int R, bool REAL, bool PRE, bool PF>
+static comms_status_t launch_decim_v(const DecimArgs& a, unsigned blocks, size_t lds, hipStream_t s) {
+    static DeviceOnce attr_once;
+    if (attr_once.need())
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_decim_kernel<R, REAL, PRE, PF>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    fir_decim_kernel<R, REAL, PRE, PF><<<dim3(blocks), dim3(DC_WG), lds, s>>>(a);
+    return launch_ok("fir_decim_kernel");
+}
+
+// prefetch variant per chain form: COMMS_DECIM_PREFETCH = bit 0 (mixer after the FIR), bit 1 (mixer first)
+static int decim_prefetch_mask() {
+    static const int m = [] {
+        const char* v = getenv("COMMS_DECIM_PREFETCH");
+        return v && *v ? atoi(v) : 3;
+    }();
+    return m;
+}
+
 template <int R>
 static comms_status_t launch_decim(const DecimArgs& a, bool real, hipStream_t s) {
     constexpr size_t lds = DcGeom<R>::LDS;
     // persistent grid: every workgroup slot of the chip gets a contiguous run of tiles
     const size_t slots = static_cast<size_t>(DcGeom<R>::WGPC) * kNumCU;
     const unsigned blocks = static_cast<unsigned>(a.n_tiles < slots ? a.n_tiles : slots);
-    static DeviceOnce attr_once;
-    if (attr_once.need()) {
-        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_decim_kernel<R, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_decim_kernel<R, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    const bool pre = (a.mode & COMMS_CHAIN_PRE) != 0;
+    const bool pf = (decim_prefetch_mask() >> (pre ? 1 : 0)) & 1;
+    switch ((real ? 4 : 0) | (pre ? 2 : 0) | (pf ? 1 : 0)) {
+        case 0: return launch_decim_v<R, false, false, false>(a, blocks, lds, s);
+        case 1: return launch_decim_v<R, false, false, true>(a, blocks, lds, s);
+        case 2: return launch_decim_v<R, false, true, false>(a, blocks, lds, s);
+        case 3: return launch_decim_v<R, false, true, true>(a, blocks, lds, s);
+        case 4: return launch_decim_v<R, true, false, false>(a, blocks, lds, s);
+        case 5: return launch_decim_v<R, true, false, true>(a, blocks, lds, s);
+        case 6: return launch_decim_v<R, true, true, false>(a, blocks, lds, s);
+        default: return launch_decim_v<R, true, true, true>(a, blocks, lds, s);
     }
-    if (real)
-        fir_decim_kernel<R, true><<<dim3(blocks), dim3(DC_WG), lds, s>>>(a);
-    else
-        fir_decim_kernel<R, false><<<dim3(blocks), dim3(DC_WG), lds, s>>>(a);
-    return launch_ok("fir_decim_kernel");
 }
 
 }  // namespace comms

@@ -1,6 +1,8 @@
 // runtime.hip -- library-wide plumbing: errors, device selection, ref-counted
 // device buffers (the DeviceBuf<T> message type), synthetic IQ generator.
 #include <atomic>
+#include <mutex>
+#include <vector>
 
 #include "common.hpp"
 
@@ -53,12 +55,74 @@ __global__ void synth_iq_kernel(float2* out, size_t n, uint64_t first, uint64_t 
 
 using namespace comms;
 
+// Device-resident message.  Besides the allocation it carries what lets node threads hand it
+// from stream to stream without ever synchronising the device:
+//   ready -- recorded by the producer after the launch that fills the buffer; a consumer's
+//            stream waits on it (hipStreamWaitEvent) before its own launch;
+//   uses  -- one event per consumer launch that reads the buffer; the memory goes back to the
+//            pool at refcount 0 and is handed out again only once these have completed.
 struct comms_buf {
     void* ptr;
-    size_t bytes;
+    size_t bytes;      // what the caller asked for
+    size_t cap;        // size class actually allocated
     int32_t device;
     std::atomic<int> refs;
+    std::mutex m;      // clones of one buffer live on different node threads
+    hipEvent_t ready = nullptr;
+    bool ready_set = false;
+    std::vector<hipEvent_t> uses;
 };
+
+namespace {
+
+// Per-device cache of released allocations by size class (powers of two from 256 B) and of
+// events, so that a steady-state graph does no hipMalloc / hipFree / hipEventCreate per message
+// (hipFree synchronises the whole device).  COMMS_BUF_POOL_MB caps the cached bytes per device
+// (default 8192; 0 disables caching).
+struct PoolBlock {
+    void* ptr;
+    std::vector<hipEvent_t> uses;  // readers that may still be running
+};
+struct DevicePool {
+    std::mutex m;
+    std::vector<PoolBlock> free_blocks[48];
+    std::vector<hipEvent_t> free_events;
+    size_t cached_bytes = 0;
+};
+DevicePool g_pools[64];
+size_t pool_cap_bytes() {
+    static const size_t cap = [] {
+        const char* v = getenv("COMMS_BUF_POOL_MB");
+        return static_cast<size_t>(v && *v ? atol(v) : 8192) << 20;
+    }();
+    return cap;
+}
+int size_class(size_t bytes, size_t* cap) {
+    int c = 8;
+    while ((static_cast<size_t>(1) << c) < bytes) ++c;
+    *cap = static_cast<size_t>(1) << c;
+    return c;
+}
+hipEvent_t pool_event(DevicePool& p) {  // caller holds no lock; current device is the pool's
+    {
+        std::lock_guard<std::mutex> lk(p.m);
+        if (!p.free_events.empty()) {
+            hipEvent_t e = p.free_events.back();
+            p.free_events.pop_back();
+            return e;
+        }
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return e;
+}
+void pool_return_events(DevicePool& p, std::vector<hipEvent_t>& evs) {
+    std::lock_guard<std::mutex> lk(p.m);
+    for (hipEvent_t e : evs) p.free_events.push_back(e);
+    evs.clear();
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -91,18 +155,52 @@ comms_status_t comms_device_info(int32_t device, char* name, size_t name_cap, in
 comms_status_t comms_buf_alloc(size_t bytes, int32_t device, comms_buf_t** out) {
     COMMS_ARG(out != nullptr, "out is NULL");
     *out = nullptr;
+    COMMS_ARG(device >= 0 && device < 64, "device index out of range");
     COMMS_TRY(use_device(device));
     comms_buf* b = new (std::nothrow) comms_buf;
     COMMS_ARG(b != nullptr, "out of host memory");
     b->ptr = nullptr;
     b->bytes = bytes;
+    b->cap = 0;
     b->device = device;
     b->refs.store(1);
     if (bytes) {
-        hipError_t e = hipMalloc(&b->ptr, bytes);
-        if (e != hipSuccess) {
-            delete b;
-            return fail(COMMS_ERR_DEVICE, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        const int cls = size_class(bytes, &b->cap);
+        DevicePool& p = g_pools[device];
+        PoolBlock blk{nullptr, {}};
+        {
+            std::lock_guard<std::mutex> lk(p.m);
+            auto& fl = p.free_blocks[cls];
+            if (!fl.empty()) {
+                blk = std::move(fl.back());
+                fl.pop_back();
+                p.cached_bytes -= b->cap;
+            }
+        }
+        if (blk.ptr) {
+            // readers of the block's previous life: normally long finished, so this does not block.
+            // A block whose users never recorded anything (callers that pass raw pointers to
+            // *_run_dev on streams of their own) gets what hipFree used to give them: a device sync.
+            hipError_t e = blk.uses.empty() ? hipDeviceSynchronize() : hipSuccess;
+            for (hipEvent_t ev : blk.uses)
+                if (e == hipSuccess) e = hipEventSynchronize(ev);
+            pool_return_events(p, blk.uses);
+            if (e != hipSuccess) {
+                (void)hipFree(blk.ptr);
+                delete b;
+                return fail(COMMS_ERR_DEVICE, "waiting for a recycled buffer's readers: %s", hipGetErrorString(e));
+            }
+            b->ptr = blk.ptr;
+        } else {
+            hipError_t e = hipMalloc(&b->ptr, b->cap);
+            if (e != hipSuccess) {
+                comms_buf_pool_trim(device);  // give the cache back and try once more
+                e = hipMalloc(&b->ptr, b->cap);
+            }
+            if (e != hipSuccess) {
+                delete b;
+                return fail(COMMS_ERR_DEVICE, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+            }
         }
     }
     *out = b;
@@ -116,12 +214,118 @@ comms_status_t comms_buf_retain(comms_buf_t* b) {
 comms_status_t comms_buf_release(comms_buf_t* b) {
     COMMS_ARG(b != nullptr, "buffer is NULL");
     if (b->refs.fetch_sub(1) == 1) {
+        DevicePool& p = g_pools[b->device];
+        if (b->ready) {
+            if (b->ready_set && b->uses.empty() && b->ptr) {
+                // filled by a launch that no reader followed: that launch is the block's last user
+                b->uses.push_back(b->ready);
+            } else {  // the producer's launch precedes every reader's: the readers' events cover it
+                std::lock_guard<std::mutex> lk(p.m);
+                p.free_events.push_back(b->ready);
+            }
+            b->ready = nullptr;
+        }
         if (b->ptr) {
-            COMMS_TRY(use_device(b->device));
-            COMMS_HIP_TRY(hipFree(b->ptr));
+            bool cached = false;
+            size_t cap = 0;
+            const int cls = size_class(b->cap, &cap);
+            {
+                std::lock_guard<std::mutex> lk(p.m);
+                if (p.cached_bytes + b->cap <= pool_cap_bytes()) {
+                    p.free_blocks[cls].push_back(PoolBlock{b->ptr, std::move(b->uses)});
+                    p.cached_bytes += b->cap;
+                    cached = true;
+                }
+            }
+            if (!cached) {
+                COMMS_TRY(use_device(b->device));
+                COMMS_HIP_TRY(hipFree(b->ptr));  // synchronises the device: every reader is done
+                pool_return_events(p, b->uses);
+            }
         }
         delete b;
     }
+    return COMMS_OK;
+}
+// Frees every cached allocation of `device` (the events stay pooled).
+comms_status_t comms_buf_pool_trim(int32_t device) {
+    COMMS_ARG(device >= 0 && device < 64, "device index out of range");
+    DevicePool& p = g_pools[device];
+    std::vector<PoolBlock> all;
+    {
+        std::lock_guard<std::mutex> lk(p.m);
+        for (auto& fl : p.free_blocks) {
+            for (auto& blk : fl) all.push_back(std::move(blk));
+            fl.clear();
+        }
+        p.cached_bytes = 0;
+    }
+    if (all.empty()) return COMMS_OK;
+    COMMS_TRY(use_device(device));
+    for (auto& blk : all) {
+        (void)hipFree(blk.ptr);
+        pool_return_events(p, blk.uses);
+    }
+    return COMMS_OK;
+}
+
+// ---- ordering that travels with the buffer (device-resident graphs; nodes.hpp *Dev nodes)
+comms_status_t comms_buf_record_ready(comms_buf_t* b, void* stream) {
+    COMMS_ARG(b != nullptr, "buffer is NULL");
+    COMMS_TRY(use_device(b->device));
+    std::lock_guard<std::mutex> lk(b->m);
+    if (!b->ready) {
+        b->ready = pool_event(g_pools[b->device]);
+        if (!b->ready) return fail(COMMS_ERR_DEVICE, "hipEventCreate failed");
+    }
+    COMMS_HIP_TRY(hipEventRecord(b->ready, reinterpret_cast<hipStream_t>(stream)));
+    b->ready_set = true;
+    return COMMS_OK;
+}
+comms_status_t comms_buf_wait_ready(comms_buf_t* b, void* stream) {
+    COMMS_ARG(b != nullptr, "buffer is NULL");
+    std::lock_guard<std::mutex> lk(b->m);
+    if (!b->ready_set) return COMMS_OK;  // filled synchronously (upload) or never written
+    COMMS_HIP_TRY(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), b->ready, 0));
+    return COMMS_OK;
+}
+comms_status_t comms_buf_record_use(comms_buf_t* b, void* stream) {
+    COMMS_ARG(b != nullptr, "buffer is NULL");
+    COMMS_TRY(use_device(b->device));
+    hipEvent_t e = pool_event(g_pools[b->device]);
+    if (!e) return fail(COMMS_ERR_DEVICE, "hipEventCreate failed");
+    hipError_t err = hipEventRecord(e, reinterpret_cast<hipStream_t>(stream));
+    std::lock_guard<std::mutex> lk(b->m);
+    b->uses.push_back(e);
+    if (err != hipSuccess) return fail(COMMS_ERR_DEVICE, "hipEventRecord: %s", hipGetErrorString(err));
+    return COMMS_OK;
+}
+comms_status_t comms_buf_sync(comms_buf_t* b) {
+    COMMS_ARG(b != nullptr, "buffer is NULL");
+    std::lock_guard<std::mutex> lk(b->m);
+    if (b->ready_set) COMMS_HIP_TRY(hipEventSynchronize(b->ready));
+    return COMMS_OK;
+}
+
+// ---- plain streams for host graph nodes (one per node thread)
+comms_status_t comms_stream_create(int32_t device, void** out_stream) {
+    COMMS_ARG(out_stream != nullptr, "out_stream is NULL");
+    *out_stream = nullptr;
+    COMMS_TRY(use_device(device));
+    hipStream_t s = nullptr;
+    COMMS_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out_stream = s;
+    return COMMS_OK;
+}
+comms_status_t comms_stream_synchronize(int32_t device, void* stream) {
+    COMMS_TRY(use_device(device));
+    COMMS_HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    return COMMS_OK;
+}
+comms_status_t comms_stream_destroy(int32_t device, void* stream) {
+    if (!stream) return COMMS_OK;
+    COMMS_TRY(use_device(device));
+    COMMS_HIP_TRY(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)));
     return COMMS_OK;
 }
 comms_status_t comms_buf_upload(comms_buf_t* b, size_t offset, const void* host, size_t bytes) {
@@ -129,6 +333,7 @@ comms_status_t comms_buf_upload(comms_buf_t* b, size_t offset, const void* host,
     COMMS_ARG(offset <= b->bytes && bytes <= b->bytes - offset, "upload of %zu at %zu exceeds %zu",
               bytes, offset, b->bytes);
     COMMS_TRY(use_device(b->device));
+    COMMS_TRY(comms_buf_sync(b));  // a pending launch that fills the buffer comes first
     if (bytes)
         COMMS_HIP_TRY(hipMemcpy(static_cast<char*>(b->ptr) + offset, host, bytes,
                                 hipMemcpyHostToDevice));
@@ -139,6 +344,7 @@ comms_status_t comms_buf_download(const comms_buf_t* b, size_t offset, void* hos
     COMMS_ARG(offset <= b->bytes && bytes <= b->bytes - offset,
               "download of %zu at %zu exceeds %zu", bytes, offset, b->bytes);
     COMMS_TRY(use_device(b->device));
+    COMMS_TRY(comms_buf_sync(const_cast<comms_buf_t*>(b)));  // the producer's launch (on its own stream) comes first
     if (bytes)
         COMMS_HIP_TRY(hipMemcpy(host, static_cast<const char*>(b->ptr) + offset, bytes,
                                 hipMemcpyDeviceToHost));

@@ -19,6 +19,7 @@
 #include <mutex>
 #include <optional>
 #include <utility>
+#include <vector>
 
 namespace comms {
 namespace channel {
@@ -54,6 +55,25 @@ public:
         s_->q.push_back(std::move(v));
         lk.unlock();
         s_->not_empty.notify_one();
+        return true;
+    }
+
+    // The same as send() on every element in order, under one lock while capacity allows
+    // (per-sample nodes that process a drained block hand their outputs back this way).
+    bool send_many(std::vector<T>&& vs) const {
+        size_t i = 0;
+        while (i < vs.size()) {
+            std::unique_lock<std::mutex> lk(s_->m);
+            if (s_->capacity)
+                s_->not_full.wait(lk, [&] { return s_->q.size() < s_->capacity || s_->receivers == 0; });
+            if (s_->receivers == 0) return false;
+            const size_t room = s_->capacity ? s_->capacity - s_->q.size() : vs.size() - i;
+            const size_t take = room < vs.size() - i ? room : vs.size() - i;
+            for (size_t k = 0; k < take; ++k) s_->q.push_back(std::move(vs[i + k]));
+            i += take;
+            lk.unlock();
+            s_->not_empty.notify_all();
+        }
         return true;
     }
 
@@ -109,6 +129,21 @@ public:
         s_->q.pop_front();
         s_->not_full.notify_one();
         return v;
+    }
+    // recv() for the first message, then try_recv() for whatever else is already queued (at most
+    // `max` in all), appended to `out` in order.  0 = disconnected and drained.
+    size_t recv_many(std::vector<T>& out, size_t max) const {
+        std::unique_lock<std::mutex> lk(s_->m);
+        s_->not_empty.wait(lk, [&] { return !s_->q.empty() || s_->senders == 0; });
+        size_t n = 0;
+        while (n < max && !s_->q.empty()) {
+            out.push_back(std::move(s_->q.front()));
+            s_->q.pop_front();
+            ++n;
+        }
+        lk.unlock();
+        if (n) s_->not_full.notify_all();
+        return n;
     }
     size_t len() const {
         std::lock_guard<std::mutex> lk(s_->m);

@@ -94,6 +94,12 @@ template <class T>
 struct is_optional : std::false_type {};
 template <class T>
 struct is_optional<std::optional<T>> : std::true_type {};
+// a node that can process a drained run of messages in one go declares
+//   Result<std::vector<Out>> run_block(const std::vector<In>& ins)
+template <class D, class = void>
+struct has_run_block : std::false_type {};
+template <class D>
+struct has_run_block<D, std::void_t<decltype(&D::run_block)>> : std::true_type {};
 }  // namespace detail
 
 // What #[derive(Node)] generates.  `Derived` lists its fields through
@@ -118,10 +124,33 @@ struct DeriveNode : Node {
         }
     }
 
+    // Per-sample nodes whose run() costs a device launch (FirNode, MixerNode, PulseNode,
+    // FFTSampleNode) would turn every message into a launch + synchronisation.  When the node
+    // offers run_block(), call() drains what is ALREADY queued behind the first message (recv, then
+    // try_recv: it never waits for more), runs the block in one launch and sends the outputs one by
+    // one in order -- every receiver sees exactly the message sequence of the reference's loop
+    // (node_derive/src/lib.rs:200-211), a lone message is processed at once, and a busy producer
+    // is followed at the rate of the kernel, not of the launch.
+    static constexpr size_t kMaxBlock = size_t(1) << 16;
+
     Status call() override {
         auto& self = static_cast<Derived&>(*this);
         auto recvs = self.receivers();
-        return recv_then_run(self, recvs, std::make_index_sequence<std::tuple_size_v<decltype(recvs)>>{});
+        if constexpr (detail::has_run_block<Derived>::value && std::tuple_size_v<decltype(recvs)> == 1) {
+            auto& r = std::get<0>(recvs);
+            if (!r) return Status(NodeError::PermanentError);
+            using In = typename std::remove_reference_t<decltype(r)>::value_type::value_type;
+            static thread_local std::vector<In> block_in;  // a node lives on one thread; reused across calls
+            block_in.clear();
+            if (!r->recv_many(block_in, kMaxBlock)) return Status(NodeError::DataEnd);
+            auto res = self.run_block(block_in);
+            if (res.is_err()) return Status(res.error());
+            bool ok = true;
+            std::apply([&](auto&... snd) { (..., send_block(snd, res.value(), ok)); }, self.senders());
+            return ok ? Ok() : Status(NodeError::CommError);
+        } else {
+            return recv_then_run(self, recvs, std::make_index_sequence<std::tuple_size_v<decltype(recvs)>>{});
+        }
     }
 
     bool is_connected() const override {
@@ -133,6 +162,15 @@ struct DeriveNode : Node {
     }
 
 private:
+    template <class S, class V>
+    static void send_block(S& snd, const std::vector<V>& outs, bool& ok) {
+        for (auto& sv : snd) {
+            if (!ok) return;
+            std::vector<V> copy(outs);  // send(res.clone()) per message
+            if (!sv.first.send_many(std::move(copy))) ok = false;
+        }
+    }
+
     template <class Tuple, size_t... I>
     Status recv_then_run(Derived& self, Tuple& recvs, std::index_sequence<I...>) {
         // Some(ref r) => r.recv().or(Err(DataEnd))?, None => return Err(PermanentError)

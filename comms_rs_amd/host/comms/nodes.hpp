@@ -77,6 +77,7 @@ public:
         return v;
     }
     T* ptr() const { return static_cast<T*>(comms_buf_ptr(b_)); }
+    comms_buf_t* raw() const { return b_; }  // for comms_buf_{wait_ready,record_use,record_ready}
     size_t size() const { return count_; }
     int device() const { return comms_buf_device(b_); }
 
@@ -134,6 +135,14 @@ public:
         if (st != COMMS_OK) return to_node_error(st);
         return out;
     }
+    // the samples already queued behind the first one, in one launch (DeriveNode::call): the
+    // filter's state runs through the block exactly as through the same samples one by one
+    Result<std::vector<Complex32>> run_block(const std::vector<Complex32>& ins) {
+        std::vector<Complex32> out(ins.size());
+        comms_status_t st = comms_fir_run(h_, c32(ins.data()), ins.size(), c32(out.data()));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
     auto receivers() { return std::tie(input); }
     auto senders() { return std::tie(output); }
 
@@ -165,6 +174,15 @@ public:
         if (st != COMMS_OK) return to_node_error(st);
         return out;
     }
+    // queued symbols in one launch; still one Vec of sam_per_sym samples per symbol downstream
+    Result<std::vector<std::vector<Complex32>>> run_block(const std::vector<Complex32>& syms) {
+        std::vector<Complex32> flat(syms.size() * sps_);
+        comms_status_t st = comms_pulse_run(h_, c32(syms.data()), syms.size(), c32(flat.data()));
+        if (st != COMMS_OK) return to_node_error(st);
+        std::vector<std::vector<Complex32>> out(syms.size());
+        for (size_t i = 0; i < syms.size(); ++i) out[i].assign(flat.begin() + i * sps_, flat.begin() + (i + 1) * sps_);
+        return out;
+    }
     auto receivers() { return std::tie(input); }
     auto senders() { return std::tie(output); }
 
@@ -189,6 +207,12 @@ public:
     Result<Complex32> run(const Complex32& in) {
         Complex32 out;
         comms_status_t st = comms_mixer_run(h_, c32(&in), 1, c32(&out));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    Result<std::vector<Complex32>> run_block(const std::vector<Complex32>& ins) {  // see FirNode::run_block
+        std::vector<Complex32> out(ins.size());
+        comms_status_t st = comms_mixer_run(h_, c32(ins.data()), ins.size(), c32(out.data()));
         if (st != COMMS_OK) return to_node_error(st);
         return out;
     }
@@ -353,6 +377,21 @@ public:
         if (st != COMMS_OK) return to_node_error(st);
         return std::optional<std::vector<Complex32>>(std::move(out));
     }
+    // queued samples at once: every completed run of fft_size samples becomes one output message
+    // (all of them transformed by one batched launch); the remainder waits in `samples_` as before
+    Result<std::vector<std::vector<Complex32>>> run_block(const std::vector<Complex32>& ins) {
+        samples_.insert(samples_.end(), ins.begin(), ins.end());
+        const size_t k = n_ ? samples_.size() / n_ : 0;
+        std::vector<std::vector<Complex32>> outs;
+        if (!k) return outs;
+        std::vector<Complex32> flat(k * n_);
+        comms_status_t st = comms_fft_run(h_, c32(samples_.data()), k * n_, c32(flat.data()));
+        samples_.erase(samples_.begin(), samples_.begin() + k * n_);
+        if (st != COMMS_OK) return to_node_error(st);
+        outs.resize(k);
+        for (size_t i = 0; i < k; ++i) outs[i].assign(flat.begin() + i * n_, flat.begin() + (i + 1) * n_);
+        return outs;
+    }
     auto receivers() { return std::tie(input); }
     auto senders() { return std::tie(output); }
 
@@ -448,26 +487,57 @@ inline std::vector<double> qfilt_taps(uint32_t n_taps, double alpha, uint32_t sa
 }
 
 // ---------------------------------------------------------------- device-resident nodes
-// Messages are DeviceBuf<T>: nothing crosses PCIe between nodes; each run() is one
-// asynchronous kernel on the node's own stream followed by a stream wait, so the
-// consumer may touch the buffer as soon as it receives it.
+// Messages are DeviceBuf<T>: nothing crosses PCIe between nodes and nothing ever synchronises
+// the device.  Every node owns a stream (DevStream); run() is
+//     wait_ready(in)  ->  one asynchronous launch on the node's stream  ->  record_use(in),
+//     record_ready(out)  ->  send(out)
+// so the consumer's stream starts its own launch only after the producer's has finished, on the
+// same or on another GPU, while the node threads themselves run ahead of the device.  Output
+// buffers come from the library's cache (no hipMalloc / hipFree in steady state); a buffer's
+// memory is recycled only after the launches that read it.  to_host() waits for the producer.
+class DevStream {
+public:
+    explicit DevStream(int device) : device_(device) { throw_on(comms_stream_create(device, &s_), "comms_stream_create"); }
+    DevStream(DevStream&& o) noexcept : s_(o.s_), device_(o.device_) { o.s_ = nullptr; }
+    DevStream(const DevStream&) = delete;
+    ~DevStream() {
+        if (!s_) return;
+        comms_stream_synchronize(device_, s_);
+        comms_stream_destroy(device_, s_);
+    }
+    // `launch(stream)` is the node's *_run_dev call
+    template <class TI, class TO, class F>
+    comms_status_t run(const DeviceBuf<TI>& in, DeviceBuf<TO>& out, F&& launch) {
+        comms_status_t st = comms_buf_wait_ready(in.raw(), s_);
+        if (st == COMMS_OK) st = launch(s_);
+        if (st == COMMS_OK) st = comms_buf_record_use(in.raw(), s_);
+        if (st == COMMS_OK) st = comms_buf_record_ready(out.raw(), s_);
+        return st;
+    }
+    int device() const { return device_; }
+
+private:
+    void* s_ = nullptr;
+    int device_;
+};
+
 class BatchFirNodeDev : public DeriveNode<BatchFirNodeDev> {
 public:
     NodeReceiver<DeviceBuf<Complex32>> input;
     NodeSender<DeviceBuf<Complex32>> output;
     BatchFirNodeDev(const std::vector<Complex32>& taps, const std::optional<std::vector<Complex32>>& state = std::nullopt,
                     int device = 0)
-        : device_(device) {
+        : device_(device), st_(device) {
         throw_on(comms_fir_create(c32(taps.data()), taps.size(), state ? c32(state->data()) : nullptr,
                                   state ? state->size() : 0, device, &h_),
                  "BatchFirNodeDev::new");
     }
     BatchFirNodeDev(BatchFirNodeDev&& o) noexcept
-        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), device_(o.device_) { o.h_ = nullptr; }
+        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), device_(o.device_), st_(std::move(o.st_)) { o.h_ = nullptr; }
     ~BatchFirNodeDev() { comms_fir_destroy(h_); }
     Result<DeviceBuf<Complex32>> run(const DeviceBuf<Complex32>& in) {
         DeviceBuf<Complex32> out(in.size(), device_);
-        comms_status_t st = comms_fir_run_dev(h_, c32(in.ptr()), in.size(), c32(out.ptr()), nullptr);
+        comms_status_t st = st_.run(in, out, [&](void* s) { return comms_fir_run_dev(h_, c32(in.ptr()), in.size(), c32(out.ptr()), s); });
         if (st != COMMS_OK) return to_node_error(st);
         return out;
     }
@@ -477,21 +547,22 @@ public:
 private:
     comms_fir_t* h_ = nullptr;
     int device_;
+    DevStream st_;
 };
 
 class BatchMixerNodeDev : public DeriveNode<BatchMixerNodeDev> {
 public:
     NodeReceiver<DeviceBuf<Complex32>> input;
     NodeSender<DeviceBuf<Complex32>> output;
-    explicit BatchMixerNodeDev(double dphase, std::optional<double> phase = std::nullopt, int device = 0) : device_(device) {
+    explicit BatchMixerNodeDev(double dphase, std::optional<double> phase = std::nullopt, int device = 0) : device_(device), st_(device) {
         throw_on(comms_mixer_create(dphase, phase.value_or(0.0), device, &h_), "BatchMixerNodeDev::new");
     }
     BatchMixerNodeDev(BatchMixerNodeDev&& o) noexcept
-        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), device_(o.device_) { o.h_ = nullptr; }
+        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), device_(o.device_), st_(std::move(o.st_)) { o.h_ = nullptr; }
     ~BatchMixerNodeDev() { comms_mixer_destroy(h_); }
     Result<DeviceBuf<Complex32>> run(const DeviceBuf<Complex32>& in) {
         DeviceBuf<Complex32> out(in.size(), device_);
-        comms_status_t st = comms_mixer_run_dev(h_, c32(in.ptr()), in.size(), c32(out.ptr()), nullptr);
+        comms_status_t st = st_.run(in, out, [&](void* s) { return comms_mixer_run_dev(h_, c32(in.ptr()), in.size(), c32(out.ptr()), s); });
         if (st != COMMS_OK) return to_node_error(st);
         return out;
     }
@@ -501,19 +572,21 @@ public:
 private:
     comms_mixer_t* h_ = nullptr;
     int device_;
+    DevStream st_;
 };
 
 class DecimateNodeDev : public DeriveNode<DecimateNodeDev> {
 public:
     NodeReceiver<DeviceBuf<Complex32>> input;
     NodeSender<DeviceBuf<Complex32>> output;
-    explicit DecimateNodeDev(size_t dec_rate, int device = 0) : rate_(dec_rate), device_(device) {}
+    explicit DecimateNodeDev(size_t dec_rate, int device = 0) : rate_(dec_rate), device_(device), st_(device) {}
     Result<DeviceBuf<Complex32>> run(const DeviceBuf<Complex32>& in) {
         size_t n_out = 0;
         comms_decimate_out_len(in.size(), rate_, &n_out);
         DeviceBuf<Complex32> out(n_out, device_);
-        comms_status_t st = comms_decimate_run_dev(in.ptr(), in.size(), sizeof(Complex32), rate_, out.ptr(), nullptr,
-                                                   device_, nullptr);
+        comms_status_t st = st_.run(in, out, [&](void* s) {
+            return comms_decimate_run_dev(in.ptr(), in.size(), sizeof(Complex32), rate_, out.ptr(), nullptr, device_, s);
+        });
         if (st != COMMS_OK) return to_node_error(st);
         return out;
     }
@@ -523,24 +596,25 @@ public:
 private:
     size_t rate_;
     int device_;
+    DevStream st_;
 };
 
 // One macro-free pattern for the remaining device-resident nodes: own the C handle, move-only,
-// run() allocates the output DeviceBuf and launches on the default stream.
+// run() takes the output DeviceBuf from the cache and launches on the node's stream.
 class FFTBatchNodeDev : public DeriveNode<FFTBatchNodeDev> {
 public:
     NodeReceiver<DeviceBuf<Complex32>> input;
     NodeSender<DeviceBuf<Complex32>> output;
-    FFTBatchNodeDev(size_t fft_size, bool ifft, int device = 0) : device_(device) {
+    FFTBatchNodeDev(size_t fft_size, bool ifft, int device = 0) : device_(device), st_(device) {
         throw_on(comms_fft_create(fft_size, ifft ? 1 : 0, device, &h_), "FFTBatchNodeDev::new");
     }
     FFTBatchNodeDev(FFTBatchNodeDev&& o) noexcept
-        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), device_(o.device_) { o.h_ = nullptr; }
+        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), device_(o.device_), st_(std::move(o.st_)) { o.h_ = nullptr; }
     ~FFTBatchNodeDev() { comms_fft_destroy(h_); }
     // the message may hold any whole number of transforms (the reference: exactly one)
     Result<DeviceBuf<Complex32>> run(const DeviceBuf<Complex32>& in) {
         DeviceBuf<Complex32> out(in.size(), device_);
-        comms_status_t st = comms_fft_run_dev(h_, c32(in.ptr()), in.size(), c32(out.ptr()), nullptr);
+        comms_status_t st = st_.run(in, out, [&](void* s) { return comms_fft_run_dev(h_, c32(in.ptr()), in.size(), c32(out.ptr()), s); });
         if (st != COMMS_OK) return to_node_error(st);
         return out;
     }
@@ -550,21 +624,22 @@ public:
 private:
     comms_fft_t* h_ = nullptr;
     int device_;
+    DevStream st_;
 };
 
 class FMDemodNodeDev : public DeriveNode<FMDemodNodeDev> {
 public:
     NodeReceiver<DeviceBuf<Complex32>> input;
     NodeSender<DeviceBuf<float>> output;
-    explicit FMDemodNodeDev(int device = 0) : device_(device) {
+    explicit FMDemodNodeDev(int device = 0) : device_(device), st_(device) {
         throw_on(comms_fmdemod_create(device, &h_), "FMDemodNodeDev::new");
     }
     FMDemodNodeDev(FMDemodNodeDev&& o) noexcept
-        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), device_(o.device_) { o.h_ = nullptr; }
+        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), device_(o.device_), st_(std::move(o.st_)) { o.h_ = nullptr; }
     ~FMDemodNodeDev() { comms_fmdemod_destroy(h_); }
     Result<DeviceBuf<float>> run(const DeviceBuf<Complex32>& in) {
         DeviceBuf<float> out(in.size(), device_);
-        comms_status_t st = comms_fmdemod_run_dev(h_, c32(in.ptr()), in.size(), out.ptr(), nullptr);
+        comms_status_t st = st_.run(in, out, [&](void* s) { return comms_fmdemod_run_dev(h_, c32(in.ptr()), in.size(), out.ptr(), s); });
         if (st != COMMS_OK) return to_node_error(st);
         return out;
     }
@@ -574,6 +649,7 @@ public:
 private:
     comms_fmdemod_t* h_ = nullptr;
     int device_;
+    DevStream st_;
 };
 
 // PulseNode over whole symbol blocks: n symbols in, n * sam_per_sym samples out
@@ -582,11 +658,11 @@ public:
     NodeReceiver<DeviceBuf<Complex32>> input;
     NodeSender<DeviceBuf<Complex32>> output;
     BatchPulseNodeDev(const std::vector<Complex32>& taps, size_t sam_per_sym, int device = 0)
-        : sps_(sam_per_sym), device_(device) {
+        : sps_(sam_per_sym), device_(device), st_(device) {
         throw_on(comms_pulse_create(c32(taps.data()), taps.size(), sam_per_sym, device, &h_), "BatchPulseNodeDev::new");
     }
     BatchPulseNodeDev(BatchPulseNodeDev&& o) noexcept
-        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), sps_(o.sps_), device_(o.device_) { o.h_ = nullptr; }
+        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), sps_(o.sps_), device_(o.device_), st_(std::move(o.st_)) { o.h_ = nullptr; }
     ~BatchPulseNodeDev() { comms_pulse_destroy(h_); }
     BatchPulseNodeDev& with_mixer(double dphase, std::optional<double> phase = std::nullopt) {
         throw_on(comms_pulse_set_mixer(h_, dphase, phase.value_or(0.0)), "BatchPulseNodeDev::with_mixer");
@@ -594,7 +670,7 @@ public:
     }
     Result<DeviceBuf<Complex32>> run(const DeviceBuf<Complex32>& sym) {
         DeviceBuf<Complex32> out(sym.size() * sps_, device_);
-        comms_status_t st = comms_pulse_run_dev(h_, c32(sym.ptr()), sym.size(), c32(out.ptr()), nullptr);
+        comms_status_t st = st_.run(sym, out, [&](void* s) { return comms_pulse_run_dev(h_, c32(sym.ptr()), sym.size(), c32(out.ptr()), s); });
         if (st != COMMS_OK) return to_node_error(st);
         return out;
     }
@@ -605,19 +681,21 @@ private:
     comms_pulse_t* h_ = nullptr;
     size_t sps_;
     int device_;
+    DevStream st_;
 };
 
 class UpsampleNodeDev : public DeriveNode<UpsampleNodeDev> {
 public:
     NodeReceiver<DeviceBuf<Complex32>> input;
     NodeSender<DeviceBuf<Complex32>> output;
-    explicit UpsampleNodeDev(size_t ups_rate, int device = 0) : rate_(ups_rate), device_(device) {}
+    explicit UpsampleNodeDev(size_t ups_rate, int device = 0) : rate_(ups_rate), device_(device), st_(device) {}
     Result<DeviceBuf<Complex32>> run(const DeviceBuf<Complex32>& in) {
         size_t n_out = 0;
         comms_upsample_out_len(in.size(), rate_, &n_out);
         DeviceBuf<Complex32> out(n_out, device_);
-        comms_status_t st = comms_upsample_run_dev(in.ptr(), in.size(), sizeof(Complex32), rate_, out.ptr(), nullptr,
-                                                   device_, nullptr);
+        comms_status_t st = st_.run(in, out, [&](void* s) {
+            return comms_upsample_run_dev(in.ptr(), in.size(), sizeof(Complex32), rate_, out.ptr(), nullptr, device_, s);
+        });
         if (st != COMMS_OK) return to_node_error(st);
         return out;
     }
@@ -627,6 +705,7 @@ public:
 private:
     size_t rate_;
     int device_;
+    DevStream st_;
 };
 
 // mixer / FIR / decimate [/ FM demod] as ONE node (comms_chain_*; an additional node, the results of
@@ -639,18 +718,18 @@ public:
     NodeSender<DeviceBuf<Out>> output;
     ChainNodeDev(double dphase, double phase, const std::vector<Complex32>& taps, size_t rate, bool mixer_after_fir = false,
                  int device = 0)
-        : rate_(rate), device_(device) {
+        : rate_(rate), device_(device), st_(device) {
         const int32_t flags = (kFm ? COMMS_CHAIN_FM_DEMOD : 0) | (mixer_after_fir ? COMMS_CHAIN_MIXER_AFTER_FIR : 0);
         throw_on(comms_chain_create_ex(dphase, phase, c32(taps.data()), taps.size(), rate, flags, device, &h_),
                  "ChainNodeDev::new");
     }
     ChainNodeDev(ChainNodeDev&& o) noexcept
-        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), rate_(o.rate_), device_(o.device_) { o.h_ = nullptr; }
+        : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), rate_(o.rate_), device_(o.device_), st_(std::move(o.st_)) { o.h_ = nullptr; }
     ~ChainNodeDev() { comms_chain_destroy(h_); }
     Result<DeviceBuf<Out>> run(const DeviceBuf<Complex32>& in) {
         if (rate_ == 0 || in.size() % rate_) return NodeError::DataError;
         DeviceBuf<Out> out(in.size() / rate_, device_);
-        comms_status_t st = comms_chain_run_dev(h_, c32(in.ptr()), in.size(), out.ptr(), nullptr);
+        comms_status_t st = st_.run(in, out, [&](void* s) { return comms_chain_run_dev(h_, c32(in.ptr()), in.size(), out.ptr(), s); });
         if (st != COMMS_OK) return to_node_error(st);
         return out;
     }
@@ -666,6 +745,7 @@ private:
     comms_chain_t* h_ = nullptr;
     size_t rate_;
     int device_;
+    DevStream st_;
 };
 
 }  // namespace comms

@@ -7,14 +7,20 @@ l = c.lib()
 f = l.comms_debug_valu; f.restype = C.c_int32; f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
 out = torch.empty(256 * 8 * 256, dtype=torch.float32, device="cuda:0")
 iters = 20000
-for kind, nm in [(0, "v_fma_f32"), (3, "v_pk_fma_f32"), (4, "cmul=pk_mul+pk_fma (2 instr)"), (5, "v_permlane32_swap (8 per 16 slots)"), (6, "v_permlane16_swap (8 per 16 slots)")]:
-    for wps in (1, 2, 4, 8):   # waves per SIMD
+KINDS = [int(k) for k in os.environ.get("KINDS", "0,3,4,5,6,7,8,9,10,11,12").split(",")]
+for kind, nm in [(k, n) for k, n in [(0, "v_fma_f32"), (3, "v_pk_fma_f32"), (7, "MAC pk_fma acc+=u*SGPRpair, 2 chains"), (8, "MAC pk_fma acc+=u*VGPRpair, 2 chains"),
+                 (20, "form0 acc=u*tV+acc plain"), (21, "form1 +op_sel_hi[1,0,1] on tap"), (22, "form2 +op_sel hi-broadcast on tap"),
+                 (23, "form3 acc=acc*tV+u (dst==src0) plain"), (24, "form4 dst==src0 + op_sel_hi[1,0,1]"), (25, "form5 plain, SGPR tap"),
+                 (26, "form6 2x v_fma_f32 SGPR tap (2 instr)"), (27, "form7 pk_mul(op_sel)+pk_add (2 instr)"), (28, "form8 acc=u*u+acc (2 VGPR pairs)"),
+                 (29, "form9 pk_mul only"),
+                 (9, "MAC SGPR taps, 16 chains"), (10, "MAC VGPR taps, 16 chains"), (11, "MAC SGPR taps, 4 chains"), (12, "MAC VGPR taps, 4 chains"), (4, "cmul=pk_mul+pk_fma (2 instr)"), (5, "v_permlane32_swap (8 per 16 slots)"), (6, "v_permlane16_swap (8 per 16 slots)")] if k in KINDS]:
+    for wps in [int(w) for w in os.environ.get('WPS', '1,2,4,8').split(',')]:   # waves per SIMD
         blocks = 256 * wps
         f(out.data_ptr(), kind, 100, blocks, None)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); f(out.data_ptr(), kind, iters, blocks, None); b.record(); torch.cuda.synchronize()
         ms = a.elapsed_time(b)
-        instr_per_simd = iters * 16 * wps * (2 if kind == 4 else 0.5 if kind >= 5 else 1)
+        instr_per_simd = iters * 16 * wps * (2 if kind in (4, 26, 27) else 0.5 if kind in (5, 6) else 1)
         print("%s waves/SIMD=%d: %.2f ms -> %.2f ns per wave-instr per SIMD = %.2f cycles @2.4GHz" %
               (nm, wps, ms, ms * 1e6 / instr_per_simd, ms * 1e6 / instr_per_simd * 2.4))
 

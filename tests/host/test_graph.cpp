@@ -286,8 +286,148 @@ static void test_channel() {
     CHECK(!ch.second.recv().has_value());  // then RecvError
 }
 
+// ---- drained blocks: a per-sample node that offers run_block() must be indistinguishable, message
+// for message, from the same node driven one sample at a time (node_derive/src/lib.rs:200-211)
+struct RampSource : DeriveNode<RampSource> {
+    int n, i = 0;
+    NodeSender<int> output;
+    explicit RampSource(int n_) : n(n_) {}
+    Result<int> run() {
+        if (i >= n) return NodeError::DataEnd;
+        return i++;
+    }
+    auto receivers() { return std::tie(); }
+    auto senders() { return std::tie(output); }
+};
+struct AccumulateSample : DeriveNode<AccumulateSample> {  // stateful: y[i] = y[i-1] + 3 x[i]
+    NodeReceiver<int> input;
+    NodeSender<long> output, tap;                    // two senders: every one gets every message
+    long acc = 0;
+    size_t calls = 0;
+    Result<long> run(const int& v) {
+        ++calls;
+        return acc += 3L * v;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output, tap); }
+};
+struct AccumulateBlock : DeriveNode<AccumulateBlock> {    // the same node, offering run_block()
+    NodeReceiver<int> input;
+    NodeSender<long> output, tap;
+    long acc = 0;
+    size_t calls = 0, largest = 0;
+    Result<long> run(const int& v) { return acc += 3L * v; }
+    Result<std::vector<long>> run_block(const std::vector<int>& vs) {
+        ++calls;
+        if (vs.size() > largest) largest = vs.size();
+        std::vector<long> out;
+        for (int v : vs) out.push_back(acc += 3L * v);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output, tap); }
+};
+struct PairsBlock : DeriveNode<PairsBlock> {  // #[aggregate] in block form: one Vec per two inputs
+    NodeReceiver<long> input;
+    NodeSender<std::vector<long>> output;
+    std::vector<long> held;
+    Result<std::optional<std::vector<long>>> run(const long& v) {
+        held.push_back(v);
+        if (held.size() < 2) return std::optional<std::vector<long>>(std::nullopt);
+        auto o = std::move(held);
+        held.clear();
+        return std::optional<std::vector<long>>(std::move(o));
+    }
+    Result<std::vector<std::vector<long>>> run_block(const std::vector<long>& vs) {
+        std::vector<std::vector<long>> outs;
+        for (long v : vs) {
+            held.push_back(v);
+            if (held.size() == 2) {
+                outs.push_back(held);
+                held.clear();
+            }
+        }
+        return outs;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+};
+static void test_drained_blocks_equal_per_sample() {
+    const int n = 200001;
+    std::vector<long> per_sample, blocked, tapped;
+    std::vector<std::vector<long>> pairs;
+    {
+        RampSource src(n);
+        AccumulateSample acc;
+        NodeReceiver<long> out, tap;
+        connect_nodes(src.output, acc.input);
+        connect_nodes(acc.output, out);
+        connect_nodes(acc.tap, tap);
+        std::thread a([&] { src.start(); src.output.clear(); });
+        std::thread b([&] { acc.start(); acc.output.clear(); acc.tap.clear(); });
+        while (auto v = out->recv()) per_sample.push_back(*v);
+        a.join();
+        b.join();
+        CHECK(acc.calls == static_cast<size_t>(n));
+    }
+    {
+        RampSource src(n);
+        AccumulateBlock acc;
+        PairsBlock pr;
+        NodeReceiver<long> tap;
+        NodeReceiver<std::vector<long>> out;
+        connect_nodes(src.output, acc.input);
+        connect_nodes(acc.output, pr.input);
+        connect_nodes(acc.tap, tap);
+        connect_nodes(pr.output, out);
+        std::thread a([&] { src.start(); src.output.clear(); });
+        std::thread b([&] { acc.start(); acc.output.clear(); acc.tap.clear(); });
+        std::thread c([&] { pr.start(); pr.output.clear(); });
+        std::thread d([&] { while (auto v = tap->recv()) tapped.push_back(*v); });
+        while (auto v = out->recv()) pairs.push_back(*v);
+        a.join();
+        b.join();
+        c.join();
+        d.join();
+        CHECK(acc.calls >= 1 && acc.calls <= static_cast<size_t>(n));
+        std::printf("drained blocks: %zu calls for %d messages, largest block %zu\n", acc.calls, n, acc.largest);
+    }
+    for (auto& p : pairs) blocked.insert(blocked.end(), p.begin(), p.end());
+    CHECK(pairs.size() == static_cast<size_t>(n / 2));          // the odd last sample stays held, as per sample
+    CHECK(tapped == per_sample);                                 // every sender saw every message, in order
+    per_sample.resize(blocked.size());
+    CHECK(blocked == per_sample);
+    // a lone message is processed at once: call() never waits for a second one
+    {
+        AccumulateBlock acc;
+        NodeSender<int> in;
+        NodeReceiver<long> out, tap;
+        connect_nodes(in, acc.input);
+        connect_nodes(acc.output, out);
+        connect_nodes(acc.tap, tap);
+        CHECK(in[0].first.send(5));
+        CHECK(acc.call().is_ok());
+        CHECK(*out->try_recv() == 15 && *tap->try_recv() == 15);
+        in.clear();
+        CHECK(acc.call().is_err() && acc.call().error() == NodeError::DataEnd);
+    }
+    // bounded channels: send_many respects the capacity (blocks instead of overfilling)
+    {
+        auto ch = channel::bounded<int>(4);
+        std::thread t([&] { CHECK(ch.first.send_many(std::vector<int>{1, 2, 3, 4, 5, 6, 7, 8, 9})); });
+        std::vector<int> got;
+        while (got.size() < 9) {
+            CHECK(ch.second.len() <= 4);
+            CHECK(ch.second.recv_many(got, 3) > 0);
+        }
+        t.join();
+        CHECK((got == std::vector<int>{1, 2, 3, 4, 5, 6, 7, 8, 9}));
+    }
+}
+
 int main() {
     test_channel();
+    test_drained_blocks_equal_per_sample();
     test_counter();
     test_feedback();
     test_fan_in_and_data_end();

@@ -115,6 +115,16 @@ def test_cpp_graph_runtime():
     assert "all passed" in out.stdout
 
 
+@pytest.mark.parametrize("san", ["asan", "tsan"])
+def test_cpp_graph_runtime_under_sanitizers(san):
+    """AddressSanitizer + UBSan, and ThreadSanitizer, over the host graph runtime's own tests (channels,
+    DeriveNode incl. drained blocks, feedback, thread pool, Graph).  CPU build only."""
+    out = subprocess.run(["make", "-C", os.path.join(ROOT, "comms_rs_amd", "host"), san], capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "all passed" in out.stdout
+
+
 def test_shard_ranges():
     from comms_rs_amd.sharding import shard_range
 
