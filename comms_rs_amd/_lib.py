@@ -15,6 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 COMMS_OK, COMMS_ERR_ARG, COMMS_ERR_DEVICE = 0, 1, 2
 FIR_AUTO, FIR_DIRECT, FIR_OVERLAP_SAVE, FIR_OS1024, FIR_OS4096, FIR_OS16K, FIR_OS1024_FIXED = 0, 1, 2, 3, 4, 5, 6
+IQ_C32, IQ_I16, IQ_U8 = 0, 1, 2
 STREAM_HANDLE = C.c_void_p(-1).value  # COMMS_STREAM_HANDLE: the handle's own stream
 
 
@@ -63,6 +64,8 @@ _PROTOS = {
     "comms_timer_read": [_vp, _vp, _sz, _psz],
     "comms_timer_destroy": [_vp],
     "comms_fir_set_timer": [_vp, _vp],
+    "comms_fir_set_input_format": [_vp, _i32, C.c_float],
+    "comms_chain_set_input_format": [_vp, _i32, C.c_float],
     "comms_mixer_set_timer": [_vp, _vp],
     "comms_fmdemod_set_timer": [_vp, _vp],
     "comms_fft_set_timer": [_vp, _vp],

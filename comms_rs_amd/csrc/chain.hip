@@ -46,6 +46,9 @@ struct comms_chain : Handle {
     float2* raw_hist[2] = {nullptr, nullptr};  // unfused + mixer first: last n_eff raw inputs, time order
     int raw_cur = 0;
     std::vector<comms_c32> pending_raw;        // a user state not yet mixed into the FIR node's history
+    int in_fmt = COMMS_IQ_C32;                 // wire format of d_in (comms_chain_set_input_format)
+    float in_scale = 1.0f;
+    Scratch t0;                                // converted input, for the paths that read Complex<f32> only
 };
 
 // four-kernel path with the mixer in front: the FIR node keeps MIXED samples, so a raw user history is
@@ -81,6 +84,7 @@ static void free_chain(comms_chain* h) {
     h->t1.release();
     h->t2.release();
     h->t3.release();
+    h->t0.release();
     h->fini();
     delete h;
 }
@@ -152,23 +156,40 @@ comms_status_t comms_chain_is_fused(const comms_chain_t* h, int32_t* out_fused) 
     return COMMS_OK;
 }
 
-comms_status_t comms_chain_run_dev(comms_chain_t* h, const comms_c32* d_in, size_t n,
+comms_status_t comms_chain_run_dev(comms_chain_t* h, const comms_c32* d_in_any, size_t n,
                                    void* d_out, void* stream) {
     COMMS_ARG(h != nullptr, "handle is NULL");
-    COMMS_ARG((d_in && d_out) || !n, "NULL device pointer");
+    COMMS_ARG((d_in_any && d_out) || !n, "NULL device pointer");
+    const comms_c32* d_in = d_in_any;  // n samples in the chain's input format
     COMMS_ARG(n % h->rate == 0, "n (%zu) must be a multiple of the decimation rate %zu", n, h->rate);
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
-    COMMS_ARG(!ranges_overlap(d_in, n * sizeof(comms_c32), d_out,
+    const size_t in_elem = h->in_fmt == COMMS_IQ_I16 ? 4 : h->in_fmt == COMMS_IQ_U8 ? 2 : 8;
+    COMMS_ARG(!ranges_overlap(d_in, n * in_elem, d_out,
                               (n / h->rate) * (h->fm_demod ? sizeof(float) : sizeof(comms_c32))),
               "the chain cannot run in place");
+    COMMS_ARG((reinterpret_cast<uintptr_t>(d_in) & (in_elem - 1)) == 0, "input must be aligned to one IQ sample");
     hipStream_t hs = nullptr;
     COMMS_TRY(h->enter(stream, &hs));  // the stages' state (history, prev) advances in stream order
     void* s = static_cast<void*>(hs);
+    if (h->in_fmt != COMMS_IQ_C32 && !(h->fused && h->decim)) {
+        // only the time-domain kernel reads wire formats in its load stage; everything else gets one
+        // conversion pass first (same arithmetic, iqformat.hip)
+        COMMS_TRY(h->t0.reserve(n * sizeof(comms_c32)));
+        comms_c32* c = static_cast<comms_c32*>(h->t0.p);
+        if (h->in_fmt == COMMS_IQ_I16)
+            COMMS_TRY(comms_iq_i16_to_c32_dev(reinterpret_cast<const int16_t*>(d_in), n, h->in_scale, c, h->device, s));
+        else
+            COMMS_TRY(comms_iq_u8_to_c32_dev(reinterpret_cast<const uint8_t*>(d_in), n, c, h->device, s));
+        d_in = c;
+    }
     if (h->fused) {
-        COMMS_TRY((h->decim ? comms_fir_run_decim_dev : comms_fir_run_fused_dev)(
-            h->fir, d_in, n, d_out, h->mode, h->turns, h->frac, static_cast<uint32_t>(h->rate), h->d_prev[h->cur],
-            h->d_prev[h->cur ^ 1], s));
+        if (h->decim)
+            COMMS_TRY(comms_fir_run_decim_dev(h->fir, d_in, n, d_out, h->mode, h->turns, h->frac, static_cast<uint32_t>(h->rate),
+                                              h->d_prev[h->cur], h->d_prev[h->cur ^ 1], s));
+        else
+            COMMS_TRY(comms_fir_run_fused_dev(h->fir, d_in, n, d_out, h->mode, h->turns, h->frac, static_cast<uint32_t>(h->rate),
+                                              h->d_prev[h->cur], h->d_prev[h->cur ^ 1], s));
         h->turns += static_cast<uint64_t>(n) * h->frac;
         if (h->fm_demod) h->cur ^= 1;
         return COMMS_OK;
@@ -205,9 +226,23 @@ comms_status_t comms_chain_run(comms_chain_t* h, const comms_c32* in, size_t n, 
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
     const size_t out_bytes = (n / h->rate) * (h->fm_demod ? sizeof(float) : sizeof(comms_c32));
-    return h->run_host(in, n * sizeof(comms_c32), out, out_bytes, [&](void* d_in, void* d_out) {
+    const size_t in_elem = h->in_fmt == COMMS_IQ_I16 ? 4 : h->in_fmt == COMMS_IQ_U8 ? 2 : 8;
+    return h->run_host(in, n * in_elem, out, out_bytes, [&](void* d_in, void* d_out) {
         return comms_chain_run_dev(h, static_cast<const comms_c32*>(d_in), n, d_out, COMMS_STREAM_HANDLE);
     });
+}
+
+// d_in of the run entries then points to raw IQ samples of that format; the conversion (iqformat.hip's
+// arithmetic, bit for bit) happens in the load stage of the time-domain chain kernel -- HBM sees 4 or 2
+// bytes per input sample -- and as one extra pass in front of the other chain forms.
+comms_status_t comms_chain_set_input_format(comms_chain_t* h, int32_t format, float scale) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG(format == COMMS_IQ_C32 || format == COMMS_IQ_I16 || format == COMMS_IQ_U8, "unknown sample format %d", format);
+    COMMS_ARG(format != COMMS_IQ_I16 || std::isfinite(scale), "scale must be finite");
+    h->in_fmt = format;
+    h->in_scale = format == COMMS_IQ_I16 ? scale : 1.0f;
+    if (h->fused && h->decim) COMMS_TRY(comms_fir_set_input_format(h->fir, format, scale));
+    return COMMS_OK;
 }
 
 comms_status_t comms_chain_set_timer(comms_chain_t* h, comms_timer_t* t) {

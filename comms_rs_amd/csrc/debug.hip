@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void probe_mac_form_kernel(float* out, int ite
     for (int i = 0; i < 8; ++i) u[i] = v2f{threadIdx.x * 0.002f + i, 2.0f - i};
 #pragma unroll
     for (int i = 0; i < 8; ++i) tv[i] = v2f{a.t[2 * i], a.t[2 * i + 1]};
-    if (V != 5 && V != 6) {
+    if (V != 5 && V != 6 && V != 13) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(tv[i]));
     }
@@ -239,6 +239,17 @@ __global__ __launch_bounds__(256) void probe_mac_form_kernel(float* out, int ite
             }
             if (V == 8) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(ac) : "v"(uu));        // two distinct VGPR pairs only
             if (V == 9) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(ac) : "v"(uu), "v"(tt));  // no accumulate
+            if (V == 10 || V == 11 || V == 13) {  // lo / hi alternating: 10 same pair twice, 11 a new pair each time, 13 SGPR pair
+                const v2f& t2 = V == 11 ? tv[i & 7] : tt;
+                if (V == 13) {
+                    if (i & 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(ac) : "v"(uu), "s"(t2));
+                    else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(ac) : "v"(uu), "s"(t2));
+                } else {
+                    if (i & 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(ac) : "v"(uu), "v"(t2));
+                    else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(ac) : "v"(uu), "v"(t2));
+                }
+            }
+            if (V == 12) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(ac) : "v"(uu), "v"(tt));  // lo, lo on the same pair
         }
     }
     float s = 0;
@@ -291,11 +302,11 @@ extern "C" comms_status_t comms_debug_valu(float* d_out, int kind, int iters, in
     else if (kind == 2) comms::probe_valu_kernel<2><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 1.0001f, 0.5f);
     else if (kind == 5) comms::probe_swap_kernel<5><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters);
     else if (kind == 6) comms::probe_swap_kernel<6><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters);
-    else if (kind >= 20 && kind <= 29) {
+    else if (kind >= 20 && kind <= 33) {
         comms::MacProbeArgs a;
         for (int i = 0; i < 32; ++i) a.t[i] = 1e-3f * (i + 1);
 #define COMMS_PF(V) if (kind == 20 + V) comms::probe_mac_form_kernel<V><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, a);
-        COMMS_PF(0) COMMS_PF(1) COMMS_PF(2) COMMS_PF(3) COMMS_PF(4) COMMS_PF(5) COMMS_PF(6) COMMS_PF(7) COMMS_PF(8) COMMS_PF(9)
+        COMMS_PF(0) COMMS_PF(1) COMMS_PF(2) COMMS_PF(3) COMMS_PF(4) COMMS_PF(5) COMMS_PF(6) COMMS_PF(7) COMMS_PF(8) COMMS_PF(9) COMMS_PF(10) COMMS_PF(11) COMMS_PF(12) COMMS_PF(13)
 #undef COMMS_PF
     } else if (kind >= 7 && kind <= 12) {
         comms::MacProbeArgs a;

@@ -58,8 +58,8 @@ __device__ __forceinline__ void mac_cplx(cf& acc, cf h, cf x) {
 }
 typedef float cf2 __attribute__((ext_vector_type(4)));  // two packed complex values (16 B)
 
-template <bool REAL_TAPS>
-__global__ __launch_bounds__(256) void fir_direct_kernel(const float2* __restrict__ in,
+template <bool REAL_TAPS, class In = const float2*>
+__global__ __launch_bounds__(256) void fir_direct_kernel(In in,
                                                          const float2* __restrict__ hist,
                                                          int hist_len,
                                                          const float2* __restrict__ taps_pad,
@@ -348,8 +348,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // The NR new 64-sample rows of the segment that starts at sample nb (zeros past the end)
-template <int NR>
-__device__ __forceinline__ void load_rows(const float2* __restrict__ in, size_t nb, int l, size_t n,
+template <int NR, class In>
+__device__ __forceinline__ void load_rows(In in, size_t nb, int l, size_t n,
                                           cf (&r)[NR]) {
     if (nb + 64 * NR <= n) {
 #pragma unroll
@@ -705,8 +705,8 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2
 // (Loading the NEXT segment's rows into spare registers before transforming this one -- the wait
 // then sits after the 16 - HR stores as a counted vmcnt -- was measured too: 3 us SLOWER at 2^24,
 // the 32 register moves per segment cost more than the covered latency.)
-template <int HR, bool TRACE>
-__global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(const float2* __restrict__ in,
+template <int HR, bool TRACE, class In = const float2*>
+__global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(In in,
                                                                  const float2* __restrict__ hist, int hist_len,
                                                                  float2* __restrict__ out, size_t n, WTables tb,
                                                                  float2* __restrict__ new_hist, void* trace_buf) {
@@ -742,9 +742,9 @@ __global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(const float2* _
         return lo + static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(t)));
     };
     auto fetch = [&](size_t sg, cf (&r)[16]) {
-        const float2* p = in + (sg * WVK - HALO + l);
+        const size_t p = sg * WVK - HALO + l;
 #pragma unroll
-        for (int a = 0; a < 16; ++a) r[a] = to_cf(p[64 * a]);
+        for (int a = 0; a < 16; ++a) r[a] = to_cf(in[p + 64 * a]);
     };
     auto nostamp = [](int) {};
 
@@ -1023,6 +1023,7 @@ using namespace comms;
 
 // ================================================================= FIR handle (struct comms_fir: fir_handle.hpp)
 static void free_fir(comms_fir* h) {
+    h->conv.release();
     (void)use_device(h->device);
     if (h->d_taps_pad) (void)hipFree(h->d_taps_pad);
     if (h->d_wtw1) (void)hipFree(h->d_wtw1);
@@ -1099,25 +1100,25 @@ extern "C" void comms_debug_os1024_dynamic(int mode) { g_os1024_dynamic.store(mo
 #endif
 
 // One launch of fir_os1024_dyn_kernel: one 16-wave workgroup per CU (fewer for short inputs).
-template <int HR, bool TRACE = false>
-static comms_status_t launch_os1024_dyn(hipStream_t s, const float2* in, const float2* hist, int n_eff, float2* o,
+template <int HR, bool TRACE = false, class In = const float2*>
+static comms_status_t launch_os1024_dyn(hipStream_t s, In in, const float2* hist, int n_eff, float2* o,
                                         size_t n, const comms::WTables& tb, float2* nh, void* trace_buf = nullptr,
                                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     using namespace comms;
     const size_t lds = (2112 + 16 * W_LDS + 1) * sizeof(float2);  // tables, exchange buffers, ticket counter
     static DeviceOnce attr_once;
     if (attr_once.need()) {
-        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os1024_dyn_kernel<HR, TRACE>),
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os1024_dyn_kernel<HR, TRACE, In>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     }
     const size_t nseg = (n + (1024 - 64 * HR) - 1) / (1024 - 64 * HR);
     const size_t want = (nseg + 15) / 16;
     const dim3 grid(static_cast<unsigned>(want < static_cast<size_t>(kNumCU) ? want : kNumCU));
     if (ev_start)  // timed launch: the events take the kernel's own begin / end timestamps
-        hipExtLaunchKernelGGL((fir_os1024_dyn_kernel<HR, TRACE>), grid, dim3(1024), static_cast<uint32_t>(lds), s, ev_start,
+        hipExtLaunchKernelGGL((fir_os1024_dyn_kernel<HR, TRACE, In>), grid, dim3(1024), static_cast<uint32_t>(lds), s, ev_start,
                               ev_stop, 0u, in, hist, n_eff, o, n, tb, nh, trace_buf);
     else
-        fir_os1024_dyn_kernel<HR, TRACE><<<grid, dim3(1024), lds, s>>>(in, hist, n_eff, o, n, tb, nh, trace_buf);
+        fir_os1024_dyn_kernel<HR, TRACE, In><<<grid, dim3(1024), lds, s>>>(in, hist, n_eff, o, n, tb, nh, trace_buf);
     return COMMS_OK;
 }
 
@@ -1463,22 +1464,72 @@ comms_status_t comms_fir_get_algo(const comms_fir_t* h, size_t n, int32_t* out_a
     return COMMS_OK;
 }
 
-comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n,
+}  // extern "C"
+
+// Wire-format input for the kernels that read Complex<f32> only: one conversion pass (iqformat.hip's
+// kernels) into a handle-owned buffer on the same stream.  The direct, ticketed 1024-point and
+// decimating-chain kernels convert in their load stage instead and never come here.
+static comms_status_t fir_converted_input(comms_fir* h, const void* d_in, size_t n, hipStream_t s, const float2** out) {
+    if (h->in_fmt == COMMS_IQ_C32) {
+        *out = static_cast<const float2*>(d_in);
+        return COMMS_OK;
+    }
+    COMMS_TRY(h->conv.reserve(n * sizeof(float2)));
+    comms_c32* tmp = static_cast<comms_c32*>(h->conv.p);
+    if (h->in_fmt == COMMS_IQ_I16)
+        COMMS_TRY(comms_iq_i16_to_c32_dev(static_cast<const int16_t*>(d_in), n, h->in_scale, tmp, h->device, s));
+    else
+        COMMS_TRY(comms_iq_u8_to_c32_dev(static_cast<const uint8_t*>(d_in), n, tmp, h->device, s));
+    *out = static_cast<const float2*>(h->conv.p);
+    return COMMS_OK;
+}
+
+template <int HR, class In>
+static comms_status_t launch_dyn_in(hipStream_t s, In in, comms_fir* h, float2* o, size_t n, const WTables& tb, float2* nh,
+                                    hipEvent_t ea, hipEvent_t eb) {
+    return launch_os1024_dyn<HR, false, In>(s, in, h->d_hist[h->cur], h->n_eff, o, n, tb, nh, nullptr, ea, eb);
+}
+template <class In>
+static comms_status_t launch_dyn_hr(int hr, hipStream_t s, In in, comms_fir* h, float2* o, size_t n, const WTables& tb,
+                                    float2* nh, hipEvent_t ea, hipEvent_t eb) {
+    switch (hr) {
+        case 1: return launch_dyn_in<1>(s, in, h, o, n, tb, nh, ea, eb);
+        case 2: return launch_dyn_in<2>(s, in, h, o, n, tb, nh, ea, eb);
+        case 3: return launch_dyn_in<3>(s, in, h, o, n, tb, nh, ea, eb);
+        default: return launch_dyn_in<4>(s, in, h, o, n, tb, nh, ea, eb);
+    }
+}
+template <class In>
+static void launch_direct_in(comms_fir* h, In in, const float2* hist, float2* o, size_t n, float2* nh, unsigned blocks,
+                             size_t lds, int vec4, hipStream_t s) {
+    if (h->real_taps)
+        fir_direct_kernel<true, In><<<dim3(blocks), dim3(256), lds, s>>>(in, hist, h->n_eff, h->d_taps_pad, h->NP, o, n, vec4, nh);
+    else
+        fir_direct_kernel<false, In><<<dim3(blocks), dim3(256), lds, s>>>(in, hist, h->n_eff, h->d_taps_pad, h->NP, o, n, vec4, nh);
+}
+
+extern "C" {
+
+comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size_t n,
                                  comms_c32* d_out, void* stream) {
     COMMS_ARG(h != nullptr, "handle is NULL");
-    COMMS_ARG((d_in && d_out) || !n, "NULL device pointer");
+    COMMS_ARG((d_in_any && d_out) || !n, "NULL device pointer");
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
-    COMMS_ARG(!ranges_overlap(d_in, n * 8, d_out, n * 8), "FIR cannot run in place");
-    COMMS_ARG((reinterpret_cast<uintptr_t>(d_in) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 7) == 0,
-              "device pointers must be 8-byte aligned");
+    const void* d_in = d_in_any;  // n samples in the handle's input format
+    const size_t in_elem = h->in_fmt == COMMS_IQ_I16 ? 4 : h->in_fmt == COMMS_IQ_U8 ? 2 : 8;
+    COMMS_ARG(!ranges_overlap(d_in, n * in_elem, d_out, n * 8), "FIR cannot run in place");
+    COMMS_ARG((reinterpret_cast<uintptr_t>(d_in) & (in_elem - 1)) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 7) == 0,
+              "device pointers must be aligned to one sample");
     hipStream_t s = nullptr;
     COMMS_TRY(h->enter(stream, &s));
-    const float2* in = reinterpret_cast<const float2*>(d_in);
     float2* o = reinterpret_cast<float2*>(d_out);
     const float2* hist = h->d_hist[h->cur];
     float2* nh = h->d_hist[h->cur ^ 1];  // the kernel's workgroup 0 advances the history into it
     const int algo = fir_pick(h, n);
+    const bool fused_fmt = algo == COMMS_FIR_DIRECT || (algo == COMMS_FIR_OS1024 && os1024_plan(h, n).dyn);
+    const float2* in = nullptr;  // Complex<f32> view of the input (the conversion pass, where the kernel needs one)
+    if (!fused_fmt || h->in_fmt == COMMS_IQ_C32) COMMS_TRY(fir_converted_input(h, d_in, n, s, &in));
     if (algo == COMMS_FIR_DIRECT) {
         COMMS_TRY(fir_prepare_direct(h));
         const unsigned blocks = static_cast<unsigned>((n + DTILE - 1) / DTILE);
@@ -1486,10 +1537,12 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
         const size_t lds = static_cast<size_t>(nrows) * DROW * sizeof(float2) + static_cast<size_t>(h->NP) * sizeof(float2);
         const int vec4 = (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
         h->tic(s);
-        if (h->real_taps)
-            fir_direct_kernel<true><<<dim3(blocks), dim3(256), lds, s>>>(in, hist, h->n_eff, h->d_taps_pad, h->NP, o, n, vec4, nh);
+        if (h->in_fmt == COMMS_IQ_I16)
+            launch_direct_in(h, InI16{static_cast<const short2*>(d_in), h->in_scale}, hist, o, n, nh, blocks, lds, vec4, s);
+        else if (h->in_fmt == COMMS_IQ_U8)
+            launch_direct_in(h, InU8{static_cast<const uchar2*>(d_in)}, hist, o, n, nh, blocks, lds, vec4, s);
         else
-            fir_direct_kernel<false><<<dim3(blocks), dim3(256), lds, s>>>(in, hist, h->n_eff, h->d_taps_pad, h->NP, o, n, vec4, nh);
+            launch_direct_in(h, in, hist, o, n, nh, blocks, lds, vec4, s);
         h->toc(s);
         COMMS_TRY(launch_ok("fir_direct_kernel"));
     } else if (algo == COMMS_FIR_OS1024) {
@@ -1501,15 +1554,20 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in, size_t n
         hipEvent_t ea = nullptr, eb = nullptr;
         if (h->timed() && pl.wpb == 16) h->next_events(ea, eb);
         if (!ea) h->tic(s);
-        switch (pl.dyn ? pl.hr : -pl.hr) {
-            case 1: COMMS_TRY((launch_os1024_dyn<1>(s, in, hist, h->n_eff, o, n, tb, nh, nullptr, ea, eb))); break;
-            case 2: COMMS_TRY((launch_os1024_dyn<2>(s, in, hist, h->n_eff, o, n, tb, nh, nullptr, ea, eb))); break;
-            case 3: COMMS_TRY((launch_os1024_dyn<3>(s, in, hist, h->n_eff, o, n, tb, nh, nullptr, ea, eb))); break;
-            case 4: COMMS_TRY((launch_os1024_dyn<4>(s, in, hist, h->n_eff, o, n, tb, nh, nullptr, ea, eb))); break;
-            case -1: COMMS_TRY((launch_os1024<0, 1>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb))); break;
-            case -2: COMMS_TRY((launch_os1024<0, 2>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb))); break;
-            case -3: COMMS_TRY((launch_os1024<0, 3>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb))); break;
-            default: COMMS_TRY((launch_os1024<0, 4>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb))); break;
+        if (pl.dyn) {
+            if (h->in_fmt == COMMS_IQ_I16)
+                COMMS_TRY(launch_dyn_hr(pl.hr, s, InI16{static_cast<const short2*>(d_in), h->in_scale}, h, o, n, tb, nh, ea, eb));
+            else if (h->in_fmt == COMMS_IQ_U8)
+                COMMS_TRY(launch_dyn_hr(pl.hr, s, InU8{static_cast<const uchar2*>(d_in)}, h, o, n, tb, nh, ea, eb));
+            else
+                COMMS_TRY(launch_dyn_hr(pl.hr, s, in, h, o, n, tb, nh, ea, eb));
+        } else {
+            switch (pl.hr) {
+                case 1: COMMS_TRY((launch_os1024<0, 1>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb))); break;
+                case 2: COMMS_TRY((launch_os1024<0, 2>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb))); break;
+                case 3: COMMS_TRY((launch_os1024<0, 3>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb))); break;
+                default: COMMS_TRY((launch_os1024<0, 4>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb))); break;
+            }
         }
         if (!ea) h->toc(s);
         COMMS_TRY(launch_ok("fir_os1024_kernel"));
@@ -1559,7 +1617,8 @@ comms_status_t comms_fir_run(comms_fir_t* h, const comms_c32* in, size_t n, comm
     COMMS_ARG((in && out) || !n, "NULL host pointer");
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
-    return h->run_host(in, n * sizeof(comms_c32), out, n * sizeof(comms_c32), [&](void* d_in, void* d_out) {
+    const size_t in_elem = h->in_fmt == COMMS_IQ_I16 ? 4 : h->in_fmt == COMMS_IQ_U8 ? 2 : 8;
+    return h->run_host(in, n * in_elem, out, n * sizeof(comms_c32), [&](void* d_in, void* d_out) {
         return comms_fir_run_dev(h, static_cast<const comms_c32*>(d_in), n, static_cast<comms_c32*>(d_out), COMMS_STREAM_HANDLE);
     });
 }
@@ -1589,6 +1648,15 @@ comms_status_t comms_fir_set_state(comms_fir_t* h, const comms_c32* state, size_
 comms_status_t comms_fir_set_timer(comms_fir_t* h, comms_timer_t* t) {
     COMMS_ARG(h != nullptr, "handle is NULL");
     h->timer = t;
+    return COMMS_OK;
+}
+
+comms_status_t comms_fir_set_input_format(comms_fir_t* h, int32_t format, float scale) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG(format == COMMS_IQ_C32 || format == COMMS_IQ_I16 || format == COMMS_IQ_U8, "unknown sample format %d", format);
+    COMMS_ARG(format != COMMS_IQ_I16 || std::isfinite(scale), "scale must be finite");
+    h->in_fmt = format;
+    h->in_scale = format == COMMS_IQ_I16 ? scale : 1.0f;
     return COMMS_OK;
 }
 

@@ -27,35 +27,46 @@
 
 namespace comms {
 
-constexpr int DC_WG = 256;          // lanes per workgroup
-constexpr int DC_TILE = 2 * DC_WG;  // outputs per tile (two per lane)
+constexpr int DC_TILE = 512;        // outputs per tile
 constexpr int DC_NMAX = 257;        // taps (kernel-argument budget)
-constexpr int DC_AMAX = 356;        // padded tap array: 2R*nd + R + 4 <= 256 + 63 + 16 + 4 (+ pair slack)
+constexpr int DC_AMAX = 384;        // padded tap array: OPL*R*nd + (OPL-1)*R + pair slack (worst: R = 12, OPL = 4: 376)
 constexpr int DC_RMAX = 16;
+constexpr int DC_OPLMAX = 4;
 
-template <int R>
+// A lane owns OPL consecutive outputs (2 or 4), a workgroup of 512 / OPL lanes one tile of 512.  Every LDS
+// read of the filter loop feeds OPL MACs: at OPL = 2 the loop issues one ds_read_b64 per two packed FMAs and
+// the LDS array is as busy as the vector ALU (the two do not overlap perfectly: ~10 cycles per MAC and SIMD
+// measured against 4.9 for the FMA alone); OPL = 4 halves the LDS traffic for the same FMAs, at half the
+// waves per CU (the staged inputs of a tile bound how many outputs can be resident).
+template <int R, int OPL>
 struct DcGeom {
-    static constexpr int PR = 2 * R;                               // phases
+    static constexpr int PR = OPL * R;                             // phases
+    static constexpr int WG = DC_TILE / OPL;                       // lanes per workgroup
     static constexpr int HLQ_MAX = (DC_NMAX - 1 + PR - 1) / PR;    // halo in phase-array elements
-    static constexpr int S = (DC_WG + HLQ_MAX + 1) | 1;            // phase-array stride (odd: staging writes spread over the banks)
+    static constexpr int HROWS = (HLQ_MAX * PR + WG - 1) / WG;     // halo rows of WG samples
+    static constexpr int S = (WG + HLQ_MAX + 1) | 1;               // phase-array stride (odd: staging writes spread over the banks)
     static constexpr size_t LDS = static_cast<size_t>(PR) * S * sizeof(float2);
-    static constexpr int WGPC = R <= 8 ? 4 : R <= 12 ? 3 : 2;     // workgroups per CU that fit in LDS (and set the VGPR budget)
+    static constexpr int WGPC = R <= 8 ? 4 : R <= 12 ? 3 : 2;     // workgroups per CU that fit in LDS
+    static constexpr int WAVES_PER_SIMD = (WGPC * WG / 64 + 3) / 4;  // __launch_bounds__' second argument: sets the VGPR budget
+    static_assert(PR * (HLQ_MAX + 1) + (OPL - 1) * R + 4 <= DC_AMAX, "tap table too small");
 };
 
 struct DecimArgs {
-    const float2* in;
+    const void* in;                // n samples in format `fmt`
     const float2* hist;
     float2* new_hist;
     void* out;
     const float2* fm_prev;
     float2* fm_prev_new;
     size_t n, n_out, n_tiles;
-    int hist_len, hlq, nd, mode;   // hlq = ceil((N-1)/2R); nd = hlq + 1 tap blocks of 2R
+    int hist_len, hlq, nd, mode;   // hlq = ceil((N-1)/PR); nd = hlq + 1 tap blocks of PR
+    int fmt;                       // COMMS_IQ_*
+    float in_scale;
     uint64_t turns0, frac;         // mixer phase of input sample 0 and per-sample increment (turns)
     double tile_c, tile_s;         // e^{i * R * tile_step * dphi}
-    float2 step_r;                 // e^{i * R * dphi}  (second output of a lane, mixer-after-FIR)
-    float2 step[2 * DC_RMAX];      // e^{i * 256 m * dphi}, staging row m
-    float are[DC_AMAX];            // A[m] = Re h[m - (2R-1)], zero outside [0, N)
+    float2 step_r[DC_OPLMAX];      // e^{i * c * R * dphi}  (output c of a lane, mixer-after-FIR)
+    float2 step[DC_OPLMAX * DC_RMAX];  // e^{i * WG m * dphi}, staging row m
+    float are[DC_AMAX];            // A[m] = Re h[m - (PR-1)], zero outside [0, N)
     float aim[DC_AMAX];
     unsigned long long* stamps;    // diagnostic (scripts/stamp_decim.py): per-wave cycles per phase, or NULL
 };
@@ -106,18 +117,19 @@ __device__ __forceinline__ void lds_barrier() {  // (kept light: nothing global 
 }
 
 // PRE: the mixer sits in front of the FIR (samples are mixed on their way into LDS); otherwise it
-// follows the FIR (or is absent).  PF: the next tile's global loads are issued right after this
-// tile has been staged, so that they fly during the filter loop (costs the 2R + 2 staging
-// registers across the loop; the PRE form then derives its row rotors on the fly instead of
-// keeping 2R of them in VGPRs).
-template <int R, bool REAL, bool PRE, bool PF>
-__global__ __launch_bounds__(DC_WG, DcGeom<R>::WGPC) void fir_decim_kernel(const DecimArgs a) {
-    using G = DcGeom<R>;
-    constexpr int PR = G::PR, S = G::S;
+// follows the FIR (or is absent).
+template <int R, int OPL, bool REAL, bool PRE>
+__global__ __launch_bounds__((DcGeom<R, OPL>::WG), (DcGeom<R, OPL>::WAVES_PER_SIMD)) void fir_decim_kernel(const DecimArgs a) {
+    using G = DcGeom<R, OPL>;
+    constexpr int PR = G::PR, S = G::S, WG = G::WG, HROWS = G::HROWS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* sh = reinterpret_cast<cf*>(smem);  // [PR][S]
-    __shared__ float2 sh_y[DC_WG / 64];
-    hist_advance(a.hist, a.in, a.n, a.new_hist, a.hist_len);
+    __shared__ float2 sh_y[WG / 64];
+    switch (a.fmt) {
+        case COMMS_IQ_I16: hist_advance(a.hist, InI16{static_cast<const short2*>(a.in), a.in_scale}, a.n, a.new_hist, a.hist_len); break;
+        case COMMS_IQ_U8: hist_advance(a.hist, InU8{static_cast<const uchar2*>(a.in)}, a.n, a.new_hist, a.hist_len); break;
+        default: hist_advance(a.hist, static_cast<const float2*>(a.in), a.n, a.new_hist, a.hist_len); break;
+    }
 
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     constexpr bool pre = PRE;
@@ -131,13 +143,13 @@ __global__ __launch_bounds__(DC_WG, DcGeom<R>::WGPC) void fir_decim_kernel(const
     const size_t t1 = static_cast<size_t>(blockIdx.x + 1) * a.n_tiles / gridDim.x;
     if (t0 >= t1) return;
 
-    // Mixer rotors.  The phase of input sample i = ib + tid + 256 m of a tile splits into a part
+    // Mixer rotors.  The phase of input sample i = ib + tid + WG m of a tile splits into a part
     // that is the same for the whole tile, T = rot(ib) (f64, stepped per tile, applied to the
-    // two outputs after the filter -- the filter is linear), and a part that never changes,
-    // lrow[m] = e^{i (tid + 256 m) dphi} (f32, set up once): one multiply per staged sample.
-    //   mixer after the FIR: ro = rot(R (jb + 2 tid)) is this lane's first output's rotor.
-    constexpr int NROW = PRE && !PF ? PR : 1;
-    cf lrow[NROW], lhalo[2];
+    // outputs after the filter -- the filter is linear), and a part that never changes,
+    // lrow[m] = e^{i (tid + WG m) dphi} (f32, set up once): one multiply per staged sample.
+    //   mixer after the FIR: ro = rot(R (jb + OPL tid)) is this lane's first output's rotor.
+    constexpr int NROW = PRE ? PR : 1;
+    cf lrow[NROW], lhalo[HROWS];
     double tt_c = 1.0, tt_s = 0.0, ro_c = 1.0, ro_s = 0.0;
     {
         const long long jb0 = static_cast<long long>(t0) * ts - ovl;
@@ -150,45 +162,54 @@ __global__ __launch_bounds__(DC_WG, DcGeom<R>::WGPC) void fir_decim_kernel(const
 #pragma unroll
             for (int m = 0; m < NROW; ++m) lrow[m] = m ? cmulf(l0, to_cf(a.step[m])) : l0;
 #pragma unroll
-            for (int m = 0; m < 2; ++m) lhalo[m] = m ? cmulf(h0, to_cf(a.step[m])) : h0;
+            for (int m = 0; m < HROWS; ++m) lhalo[m] = m ? cmulf(h0, to_cf(a.step[m])) : h0;
             rotor_at(a.turns0 + static_cast<uint64_t>(R * jb0) * a.frac, tt_c, tt_s);
         }
-        if (post) rotor_at(a.turns0 + static_cast<uint64_t>(R * (jb0 + 2 * tid)) * a.frac, ro_c, ro_s);
+        if (post) rotor_at(a.turns0 + static_cast<uint64_t>(R * (jb0 + OPL * tid)) * a.frac, ro_c, ro_s);
     }
-    // LDS slots of this lane's staged samples (sample hl + tid + 256 m of the tile; halo: tid + 256 m)
-    int slot[PR], slot_h[2];
+    // LDS slots of this lane's staged samples (sample hl + tid + WG m of the tile; halo: tid + WG m)
+    // (when PR divides WG, row m sits WG / PR elements behind row 0 in the same phase array: one register
+    // and immediate offsets instead of PR registers)
+    constexpr bool kLinearSlots = WG % PR == 0;
+    constexpr int NSLOT = kLinearSlots ? 1 : PR;
+    int slot[NSLOT], slot_h[HROWS];
 #pragma unroll
-    for (int m = 0; m < PR; ++m) {
-        const unsigned s = static_cast<unsigned>(tid + 256 * m);
+    for (int m = 0; m < NSLOT; ++m) {
+        const unsigned s = static_cast<unsigned>(tid + WG * m);
         slot[m] = static_cast<int>((s % PR) * S + a.hlq + s / PR);
     }
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const unsigned s = static_cast<unsigned>(tid + 256 * m);
+    for (int m = 0; m < HROWS; ++m) {
+        const unsigned s = static_cast<unsigned>(tid + WG * m);
         slot_h[m] = s < static_cast<unsigned>(hl) ? static_cast<int>((s % PR) * S + s / PR) : -1;
     }
 
-    // The tile's samples travel global -> VGPRs -> (mixer) -> LDS.  (Requesting the next tile's
-    // rows before this tile's filter loop was measured and does not pay: it costs 36 VGPRs, i.e.
-    // either the persistent row rotors or the fourth workgroup per CU, and the four workgroups
-    // already cover each other's loads: 158 us without, 162-171 us with, config 3 at 2^26.)
-    cf x[PR], xh[2];
-    auto load_tile = [&](size_t t) {
+    // The tile's samples travel global -> VGPRs -> (format conversion, mixer) -> LDS.  (Requesting the next
+    // tile's rows before this tile's filter loop was measured, twice, and does not pay: 47.5 -> 48.5 us on the
+    // metric chain, 147 -> 152 us on config 3 -- the workgroups of a CU already cover each other's loads.)
+    cf x[PR], xh[HROWS];
+    auto load_tile_from = [&](auto in, size_t t) {
         const long long ib = R * (static_cast<long long>(t) * ts - ovl);
-        if (ib - hl >= 0 && static_cast<size_t>(ib) + 256u * PR <= a.n) {  // interior tile: no edge handling
-            const float2* src = a.in + ib;
+        if (ib - hl >= 0 && static_cast<size_t>(ib) + static_cast<size_t>(WG) * PR <= a.n) {  // interior tile: no edge handling
+            const size_t base = static_cast<size_t>(ib) + static_cast<unsigned>(tid);
 #pragma unroll
-            for (int m = 0; m < PR; ++m) x[m] = to_cf((src + 256 * m)[static_cast<unsigned>(tid)]);
+            for (int m = 0; m < PR; ++m) x[m] = to_cf(in[base + WG * m]);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
-                xh[m] = slot_h[m] >= 0 ? to_cf((src - hl + 256 * m)[static_cast<unsigned>(tid)]) : cf{0.f, 0.f};
+            for (int m = 0; m < HROWS; ++m) xh[m] = slot_h[m] >= 0 ? to_cf(in[base - hl + WG * m]) : cf{0.f, 0.f};
         } else {
 #pragma unroll
-            for (int m = 0; m < PR; ++m) x[m] = to_cf(stream_at(a.in, a.hist, a.hist_len, ib + tid + 256 * m, a.n));
+            for (int m = 0; m < PR; ++m) x[m] = to_cf(stream_at(in, a.hist, a.hist_len, ib + tid + WG * m, a.n));
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
-                xh[m] = slot_h[m] >= 0 ? to_cf(stream_at(a.in, a.hist, a.hist_len, ib - hl + tid + 256 * m, a.n))
+            for (int m = 0; m < HROWS; ++m)
+                xh[m] = slot_h[m] >= 0 ? to_cf(stream_at(in, a.hist, a.hist_len, ib - hl + tid + WG * m, a.n))
                                        : cf{0.f, 0.f};
+        }
+    };
+    auto load_tile = [&](size_t t) {
+        switch (a.fmt) {   // wave-uniform: one scalar branch per tile
+            case COMMS_IQ_I16: load_tile_from(InI16{static_cast<const short2*>(a.in), a.in_scale}, t); break;
+            case COMMS_IQ_U8: load_tile_from(InU8{static_cast<const uchar2*>(a.in)}, t); break;
+            default: load_tile_from(static_cast<const float2*>(a.in), t); break;
         }
     };
 
@@ -204,41 +225,42 @@ __global__ __launch_bounds__(DC_WG, DcGeom<R>::WGPC) void fir_decim_kernel(const
     }
     if (a.stamps) st_prev = __builtin_amdgcn_s_memtime();
 
-    if (PF) load_tile(t0);
     for (size_t t = t0; t < t1; ++t) {
         const long long jb = static_cast<long long>(t) * ts - ovl;  // first output computed by this tile
-        // ---- stage the tile: 2R rows of new samples, then the halo (<= 2 rows)
-        if (!PF) load_tile(t);
+        // ---- stage the tile: PR rows of new samples, then the halo
+        load_tile(t);
         DC_STAMP(0)  // global loads landed
         if (pre) {
 #pragma unroll
-            for (int m = 0; m < PR; ++m)
-                x[m] = cmulf(x[m], PF ? (m ? cmulf(lrow[0], to_cf(a.step[m])) : lrow[0]) : lrow[m < NROW ? m : 0]);
+            for (int m = 0; m < PR; ++m) x[m] = cmulf(x[m], lrow[m < NROW ? m : 0]);
 #pragma unroll
-            for (int m = 0; m < 2; ++m) xh[m] = cmulf(xh[m], lhalo[m]);
+            for (int m = 0; m < HROWS; ++m) xh[m] = cmulf(xh[m], lhalo[m]);
         }
 #pragma unroll
-        for (int m = 0; m < PR; ++m) sh[slot[m]] = x[m];
+        for (int m = 0; m < PR; ++m) sh[kLinearSlots ? slot[0] + (WG / PR) * m : slot[m < NSLOT ? m : 0]] = x[m];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < HROWS; ++m)
             if (slot_h[m] >= 0) sh[slot_h[m]] = xh[m];
         DC_STAMP(1)  // mixer + LDS writes
         lds_barrier();
         DC_STAMP(2)
-        if (PF && t + 1 < t1) load_tile(t + 1);  // in flight during the filter loop
 
-        // ---- outputs j = jb + 2 tid + c:  y_c = sum_k h[k] u[R j - k]
-        // tile sample index of u[R j - k] is 2R (tid + hlq) + (R c - k) = 2R (tid + hlq - d) + p with
-        // k = 2R d + R c - p: block d, phase p descending = taps ascending; A[m] = h[m - (2R-1)]
+        // ---- outputs j = jb + OPL tid + c:  y_c = sum_k h[k] u[R j - k]
+        // tile sample index of u[R j - k] is PR (tid + hlq) + (R c - k) = PR (tid + hlq - d) + p with
+        // k = PR d + R c - p: block d, phase p descending = taps ascending; A[m] = h[m - (PR-1)], so that
+        // with q = PR - 1 - p the tap of output c is A[PR d + q + R c].
         // Software pipeline over chunks of CH taps: the next chunk's LDS reads and tap loads are
         // issued before this chunk's FMAs.  The empty asm "uses" this chunk's registers first, so
         // the one s_waitcnt the compiler needs for them lands BEFORE the prefetch is issued (SMEM
         // returns out of order: any later wait would be lgkmcnt(0) and drain the prefetch too).
-        cf acc0 = cf{0.f, 0.f}, acc1 = cf{0.f, 0.f};
+        cf acc[OPL];
+#pragma unroll
+        for (int c = 0; c < OPL; ++c) acc[c] = cf{0.f, 0.f};
         const cf* up = sh + tid + a.hlq;
-        constexpr int CH = R <= 10 ? R : R / 2;   // taps per chunk; PR / CH chunks (2 or 4) per block of 2R
+        constexpr int CH = OPL == 2 ? (R <= 10 ? R : R / 2) : (R <= 4 ? R : R % 4 == 0 ? R / 2 : R <= 6 ? R : R / 2);  // taps per chunk
+        static_assert(PR % CH == 0 && (PR / CH) % 2 == 0, "chunks must pair up inside a block");
         constexpr int NCH = PR / CH;
-        constexpr int NP = (CH + R) / 2 + (R & 1);  // SGPR pairs (A[2i], A[2i+1]) covering the chunk's taps of both outputs
+        constexpr int NP = ((CH & 1) + CH + (OPL - 1) * R + 1) / 2;  // SGPR pairs (A[2i], A[2i+1]) covering the chunk's taps of all OPL outputs (an odd chunk may start in a pair's hi half)
         cf ua[CH], ub[CH];
         v2f ra[NP], rb[NP], ia[NP], ib_[NP];
         // chunk g of block d: phases q = g*CH .. g*CH + CH - 1 (tap index ascending)
@@ -260,9 +282,11 @@ __global__ __launch_bounds__(DC_WG, DcGeom<R>::WGPC) void fir_decim_kernel(const
             const int off = (g * CH) & 1;  // the chunk's first tap sits in the hi half of pair 0 when g*CH is odd
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
-                const int e0 = off + i, e1 = off + i + R;
-                mac_tap<REAL>(acc0, u[i], tr[e0 >> 1], ti[e0 >> 1], (e0 & 1) != 0);
-                mac_tap<REAL>(acc1, u[i], tr[e1 >> 1], ti[e1 >> 1], (e1 & 1) != 0);
+#pragma unroll
+                for (int c = 0; c < OPL; ++c) {
+                    const int e = off + i + R * c;
+                    mac_tap<REAL>(acc[c], u[i], tr[e >> 1], ti[e >> 1], (e & 1) != 0);
+                }
             }
         };
         fetch(0, 0, ua, ra, ia);
@@ -283,82 +307,98 @@ __global__ __launch_bounds__(DC_WG, DcGeom<R>::WGPC) void fir_decim_kernel(const
 
         // ---- epilogue: mixer after the FIR, FM demod, stores
         DC_STAMP(4)  // filter loop
-        float2 y0 = to_f2(acc0), y1 = to_f2(acc1);
+        float2 y[OPL];
+#pragma unroll
+        for (int c = 0; c < OPL; ++c) y[c] = to_f2(acc[c]);
         if (pre) {
             const cf tt = cf{static_cast<float>(tt_c), static_cast<float>(tt_s)};
-            y0 = to_f2(cmulf(acc0, tt));
-            y1 = to_f2(cmulf(acc1, tt));
+#pragma unroll
+            for (int c = 0; c < OPL; ++c) y[c] = to_f2(cmulf(acc[c], tt));
             rotor_step(tt_c, tt_s, a.tile_c, a.tile_s);
         }
         if (post) {
             const cf ro = cf{static_cast<float>(ro_c), static_cast<float>(ro_s)};
-            y0 = to_f2(cmulf(acc0, ro));
-            y1 = to_f2(cmulf(acc1, cmulf(ro, to_cf(a.step_r))));
+#pragma unroll
+            for (int c = 0; c < OPL; ++c) y[c] = to_f2(cmulf(acc[c], c ? cmulf(ro, to_cf(a.step_r[c])) : ro));
             rotor_step(ro_c, ro_s, a.tile_c, a.tile_s);
         }
-        const long long j0 = jb + 2 * tid, j1 = j0 + 1;
+        const long long j0 = jb + OPL * tid;
         if (fm) {
-            if (j0 < 0) y0 = a.fm_prev[0];  // FM.prev of the previous call stands in for y[-1]
-            if (l == 63) sh_y[w] = y1;
+            if (j0 < 0) y[0] = a.fm_prev[0];  // FM.prev of the previous call stands in for y[-1]
+            if (l == 63) sh_y[w] = y[OPL - 1];
         }
         lds_barrier();  // sh_y visible; every lane is done reading the staged tile
         if (fm) {
-            float2 p0 = make_float2(__shfl_up(y1.x, 1), __shfl_up(y1.y, 1));
+            float2 p0 = make_float2(__shfl_up(y[OPL - 1].x, 1), __shfl_up(y[OPL - 1].y, 1));
             if (l == 0 && w > 0) p0 = sh_y[w - 1];
             float* o = static_cast<float*>(a.out);
-            if (tid > 0 && j0 < static_cast<long long>(a.n_out)) o[j0] = fm_step_fast(y0, p0);
-            if (j1 < static_cast<long long>(a.n_out)) o[j1] = fm_step_fast(y1, y0);
-            if (j0 == static_cast<long long>(a.n_out) - 1) a.fm_prev_new[0] = y0;
-            if (j1 == static_cast<long long>(a.n_out) - 1) a.fm_prev_new[0] = y1;
+            const long long n_out = static_cast<long long>(a.n_out);
+            if (tid > 0 && j0 < n_out) o[j0] = fm_step_fast(y[0], p0);
+#pragma unroll
+            for (int c = 1; c < OPL; ++c)
+                if (j0 + c < n_out) o[j0 + c] = fm_step_fast(y[c], y[c - 1]);
+#pragma unroll
+            for (int c = 0; c < OPL; ++c)
+                if (j0 + c == n_out - 1) a.fm_prev_new[0] = y[c];
         } else {
             float2* o = static_cast<float2*>(a.out);
-            if (j0 < static_cast<long long>(a.n_out)) o[j0] = y0;
-            if (j1 < static_cast<long long>(a.n_out)) o[j1] = y1;
+#pragma unroll
+            for (int c = 0; c < OPL; ++c)
+                if (j0 + c < static_cast<long long>(a.n_out)) o[j0 + c] = y[c];
         }
         DC_STAMP(5)  // barrier 2 + epilogue + stores
     }
     if (a.stamps && l == 0)
-        for (int i = 0; i < 6; ++i) a.stamps[(static_cast<size_t>(blockIdx.x) * (DC_WG / 64) + w) * 8 + i] = st_acc[i];
+        for (int i = 0; i < 6; ++i) a.stamps[(static_cast<size_t>(blockIdx.x) * (WG / 64) + w) * 8 + i] = st_acc[i];
 #undef DC_STAMP
 }
 
-template <int R, bool REAL, bool PRE, bool PF>
-static comms_status_t launch_decim_v(const DecimArgs& a, unsigned blocks, size_t lds, hipStream_t s) {
+template <int R, int OPL, bool REAL, bool PRE>
+static comms_status_t launch_decim_v(const DecimArgs& a, hipStream_t s) {
+    using G = DcGeom<R, OPL>;
+    constexpr size_t lds = G::LDS;
+    // persistent grid: every workgroup slot of the chip gets a contiguous run of tiles
+    const size_t slots = static_cast<size_t>(G::WGPC) * kNumCU;
+    const unsigned blocks = static_cast<unsigned>(a.n_tiles < slots ? a.n_tiles : slots);
     static DeviceOnce attr_once;
     if (attr_once.need())
-        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_decim_kernel<R, REAL, PRE, PF>),
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_decim_kernel<R, OPL, REAL, PRE>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    fir_decim_kernel<R, REAL, PRE, PF><<<dim3(blocks), dim3(DC_WG), lds, s>>>(a);
+    fir_decim_kernel<R, OPL, REAL, PRE><<<dim3(blocks), dim3(G::WG), lds, s>>>(a);
     return launch_ok("fir_decim_kernel");
 }
 
-// prefetch variant per chain form: COMMS_DECIM_PREFETCH = bit 0 (mixer after the FIR), bit 1 (mixer first)
-static int decim_prefetch_mask() {
-    static const int m = [] {
-        const char* v = getenv("COMMS_DECIM_PREFETCH");
-        return v && *v ? atoi(v) : 3;
+// Outputs per lane.  Two in the product.  Four (half the LDS reads per MAC, half the waves per CU, 28 tap
+// registers per chunk instead of 16) was built and measured: slower wherever the chain kernel is chosen
+// (metric chain 50 -> 60 us, config 3 153 -> 172 us) and ahead only beyond ~100 MACs per input sample
+// (255 taps / 2: 194 -> 148 us), where the overlap-save fusion is used anyway.  The diagnostic build keeps
+// it selectable (COMMS_DECIM_OPL=4) so that the comparison can be repeated.
+static int decim_opl(bool real, int macs_per_input) {
+    (void)macs_per_input;
+#ifdef COMMS_DIAG
+    static const int forced = [] {
+        const char* v = getenv("COMMS_DECIM_OPL");
+        return v && *v ? atoi(v) : 0;
     }();
-    return m;
+    if (real && forced == 4) return 4;
+#else
+    (void)real;
+#endif
+    return 2;
 }
 
 template <int R>
-static comms_status_t launch_decim(const DecimArgs& a, bool real, hipStream_t s) {
-    constexpr size_t lds = DcGeom<R>::LDS;
-    // persistent grid: every workgroup slot of the chip gets a contiguous run of tiles
-    const size_t slots = static_cast<size_t>(DcGeom<R>::WGPC) * kNumCU;
-    const unsigned blocks = static_cast<unsigned>(a.n_tiles < slots ? a.n_tiles : slots);
+static comms_status_t launch_decim(const DecimArgs& a, bool real, int opl, hipStream_t s) {
     const bool pre = (a.mode & COMMS_CHAIN_PRE) != 0;
-    const bool pf = (decim_prefetch_mask() >> (pre ? 1 : 0)) & 1;
-    switch ((real ? 4 : 0) | (pre ? 2 : 0) | (pf ? 1 : 0)) {
-        case 0: return launch_decim_v<R, false, false, false>(a, blocks, lds, s);
-        case 1: return launch_decim_v<R, false, false, true>(a, blocks, lds, s);
-        case 2: return launch_decim_v<R, false, true, false>(a, blocks, lds, s);
-        case 3: return launch_decim_v<R, false, true, true>(a, blocks, lds, s);
-        case 4: return launch_decim_v<R, true, false, false>(a, blocks, lds, s);
-        case 5: return launch_decim_v<R, true, false, true>(a, blocks, lds, s);
-        case 6: return launch_decim_v<R, true, true, false>(a, blocks, lds, s);
-        default: return launch_decim_v<R, true, true, true>(a, blocks, lds, s);
+    if (!real) return pre ? launch_decim_v<R, 2, false, true>(a, s) : launch_decim_v<R, 2, false, false>(a, s);
+#ifdef COMMS_DIAG
+    if constexpr (R <= 8) {
+        if (opl == 4) return pre ? launch_decim_v<R, 4, true, true>(a, s) : launch_decim_v<R, 4, true, false>(a, s);
     }
+#else
+    (void)opl;
+#endif
+    return pre ? launch_decim_v<R, 2, true, true>(a, s) : launch_decim_v<R, 2, true, false>(a, s);
 }
 
 }  // namespace comms
@@ -391,7 +431,7 @@ int32_t comms_fir_decim_supported(const comms_fir_t* h, uint32_t rate) {
     return macs <= max_macs ? 2 : 1;
 }
 
-comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const comms_c32* d_in, size_t n, void* d_out, int32_t mode,
+comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t n, void* d_out, int32_t mode,
                                        uint64_t turns0, uint64_t frac, uint32_t rate, const void* fm_prev,
                                        void* fm_prev_new, void* stream) {
     COMMS_ARG(h != nullptr, "handle is NULL");
@@ -402,13 +442,20 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const comms_c32* d_in, si
     COMMS_ARG((mode & COMMS_CHAIN_DEC) && !((mode & COMMS_CHAIN_PRE) && (mode & COMMS_CHAIN_POST)), "bad chain mode");
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
-    COMMS_ARG(!ranges_overlap(d_in, n * 8, d_out, (n / rate) * ((mode & COMMS_CHAIN_FM) ? 4 : 8)),
+    const size_t in_elem = h->in_fmt == COMMS_IQ_I16 ? 4 : h->in_fmt == COMMS_IQ_U8 ? 2 : 8;
+    COMMS_ARG(!ranges_overlap(d_in, n * in_elem, d_out, (n / rate) * ((mode & COMMS_CHAIN_FM) ? 4 : 8)),
               "the decimating chain cannot run in place");
+    COMMS_ARG((reinterpret_cast<uintptr_t>(d_in) & (in_elem - 1)) == 0, "input must be aligned to one IQ sample");
     hipStream_t s = nullptr;
     COMMS_TRY(h->enter(stream, &s));
-    const int R = static_cast<int>(rate), PR = 2 * R, N = h->n_eff;
+    const bool real = h->real_taps;
+    const int R = static_cast<int>(rate), N = h->n_eff;
+    const int opl = R <= 8 ? decim_opl(real, (N + R - 1) / R) : 2;  // (the tap pairs of 4 outputs need R <= 8: SGPR budget)
+    const int PR = opl * R, WG = DC_TILE / opl;
     DecimArgs a{};
-    a.in = reinterpret_cast<const float2*>(d_in);
+    a.in = d_in;
+    a.fmt = h->in_fmt;
+    a.in_scale = h->in_scale;
     a.hist = h->d_hist[h->cur];
     a.new_hist = h->d_hist[h->cur ^ 1];
     a.out = d_out;
@@ -429,32 +476,33 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const comms_c32* d_in, si
     if (getenv("COMMS_DECIM_DEBUG_NOMAC")) a.nd = 0;  // diagnostic: staging + epilogue only
     mix_host_rotor(static_cast<uint64_t>(R) * ts * frac, a.tile_c, a.tile_s);
     double c, sn;
-    mix_host_rotor(static_cast<uint64_t>(R) * frac, c, sn);
-    a.step_r = make_float2(static_cast<float>(c), static_cast<float>(sn));
+    for (int k = 0; k < opl; ++k) {
+        mix_host_rotor(static_cast<uint64_t>(R * k) * frac, c, sn);
+        a.step_r[k] = make_float2(static_cast<float>(c), static_cast<float>(sn));
+    }
     for (int m = 0; m < PR; ++m) {
-        mix_host_rotor(static_cast<uint64_t>(256 * m) * frac, c, sn);
+        mix_host_rotor(static_cast<uint64_t>(WG * m) * frac, c, sn);
         a.step[m] = make_float2(static_cast<float>(c), static_cast<float>(sn));
     }
-    COMMS_ARG(PR * a.nd + R + 4 <= DC_AMAX, "tap table overflow");
+    COMMS_ARG(PR * (a.hlq + 1) + (opl - 1) * R + 4 <= DC_AMAX, "tap table overflow");
     for (int m = 0; m < DC_AMAX; ++m) {
         const int k = m - (PR - 1);
         const bool in_range = k >= 0 && k < N;
         a.are[m] = in_range ? h->taps[k].re : 0.f;
         a.aim[m] = in_range ? h->taps[k].im : 0.f;
     }
-    const bool real = h->real_taps;
     h->tic(s);
     comms_status_t st;
     switch (R) {
-        case 2: st = launch_decim<2>(a, real, s); break;
-        case 3: st = launch_decim<3>(a, real, s); break;
-        case 4: st = launch_decim<4>(a, real, s); break;
-        case 5: st = launch_decim<5>(a, real, s); break;
-        case 6: st = launch_decim<6>(a, real, s); break;
-        case 8: st = launch_decim<8>(a, real, s); break;
-        case 10: st = launch_decim<10>(a, real, s); break;
-        case 12: st = launch_decim<12>(a, real, s); break;
-        case 16: st = launch_decim<16>(a, real, s); break;
+        case 2: st = launch_decim<2>(a, real, opl, s); break;
+        case 3: st = launch_decim<3>(a, real, opl, s); break;
+        case 4: st = launch_decim<4>(a, real, opl, s); break;
+        case 5: st = launch_decim<5>(a, real, opl, s); break;
+        case 6: st = launch_decim<6>(a, real, opl, s); break;
+        case 8: st = launch_decim<8>(a, real, opl, s); break;
+        case 10: st = launch_decim<10>(a, real, 2, s); break;
+        case 12: st = launch_decim<12>(a, real, 2, s); break;
+        case 16: st = launch_decim<16>(a, real, 2, s); break;
         default: return fail(COMMS_ERR_ARG, "no decimating kernel for rate %d", R);
     }
     h->toc(s);

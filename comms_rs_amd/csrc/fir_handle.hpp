@@ -8,10 +8,45 @@
 
 namespace comms {
 
+// ---- raw-IQ input formats read by the first kernel of a chain: the wire
+// samples are converted in registers on their way in, with exactly iqformat.hip's arithmetic, so HBM sees
+// 4 B (i16) or 2 B (u8) per sample instead of 8 + the 12 / 10 B of a separate conversion pass.
+//   i16: cast_complex::<i16,f32> (src/util/math.rs:20-28) of IQInput's samples (src/io/raw_iq.rs:16,50-51), times scale
+//   u8 : (x as f32 - 127.5) / 127.5 (examples/fm_radio.rs:82-90, RTL-SDR bytes)
+struct InC32 {
+    const float2* p;
+    __device__ __forceinline__ float2 operator[](size_t i) const { return p[i]; }
+};
+struct InI16 {
+    const short2* p;
+    float scale;
+    __device__ __forceinline__ float2 operator[](size_t i) const {
+        const short2 v = p[i];
+        return make_float2(static_cast<float>(v.x) * scale, static_cast<float>(v.y) * scale);
+    }
+};
+// The division by 127.5 is correctly rounded in iqformat.hip (and in the reference).  q = a * fl(1/127.5)
+// followed by one residual step  q + fl(a - q * 127.5) * fl(1/127.5)  reproduces it for all 256 byte values
+// (checked exhaustively: tests/test_cpu_host.py and the GPU test): 4 flops instead of a ~10-instruction divide.
+struct InU8 {
+    const uchar2* p;
+    static __device__ __forceinline__ float cvt(float x) {
+        constexpr float kInv = 1.0f / 127.5f;
+        const float a = x - 127.5f;
+        const float q = a * kInv;
+        const float r = __builtin_fmaf(-q, 127.5f, a);
+        return __builtin_fmaf(r, kInv, q);
+    }
+    __device__ __forceinline__ float2 operator[](size_t i) const {
+        const uchar2 v = p[i];
+        return make_float2(cvt(static_cast<float>(v.x)), cvt(static_cast<float>(v.y)));
+    }
+};
+
 // Folded into every FIR kernel (workgroup 0): new_hist = last HL samples of
 // concat(old_hist[HL], in[n]) -- the reference's `state` after the batch.
-__device__ __forceinline__ void hist_advance(const float2* __restrict__ old_hist,
-                                             const float2* __restrict__ in, size_t n,
+template <class In = const float2*>
+__device__ __forceinline__ void hist_advance(const float2* __restrict__ old_hist, In in, size_t n,
                                              float2* __restrict__ new_hist, int HL) {
     if (blockIdx.x != 0) return;
     for (int j = threadIdx.x; j < HL; j += blockDim.x) {
@@ -21,8 +56,8 @@ __device__ __forceinline__ void hist_advance(const float2* __restrict__ old_hist
 }
 
 // Sample g of the logical stream [history | input | zeros]
-__device__ __forceinline__ float2 stream_at(const float2* __restrict__ in,
-                                            const float2* __restrict__ hist, int hist_len,
+template <class In = const float2*>
+__device__ __forceinline__ float2 stream_at(In in, const float2* __restrict__ hist, int hist_len,
                                             long long g, size_t n) {
     if (g >= 0) return static_cast<size_t>(g) < n ? in[g] : make_float2(0.f, 0.f);
     return g >= -static_cast<long long>(hist_len) ? hist[hist_len + g] : make_float2(0.f, 0.f);
@@ -43,6 +78,9 @@ struct comms_fir : comms::Handle {
     bool real_taps = false;
     int algo = COMMS_FIR_AUTO;
     bool os1024_fixed = false;  // COMMS_FIR_OS1024_FIXED: never the ticketed kernel
+    int in_fmt = 0;             // COMMS_IQ_C32 / _I16 / _U8: what d_in of the run entries points to
+    float in_scale = 1.0f;      // i16 only
+    comms::Scratch conv;        // converted copy, for the kernels that do not read wire formats themselves
     // direct form
     int NP = 0;          // taps padded to a multiple of 8
     float2* d_taps_pad = nullptr;

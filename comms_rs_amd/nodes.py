@@ -27,6 +27,16 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+_IQ = {"c32": (0, np.complex64, 1), "i16": (1, np.int16, 2), "u8": (2, np.uint8, 2)}
+
+
+def _as_input(a, fmt):
+    """Contiguous input array of a node whose input format is `fmt`, and its sample count."""
+    code, dtype, per = _IQ[fmt]
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a, a.size // per
+
+
 def device_count():
     n = C.c_int32(0)
     st = lib().comms_device_count(C.byref(n))
@@ -126,10 +136,19 @@ class BatchFirNode(_Handle):
         check(lib().comms_fir_get_kernel(self._h, n, buf, 64))
         return buf.value.decode()
 
+    _fmt = "c32"
+
+    def set_input_format(self, fmt, scale=1.0):
+        """Raw-IQ input: "c32" (default), "i16" (interleaved int16 re/im, times `scale`) or "u8"
+        (RTL-SDR bytes, (x - 127.5) / 127.5).  run() then takes an integer array of 2 n values."""
+        check(lib().comms_fir_set_input_format(self._h, _IQ[fmt][0], float(scale)))
+        self._fmt = fmt
+        return self
+
     def run(self, x):
-        x = _as_c64(x)
-        out = np.empty_like(x)
-        check(lib().comms_fir_run(self._h, _ptr(x), x.size, _ptr(out)))
+        x, n = _as_input(x, self._fmt)
+        out = np.empty(n, np.complex64)
+        check(lib().comms_fir_run(self._h, _ptr(x), n, _ptr(out)))
         return out
 
     def run_dev(self, in_ptr, n, out_ptr, stream=0):
@@ -373,10 +392,19 @@ class ChainNode(_Handle):
         check(lib().comms_chain_is_fused(self._h, C.byref(f)))
         return ("unfused", "freq", "time")[f.value]
 
+    _fmt = "c32"
+
+    def set_input_format(self, fmt, scale=1.0):
+        """Raw-IQ input ("c32" / "i16" / "u8", see BatchFirNode.set_input_format): converted in the load
+        stage of the time-domain chain kernel, by one extra pass in front of the other chain forms."""
+        check(lib().comms_chain_set_input_format(self._h, _IQ[fmt][0], float(scale)))
+        self._fmt = fmt
+        return self
+
     def run(self, x):
-        x = _as_c64(x)
-        out = np.empty(x.size // self.rate, np.float32 if self.fm_demod else np.complex64)
-        check(lib().comms_chain_run(self._h, _ptr(x), x.size, _ptr(out)))
+        x, n = _as_input(x, self._fmt)
+        out = np.empty(n // self.rate, np.float32 if self.fm_demod else np.complex64)
+        check(lib().comms_chain_run(self._h, _ptr(x), n, _ptr(out)))
         return out
 
     def run_dev(self, in_ptr, n, out_ptr, stream=0):

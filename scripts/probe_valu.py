@@ -12,7 +12,8 @@ for kind, nm in [(k, n) for k, n in [(0, "v_fma_f32"), (3, "v_pk_fma_f32"), (7, 
                  (20, "form0 acc=u*tV+acc plain"), (21, "form1 +op_sel_hi[1,0,1] on tap"), (22, "form2 +op_sel hi-broadcast on tap"),
                  (23, "form3 acc=acc*tV+u (dst==src0) plain"), (24, "form4 dst==src0 + op_sel_hi[1,0,1]"), (25, "form5 plain, SGPR tap"),
                  (26, "form6 2x v_fma_f32 SGPR tap (2 instr)"), (27, "form7 pk_mul(op_sel)+pk_add (2 instr)"), (28, "form8 acc=u*u+acc (2 VGPR pairs)"),
-                 (29, "form9 pk_mul only"),
+                 (29, "form9 pk_mul only"), (30, "form10 lo/hi alternating, same VGPR pair twice"), (31, "form11 lo/hi alternating, new pair each"),
+                 (32, "form12 lo,lo same pair twice"), (33, "form13 lo/hi alternating SGPR pair"),
                  (9, "MAC SGPR taps, 16 chains"), (10, "MAC VGPR taps, 16 chains"), (11, "MAC SGPR taps, 4 chains"), (12, "MAC VGPR taps, 4 chains"), (4, "cmul=pk_mul+pk_fma (2 instr)"), (5, "v_permlane32_swap (8 per 16 slots)"), (6, "v_permlane16_swap (8 per 16 slots)")] if k in KINDS]:
     for wps in [int(w) for w in os.environ.get('WPS', '1,2,4,8').split(',')]:   # waves per SIMD
         blocks = 256 * wps

@@ -125,6 +125,23 @@ def test_cpp_graph_runtime_under_sanitizers(san):
     assert "all passed" in out.stdout
 
 
+def test_u8_conversion_shortcut_matches_the_divide_for_all_bytes():
+    """csrc/fir_handle.hpp InU8::cvt replaces (x - 127.5) / 127.5 (examples/fm_radio.rs:85-86) by
+    q = a * fl(1/127.5); q + fma(-q, 127.5, a) * fl(1/127.5).  Exhaustive over the 256 byte values,
+    with the fma steps evaluated exactly (f64 holds the 24 x 24 bit products) and rounded once."""
+    x = np.arange(256, dtype=np.float32)
+    want = (x - np.float32(127.5)) / np.float32(127.5)
+    kinv = np.float32(1.0) / np.float32(127.5)
+    a = x - np.float32(127.5)
+    q = a * kinv
+    r = (a.astype(np.float64) - q.astype(np.float64) * 127.5).astype(np.float32)
+    got = (r.astype(np.float64) * np.float64(kinv) + q.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(got, want)
+    import oracle
+
+    assert np.array_equal(oracle.iq_u8_to_c32(np.stack([x, x], 1).astype(np.uint8)).real, want)
+
+
 def test_shard_ranges():
     from comms_rs_amd.sharding import shard_range
 

@@ -1,0 +1,121 @@
+"""Raw-IQ input read by the first kernel (src/io/raw_iq.rs:16,50-51,
+examples/fm_radio.rs:82-90, examples/single_thread_bpsk.rs:43): a node told that its input is i16 / u8
+converts in its load stage.  The conversion must be iqformat.hip's (= the oracle's) bit for bit, so
+"node on raw input" == "node on converted input" exactly, and == the oracle chain within the node's own
+tolerance.  Run with -m gpu."""
+import numpy as np
+import pytest
+
+import oracle
+from test_gpu_parity import circ, fir_close, lowpass_taps, rand_c
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c():
+    import comms_rs_amd as c
+
+    assert c.device_count() >= 1, "no MI355X visible: the HIP path cannot be tested (no CPU fallback)"
+    return c
+
+
+def raw_stream(rng, n, fmt):
+    """An FM-like stream quantised to the wire format, plus every byte value at least once."""
+    idx = np.arange(n, dtype=np.float64)
+    z = np.exp(1j * (-2 * np.pi * 0.05 * idx + 8.0 * np.cos(2 * np.pi * idx / 4096)))
+    if fmt == "u8":
+        raw = np.stack([np.clip(np.rint(z.real * 100 + 127.5), 0, 255), np.clip(np.rint(z.imag * 100 + 127.5), 0, 255)], 1).astype(np.uint8)
+        k = min(n, 256)
+        raw[:k, 0] = np.arange(k)
+        raw[:k, 1] = np.arange(k)[::-1]
+        return raw, oracle.iq_u8_to_c32(raw)
+    raw = np.stack([np.rint(z.real * 8192), np.rint(z.imag * 8192)], 1).astype(np.int16)
+    raw[:4] = [[-32768, 32767], [0, -1], [1, 0], [12345, -12345]]
+    return raw, oracle.iq_i16_to_c32(raw, 1.0 / 8192)
+
+
+def test_u8_conversion_formula_is_exact_for_every_byte(c):
+    """InU8::cvt (multiply by 1/127.5 + one fma residual step) against the correctly rounded divide of
+    iqformat.hip, the oracle and numpy, for all 256 values, through a kernel that uses it (the direct FIR
+    with the single tap 1)."""
+    raw = np.stack([np.arange(256), np.arange(256)[::-1]], 1).astype(np.uint8)
+    want = ((raw.astype(np.float32) - np.float32(127.5)) / np.float32(127.5))
+    assert np.array_equal(oracle.iq_u8_to_c32(raw).view(np.float32).reshape(-1, 2), want)
+    assert np.array_equal(c.iq_u8_to_c32(raw).view(np.float32).reshape(-1, 2), want)
+    got = c.BatchFirNode(np.array([1 + 0j], np.complex64)).set_algo(c.FIR_DIRECT).set_input_format("u8").run(raw)
+    assert np.array_equal(got.view(np.float32).reshape(-1, 2), want)
+
+
+@pytest.mark.parametrize("fmt", ["i16", "u8"])
+@pytest.mark.parametrize("algo,n", [("direct", 5000), ("os1024", 30000), ("dyn", 4200 * 768 + 100), ("os4096", 20000)])
+def test_fir_node_reads_raw_iq(c, fmt, algo, n):
+    """BatchFirNode on raw samples == BatchFirNode on the converted samples, bit for bit (same kernel, same
+    arithmetic after the load stage), across two calls (the history is kept converted)."""
+    rng = np.random.default_rng(5)
+    n_taps = 255 if algo != "os4096" else 600
+    taps = lowpass_taps(n_taps, 1 / 16)
+    raw, x = raw_stream(rng, n, fmt)
+    al = {"direct": c.FIR_DIRECT, "os1024": c.FIR_OS1024_FIXED, "dyn": c.FIR_OS1024, "os4096": c.FIR_OS4096}[algo]
+    scale = 1.0 / 8192
+    a = c.BatchFirNode(taps).set_algo(al).set_input_format(fmt, scale)
+    b = c.BatchFirNode(taps).set_algo(al)
+    if algo == "dyn":
+        assert a.kernel_for(n) == "fir_os1024_dyn_kernel"
+    cut = n // 2 if algo != "dyn" else n   # (the ticketed kernel needs >= 4096 segments per call)
+    got = np.concatenate([a.run(raw[:cut]), a.run(raw[cut:])]) if cut < n else a.run(raw)
+    ref = np.concatenate([b.run(x[:cut]), b.run(x[cut:])]) if cut < n else b.run(x)
+    assert np.array_equal(got.view(np.float32), ref.view(np.float32))
+    assert np.array_equal(a.state(n_taps), x[::-1][:n_taps])
+    want = oracle.batch_fir(x[:4000], taps, oracle.default_state(taps), norotate=True)
+    fir_close(got[:4000], want, taps, x)
+
+
+@pytest.mark.parametrize("fmt", ["i16", "u8"])
+@pytest.mark.parametrize("variant", ["time", "freq", "unfused"])
+def test_fm_radio_chain_from_raw_iq(c, variant, fmt):
+    """examples/fm_radio.rs:82-90,144-152: RTL-SDR bytes -> convert -> 63-tap FIR -> decimate by 5 -> FM demod,
+    as ONE chain node fed the raw bytes (the chain's mixer at dphase 0 = identity).  Equal to the same chain fed
+    the converted samples -- bit for bit on the time-domain kernel, which converts in its load stage -- and to the
+    oracle's iq_u8_to_c32 -> batch_fir -> decimate -> FM::demod."""
+    rng = np.random.default_rng(8)
+    n = 5 * 40000
+    t = rng.uniform(-0.03, 0.03, 31).astype(np.float32)
+    taps = np.concatenate([t, [np.float32(0.18)], t[::-1]]).astype(np.complex64)
+    raw, x = raw_stream(rng, n, fmt)
+    kw = dict(unfused=variant == "unfused", kernel="auto" if variant == "unfused" else variant)
+    a = c.ChainNode(0.0, 0.0, taps, 5, True, **kw).set_input_format(fmt, 1.0 / 8192)
+    b = c.ChainNode(0.0, 0.0, taps, 5, True, **kw)
+    cuts = [0, 5 * 1000, 5 * 1001, n]
+    got = np.concatenate([a.run(raw[p:q]) for p, q in zip(cuts[:-1], cuts[1:])])
+    ref = np.concatenate([b.run(x[p:q]) for p, q in zip(cuts[:-1], cuts[1:])])
+    assert np.array_equal(got, ref)
+    y = oracle.decimate(oracle.batch_fir(x, taps, oracle.default_state(taps), norotate=True), 5)
+    want = oracle.FM().demod(y)
+    mag = np.minimum(np.abs(y), np.abs(np.concatenate([[0.0], y[:-1]])))
+    assert np.max((circ(got.astype(np.float64) - want) * mag)[16:]) <= 4e-5 * np.sum(np.abs(taps))
+
+
+def test_metric_chain_from_i16_full_size(c):
+    """The BASELINE metric's chain (255-tap FIR -> mixer -> decimate by 8) on 2^24 i16 samples resident in HBM
+    (64 MiB instead of 128): fused load-convert vs. conversion kernel + chain, bit for bit."""
+    import torch
+
+    n = 1 << 24
+    taps = c.rrc_taps(255, 8.0, 0.35)
+    x = torch.empty(n, dtype=torch.complex64, device="cuda:0")
+    c.synth_iq_dev(x.data_ptr(), n, 0, 12)
+    raw = torch.empty(n, 2, dtype=torch.int16, device="cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    c.lib().comms_iq_c32_to_i16_dev(x.data_ptr(), n, 8192.0, raw.data_ptr(), 0, s)
+    c.lib().comms_iq_i16_to_c32_dev(raw.data_ptr(), n, 1.0 / 8192, x.data_ptr(), 0, s)   # x = the converted stream
+    a = c.ChainNode(0.6, 0.1, taps, 8, False, mixer_after_fir=True).set_input_format("i16", 1.0 / 8192)
+    b = c.ChainNode(0.6, 0.1, taps, 8, False, mixer_after_fir=True)
+    assert a.kernel == "time"
+    za = torch.empty(n // 8, dtype=torch.complex64, device="cuda:0")
+    zb = torch.empty_like(za)
+    a.run_dev(raw.data_ptr(), n, za.data_ptr(), s)
+    b.run_dev(x.data_ptr(), n, zb.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.view_as_real(za), torch.view_as_real(zb))
+    assert float(za.abs().max()) > 0.1
