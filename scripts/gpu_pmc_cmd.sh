@@ -8,7 +8,7 @@ i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_RD" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_SMEM SQ_THREAD_CYCLES_VALU" \
-           "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+           "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE GRBM_COUNT" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -o pmc -- "$@" > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/p$i.log; }
 done
@@ -19,7 +19,7 @@ for d in sorted(glob.glob("$OUT/p*/")):
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if "$KSUB" in r["Kernel_Name"]:
-                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        for k, v in acc.items():
-            print("%-28s per-launch mean %.4g  (n=%d)" % (k, sum(v) / len(v), len(v)))
+                acc[(r["Kernel_Name"].split("(")[0][-60:], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (kn, k), v in sorted(acc.items()):
+            print("%-60s %-24s per-launch mean %.5g  (n=%d)" % (kn, k, sum(v) / len(v), len(v)))
 PY

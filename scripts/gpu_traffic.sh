@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/traffic; mkdir -p $OUT
 for cnt in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $cnt --output-format csv -d $OUT/$cnt -o pmc -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/$cnt.log 2>&1 || { echo "$cnt pass failed"; tail -3 $OUT/$cnt.log; }
+  timeout -k 10 400 rocprofv3 --pmc $cnt --output-format csv -d $OUT/$cnt -o pmc -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --stream-log2 0 > $OUT/$cnt.log 2>&1 || { echo "$cnt pass failed"; tail -3 $OUT/$cnt.log; }
 done
 python3 - <<PY
 import csv, glob, json, collections
