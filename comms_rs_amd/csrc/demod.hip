@@ -15,8 +15,15 @@
 //   out = exp(i*phase).  The recurrence is a prefix sum, so a block of phase errors is a
 //   scan: increments are converted to 64-bit fixed-point turns (wrap-around of the integer
 //   is the mod-2*pi), scanned exactly, and one f64 sincos per sample produces the output.
-//   Three launches: tile sums, scan of tile sums (one workgroup), apply.  Differences to
-//   the reference's sequentially rounded f64 phase stay below ~n * 2^-63 turns.
+//   Three launches: tile sums, scan of the tile sums (one workgroup), apply (a persistent grid;
+//   every lane owns coalesced sample pairs).  A single-launch decoupled look-back was built and
+//   measured: 3.6 ms against 0.19 -- with ~2000 tiles in flight a tile walks back through that
+//   many descriptors before it meets an inclusive prefix, and the walk is a chain of dependent
+//   L2 round trips; reading the 8-byte phase errors twice costs far less.
+//   exp(i*phase) comes from a 1024-entry f64 (cos, sin) table of the top 10 phase bits in LDS
+//   and a 6th / 7th-order Taylor rotor of the remainder (|lo| <= pi/1024: error < 1e-21), a
+//   tenth of the library sincos' instructions.  Differences to the reference's sequentially
+//   rounded f64 phase stay below ~n * 2^-63 turns.
 #include <cmath>
 #include <vector>
 
@@ -27,60 +34,167 @@ namespace comms {
 constexpr double kPi = 3.14159265358979323846264338327950288;
 
 // ---------------------------------------------------------------- timing estimator
-constexpr int TE_T = 256;   // outputs per tile (= workgroup size)
-constexpr int TE_KC = 256;  // taps staged per pass
+constexpr int TE_WG = 256;                  // lanes per workgroup
+constexpr int TE_OPL = 4;                   // consecutive outputs per lane
+constexpr int TE_TILE = TE_WG * TE_OPL;     // outputs per tile
+constexpr int TE_QMAX = 1020;               // q(t) taps one pass stages (a multiple of 12; 2*n*d + 1 taps in all: longer filters take several passes)
+
+// sin / cos of a large f64 angle (|th| up to ~1e8: the reference feeds -pi*i/n with i the sample index):
+// three-term Cody-Waite reduction by pi/2 with FMAs, then fdlibm's kernel polynomials on |r| <= pi/4.
+// ~30 f64 operations against the library routine's several hundred (it also handles |th| -> inf); absolute
+// error < 4e-16 for |th| < 2^27, far inside the estimator's 1e-9.
+__device__ __forceinline__ void te_sincos(double th, double& sn, double& cs) {
+    const double kf = rint(th * 6.36619772367581382433e-01);
+    double r = __fma_rn(-kf, 1.57079632673412561417e+00, th);
+    r = __fma_rn(-kf, 6.07710050630396597660e-11, r);
+    r = __fma_rn(-kf, 2.02226624871116645580e-21, r);
+    r = __fma_rn(-kf, 8.47842766036889956997e-32, r);
+    const double z = r * r;
+    double ps = __fma_rn(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __fma_rn(z, ps, 2.75573137070700676789e-06);
+    ps = __fma_rn(z, ps, -1.98412698298579493134e-04);
+    ps = __fma_rn(z, ps, 8.33333333332248946124e-03);
+    ps = __fma_rn(z, ps, -1.66666666666666324348e-01);
+    const double s0 = __fma_rn(r * z, ps, r);
+    double pc = __fma_rn(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __fma_rn(z, pc, -2.75573143513906633035e-07);
+    pc = __fma_rn(z, pc, 2.48015872894767294178e-05);
+    pc = __fma_rn(z, pc, -1.38888888888741095749e-03);
+    pc = __fma_rn(z, pc, 4.16666666666666019037e-02);
+    const double c0 = __fma_rn(z * z, pc, __fma_rn(z, -0.5, 1.0));
+    const int q = static_cast<int>(static_cast<long long>(kf)) & 3;
+    const double a = (q & 1) ? c0 : s0, b = (q & 1) ? s0 : c0;
+    sn = (q & 2) ? -a : a;
+    cs = ((q + 1) & 2) ? -b : b;
+}
 
 __device__ __forceinline__ double2 te_rotor(long long i, double n_sps) {
     // Complex::new(0.0, -PI * i as f64 / n as f64).exp()  -> (cos, sin) of that angle
     const double th = (-kPi * static_cast<double>(i)) / n_sps;
     double s, c;
-    sincos(th, &s, &c);
+    te_sincos(th, s, c);
     return make_double2(c, s);
 }
 
-__global__ __launch_bounds__(TE_T) void timing_kernel(const double2* __restrict__ x, size_t len,
-                                                      const double* __restrict__ qtaps, uint32_t n_q, uint32_t nd,
-                                                      double n_sps, double2* __restrict__ partials) {
-    __shared__ double2 sh_q[TE_T + TE_KC - 1];
-    __shared__ double sh_t[TE_KC];
-    __shared__ double2 wsum[TE_T / 64];
+// LDS image of the mixed window: element e at e + (e >> 2) -- one pad slot per four elements, so that lanes
+// reading at a stride of four elements (their OPL consecutive outputs) spread over all the banks
+__device__ __forceinline__ int te_slot(int e) { return e + (e >> 2); }
+
+// A 256-lane workgroup owns 1024 consecutive outputs, four per lane.  The mixed window (qin) of the tile and
+// the delayed mixed samples (din) are staged in LDS once -- one rotor per staged sample serves both -- and the
+// q(t) filter slides a four-element register window over the LDS image: one 16-byte LDS read feeds the taps of
+// all four outputs (4 complex x real MACs = 8 f64 FMAs), the taps themselves arrive by scalar loads.  Taps are
+// walked in the reference's order (k ascending); the MACs are fused (the reference's are not: the estimate
+// moves by < 1e-12, the oracle comparison allows 1e-9).
+__global__ __launch_bounds__(TE_WG, 4) void timing_kernel(const double2* __restrict__ x, size_t len,
+                                                       const double* __restrict__ qtaps, uint32_t n_q, uint32_t k_lo,
+                                                       uint32_t nd, double n_sps, int with_delay,
+                                                       double2* __restrict__ qacc, double2* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) char te_smem[];
+    double2* sh_q = reinterpret_cast<double2*>(te_smem);                       // window, padded image
+    const int nk = static_cast<int>(n_q);                                      // taps of this pass
+    const int win = TE_TILE + nk - 1;                                          // (+ 1 element staged past it: position -4 of the last lane)
+    double2* sh_d = sh_q + te_slot(win + 1) + 1;                               // din of the tile's outputs
+    __shared__ double2 wsum[TE_WG / 64];
     const int tid = threadIdx.x;
-    const size_t ntiles = (len + TE_T - 1) / TE_T;
+    const size_t ntiles = (len + TE_TILE - 1) / TE_TILE;
     double2 total = make_double2(0.0, 0.0);
+    // the usual case (one pass, delay n*d inside the filter's reach): the window already holds every sample din needs
+    const bool din_in_window = with_delay && k_lo == 0 && static_cast<int>(nd) <= nk - 1;
     for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long long i0 = static_cast<long long>(tile) * TE_T;
-        const long long i = i0 + tid;
-        double2 q = make_double2(0.0, 0.0);
-        for (uint32_t k0 = 0; k0 < n_q; k0 += TE_KC) {
-            const int kc = static_cast<int>(n_q - k0 < static_cast<uint32_t>(TE_KC) ? n_q - k0 : TE_KC);
-            const long long base = i0 - static_cast<long long>(k0) - (kc - 1);
-            __syncthreads();
-            for (int j = tid; j < TE_T - 1 + kc; j += TE_T) {
-                const long long idx = base + j;
+        const long long i0 = static_cast<long long>(tile) * TE_TILE;
+        __syncthreads();
+        // ---- stage qin over [i0 - k_lo - (nk - 1), i0 - k_lo + TILE) and din over [i0 - nd, i0 - nd + TILE)
+        const long long w0 = i0 - static_cast<long long>(k_lo) - (nk - 1);
+        for (int j = tid; j <= win; j += TE_WG) {
+            const long long idx = w0 + j;
+            double2 v = make_double2(0.0, 0.0);
+            if (idx >= 0 && idx < static_cast<long long>(len)) {
+                const double2 sm = x[idx];
+                const double2 r = te_rotor(idx, n_sps);
+                const double ci = -sm.y;  // conj
+                v = make_double2(sm.x * r.x - ci * r.y, sm.x * r.y + ci * r.x);
+                if (din_in_window) {  // the delayed sample of some output of this tile: same rotor, no conjugate
+                    const long long dj = idx - (i0 - static_cast<long long>(nd));
+                    if (dj >= 0 && dj < TE_TILE) sh_d[dj] = make_double2(sm.x * r.x - sm.y * r.y, sm.x * r.y + sm.y * r.x);
+                }
+            } else if (din_in_window) {
+                const long long dj = idx - (i0 - static_cast<long long>(nd));
+                if (dj >= 0 && dj < TE_TILE) sh_d[dj] = make_double2(0.0, 0.0);
+            }
+            sh_q[te_slot(j)] = v;
+        }
+        if (with_delay && !din_in_window) {
+            for (int j = tid; j < TE_TILE; j += TE_WG) {
+                const long long idx = i0 - static_cast<long long>(nd) + j;
                 double2 v = make_double2(0.0, 0.0);
                 if (idx >= 0 && idx < static_cast<long long>(len)) {
-                    const double2 s = x[idx];
+                    const double2 sm = x[idx];
                     const double2 r = te_rotor(idx, n_sps);
-                    const double ci = -s.y;  // conj
-                    v = make_double2(s.x * r.x - ci * r.y, s.x * r.y + ci * r.x);
+                    v = make_double2(sm.x * r.x - sm.y * r.y, sm.x * r.y + sm.y * r.x);
                 }
-                sh_q[j] = v;
-            }
-            if (tid < kc) sh_t[tid] = qtaps[k0 + tid];
-            __syncthreads();
-            for (int kk = 0; kk < kc; ++kk) {
-                const double t = sh_t[kk];
-                const double2 v = sh_q[tid + kc - 1 - kk];
-                q.x += t * v.x;
-                q.y += t * v.y;
+                sh_d[j] = v;
             }
         }
-        if (i < static_cast<long long>(len) && i >= static_cast<long long>(nd)) {
-            const double2 s = x[i - nd];
-            const double2 r = te_rotor(i - nd, n_sps);
-            const double2 d = make_double2(s.x * r.x - s.y * r.y, s.x * r.y + s.y * r.x);
-            total.x += q.x * d.x - q.y * d.y;
-            total.y += q.x * d.y + q.y * d.x;
+        __syncthreads();
+        // ---- q_c = sum_k t[k] v[n_c - k],  n_c = i0 + 4 tid + c:  window element of (c, k) is e0 + c - k
+        const int e0 = (nk - 1) + TE_OPL * tid;
+        double2 q[TE_OPL];
+        if (qacc && k_lo) {
+#pragma unroll
+            for (int c = 0; c < TE_OPL; ++c) {
+                const long long i = i0 + TE_OPL * tid + c;
+                q[c] = i < static_cast<long long>(len) ? qacc[i] : make_double2(0.0, 0.0);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < TE_OPL; ++c) q[c] = make_double2(0.0, 0.0);
+        }
+        // Window positions p = e0 - e grow with k: tap k of output c reads position k - c.  Positions live in
+        // register blocks of four; the taps of block b (k = 4b .. 4b + 3) touch blocks b - 1 and b.  Three
+        // blocks per loop iteration rotate through three register sets (R0, R1), (R1, R2), (R2, R0), so no
+        // value is ever moved between registers.  (The host pads the taps with zeros to a multiple of 12.)
+        auto load_block = [&](int blk, double2 (&R)[4]) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                R[m] = sh_q[te_slot(e0 - (4 * blk + m))];  // 0 <= e <= win: nk is a multiple of 12, the image holds win + 1 elements
+            }
+        };
+        auto mac_block = [&](int blk, const double2 (&P)[4], const double2 (&Q)[4]) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const double t = qtaps[4 * blk + m];  // wave-uniform: a scalar load
+#pragma unroll
+                for (int c = 0; c < TE_OPL; ++c) {
+                    const double2 v = m - c >= 0 ? Q[m - c] : P[4 + m - c];
+                    q[c].x = __fma_rn(t, v.x, q[c].x);
+                    q[c].y = __fma_rn(t, v.y, q[c].y);
+                }
+            }
+        };
+        double2 R0[4], R1[4], R2[4];
+        load_block(-1, R0);
+        const int nblk = nk / 4;  // a multiple of 3
+        for (int blk = 0; blk < nblk; blk += 3) {
+            load_block(blk, R1);
+            mac_block(blk, R0, R1);
+            load_block(blk + 1, R2);
+            mac_block(blk + 1, R1, R2);
+            load_block(blk + 2, R0);
+            mac_block(blk + 2, R2, R0);
+        }
+        // ---- delayed product, or (a pass that is not the last) the running filter sums back to memory
+#pragma unroll
+        for (int c = 0; c < TE_OPL; ++c) {
+            const long long i = i0 + TE_OPL * tid + c;
+            if (i >= static_cast<long long>(len)) continue;
+            if (!with_delay) {
+                qacc[i] = q[c];
+            } else if (i >= static_cast<long long>(nd)) {
+                const double2 d = sh_d[TE_OPL * tid + c];
+                total.x += q[c].x * d.x - q[c].y * d.y;
+                total.y += q[c].x * d.y + q[c].y * d.x;
+            }
         }
     }
 #pragma unroll
@@ -92,7 +206,7 @@ __global__ __launch_bounds__(TE_T) void timing_kernel(const double2* __restrict_
     __syncthreads();
     if (tid == 0) {
         double2 s = wsum[0];
-        for (int w = 1; w < TE_T / 64; ++w) {
+        for (int w = 1; w < TE_WG / 64; ++w) {
             s.x += wsum[w].x;
             s.y += wsum[w].y;
         }
@@ -129,23 +243,60 @@ __device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v, int lane) {
     return v;
 }
 
+constexpr int NCO_ROWS = 4;                   // a lane owns the sample pairs (2 tid, 2 tid + 1) + 512 j, j < 4
+
+// exp(i * 2*pi * ph / 2^64): table of the nearest of 1024 directions times the Taylor rotor of the rest
+__device__ __forceinline__ double2 nco_rotor(uint64_t ph, const double2* __restrict__ tab) {
+    const uint64_t r = ph + (static_cast<uint64_t>(1) << 53);
+    const unsigned idx = static_cast<unsigned>(r >> 54);                              // nearest direction (mod 1024)
+    const long long rem = static_cast<long long>(ph - (static_cast<uint64_t>(idx) << 54));  // in [-2^53, 2^53)
+    const double lo = static_cast<double>(rem) * (kTwoPi * 0x1.0p-64);                // |lo| <= pi / 1024
+    const double z = lo * lo;
+    const double sl = lo * __fma_rn(z, __fma_rn(z, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+    const double cl = __fma_rn(z, __fma_rn(z, __fma_rn(z, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
+    const double2 t = tab[idx & 1023];
+    return make_double2(__fma_rn(-t.y, sl, t.x * cl), __fma_rn(t.x, sl, t.y * cl));
+}
+
+// the lane's increments of tile t: p0[j] / p1[j] = running sum after the first / second sample of pair j
+__device__ __forceinline__ void nco_load_pairs(const double* __restrict__ perr, size_t n, double dphase, size_t base,
+                                               uint64_t (&p0)[NCO_ROWS], uint64_t (&p1)[NCO_ROWS]) {
+#pragma unroll
+    for (int j = 0; j < NCO_ROWS; ++j) {
+        const size_t i = base + 512 * static_cast<size_t>(j);
+        double e0 = 0.0, e1 = 0.0;
+        if (i + 1 < n) {
+            const double2 e = *reinterpret_cast<const double2*>(perr + i);
+            e0 = e.x;
+            e1 = e.y;
+        } else if (i < n) {
+            e0 = perr[i];
+        }
+        p0[j] = i < n ? nco_turns(dphase + e0) : 0;
+        p1[j] = p0[j] + (i + 1 < n ? nco_turns(dphase + e1) : 0);
+    }
+}
+
 // tile sums
 __global__ __launch_bounds__(NCO_WG) void nco_sum_kernel(const double* __restrict__ perr, size_t n, double dphase,
-                                                         uint64_t* __restrict__ tile_sum) {
+                                                         uint64_t* __restrict__ tile_sum, size_t ntiles) {
     __shared__ uint64_t wsum[NCO_WG / 64];
-    const size_t base = static_cast<size_t>(blockIdx.x) * NCO_TILE + static_cast<size_t>(threadIdx.x) * NCO_PER;
-    uint64_t acc = 0;
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        uint64_t p0[NCO_ROWS], p1[NCO_ROWS];
+        nco_load_pairs(perr, n, dphase, t * NCO_TILE + 2 * static_cast<size_t>(threadIdx.x), p0, p1);
+        uint64_t acc = 0;
 #pragma unroll
-    for (int j = 0; j < NCO_PER; ++j)
-        if (base + j < n) acc += nco_turns(dphase + perr[base + j]);
+        for (int j = 0; j < NCO_ROWS; ++j) acc += p1[j];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t s = 0;
-        for (int w = 0; w < NCO_WG / 64; ++w) s += wsum[w];
-        tile_sum[blockIdx.x] = s;
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t s = 0;
+            for (int w = 0; w < NCO_WG / 64; ++w) s += wsum[w];
+            tile_sum[t] = s;
+        }
     }
 }
 
@@ -176,32 +327,42 @@ __global__ __launch_bounds__(1024) void nco_scan_kernel(uint64_t* __restrict__ t
 
 // out[i] = exp(i * phase_i),  phase_i = phase_before + sum_{j<=i} (dphase + perr[j])
 __global__ __launch_bounds__(NCO_WG) void nco_apply_kernel(const double* __restrict__ perr, size_t n, double dphase,
-                                                           const uint64_t* __restrict__ tile_off,
-                                                           double2* __restrict__ out) {
-    __shared__ uint64_t wtot[NCO_WG / 64];
+                                                           const uint64_t* __restrict__ tile_off, size_t ntiles,
+                                                           const double2* __restrict__ tab_g, double2* __restrict__ out) {
+    __shared__ double2 tab[1024];
+    __shared__ uint64_t wtot[NCO_ROWS][NCO_WG / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const size_t base = static_cast<size_t>(blockIdx.x) * NCO_TILE + static_cast<size_t>(tid) * NCO_PER;
-    uint64_t t[NCO_PER];
-    uint64_t acc = 0;
+    for (int i = tid; i < 1024; i += NCO_WG) tab[i] = tab_g[i];
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const size_t base = t * NCO_TILE + 2 * static_cast<size_t>(tid);
+        uint64_t p0[NCO_ROWS], p1[NCO_ROWS], inc[NCO_ROWS];
+        nco_load_pairs(perr, n, dphase, base, p0, p1);
+        __syncthreads();  // table in place; the previous tile's wtot no longer read
 #pragma unroll
-    for (int j = 0; j < NCO_PER; ++j) {
-        acc += base + j < n ? nco_turns(dphase + perr[base + j]) : 0;
-        t[j] = acc;
-    }
-    const uint64_t inc = wave_incl_scan(acc, lane);
-    if (lane == 63) wtot[w] = inc;
-    __syncthreads();
-    uint64_t off = tile_off[blockIdx.x] + inc - acc;
-    for (int k = 0; k < w; ++k) off += wtot[k];
+        for (int j = 0; j < NCO_ROWS; ++j) {
+            inc[j] = wave_incl_scan(p1[j], lane);
+            if (lane == 63) wtot[j][w] = inc[j];
+        }
+        __syncthreads();
+        uint64_t row_off = tile_off[t];
 #pragma unroll
-    for (int j = 0; j < NCO_PER; ++j) {
-        if (base + j < n) {
-            const uint64_t ph = off + t[j];
-            // 53 significant bits of the turn fraction -> radians in [0, 2*pi)
-            const double ang = static_cast<double>(ph >> 11) * (kTwoPi * 0x1.0p-53);
-            double s, c;
-            sincos(ang, &s, &c);
-            out[base + j] = make_double2(c, s);
+        for (int j = 0; j < NCO_ROWS; ++j) {
+            uint64_t off = row_off + inc[j] - p1[j];
+#pragma unroll
+            for (int k = 0; k < NCO_WG / 64; ++k) {
+                if (k < w) off += wtot[j][k];
+                row_off += wtot[j][k];
+            }
+            const size_t i = base + 512 * static_cast<size_t>(j);
+            const double2 a = nco_rotor(off + p0[j], tab);
+            const double2 b = nco_rotor(off + p1[j], tab);
+            if (i + 1 < n) {
+                double4 v;
+                v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y;
+                *reinterpret_cast<double4*>(out + i) = v;
+            } else if (i < n) {
+                out[i] = a;
+            }
         }
     }
 }
@@ -214,12 +375,14 @@ struct comms_timing : Handle {
     uint32_t n = 0, d = 0, n_q = 0;
     double* d_taps = nullptr;
     double2* d_part = nullptr;
-    unsigned max_blocks = 8 * kNumCU;
+    unsigned max_blocks = 4 * kNumCU;
+    Scratch qacc;  // running filter sums between the passes of a filter longer than TE_QMAX taps
 };
 
 struct comms_nco : Handle {
     double dphase = 0.0;
     uint64_t* d_phase = nullptr;  // fixed-point turns, device resident
+    double2* d_tab = nullptr;     // (cos, sin)(2 pi k / 1024), f64
     Scratch tiles;
 };
 
@@ -273,6 +436,7 @@ comms_status_t comms_timing_create(uint32_t n, uint32_t d, double alpha, int32_t
     h->n = n;
     h->d = d;
     h->n_q = static_cast<uint32_t>(taps.size());
+    taps.resize((taps.size() + 11) / 12 * 12, 0.0);  // the kernel walks the taps in blocks of 12; zero taps add nothing
     hipError_t e = hipMalloc(&h->d_taps, taps.size() * sizeof(double));
     if (e == hipSuccess) e = hipMemcpy(h->d_taps, taps.data(), taps.size() * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&h->d_part, h->max_blocks * sizeof(double2));
@@ -296,12 +460,25 @@ comms_status_t comms_timing_push_dev(comms_timing_t* h, const double* d_samples,
     COMMS_TRY(h->enter(stream, &s));
     double re = 0.0, im = 0.0;
     if (len) {
-        size_t blocks = (len + TE_T - 1) / TE_T;
+        size_t blocks = (len + TE_TILE - 1) / TE_TILE;
         if (blocks > h->max_blocks) blocks = h->max_blocks;
+        const uint32_t nq12 = (h->n_q + 11) / 12 * 12;
+        const uint32_t n_pass = (nq12 + TE_QMAX - 1) / TE_QMAX;
+        double2* qacc = nullptr;
+        if (n_pass > 1) {
+            COMMS_TRY(h->qacc.reserve(len * sizeof(double2)));
+            qacc = static_cast<double2*>(h->qacc.p);
+        }
         h->tic(s);
-        timing_kernel<<<dim3(static_cast<unsigned>(blocks)), dim3(TE_T), 0, s>>>(
-            reinterpret_cast<const double2*>(d_samples), len, h->d_taps, h->n_q, h->n * h->d,
-            static_cast<double>(h->n), h->d_part);
+        for (uint32_t p = 0; p < n_pass; ++p) {
+            const uint32_t k_lo = p * TE_QMAX;
+            const uint32_t nk = nq12 - k_lo < static_cast<uint32_t>(TE_QMAX) ? nq12 - k_lo : TE_QMAX;
+            const int win = TE_TILE + static_cast<int>(nk) - 1;
+            const size_t lds = (static_cast<size_t>(win + 1 + ((win + 1) >> 2)) + 1 + TE_TILE) * sizeof(double2);
+            timing_kernel<<<dim3(static_cast<unsigned>(blocks)), dim3(TE_WG), lds, s>>>(
+                reinterpret_cast<const double2*>(d_samples), len, h->d_taps + k_lo, nk, k_lo, h->n * h->d,
+                static_cast<double>(h->n), p + 1 == n_pass ? 1 : 0, qacc, h->d_part);
+        }
         h->toc(s);
         COMMS_TRY(launch_ok("timing_kernel"));
         std::vector<double2> part(blocks);
@@ -333,6 +510,7 @@ comms_status_t comms_timing_destroy(comms_timing_t* h) {
     (void)use_device(h->device);
     if (h->d_taps) (void)hipFree(h->d_taps);
     if (h->d_part) (void)hipFree(h->d_part);
+    h->qacc.release();
     h->fini();
     delete h;
     return COMMS_OK;
@@ -352,11 +530,17 @@ comms_status_t comms_nco_create(double dphase, double phase, int32_t device, com
     }
     h->dphase = mix_wrap_dphase(dphase);  // Nco::new, nco.rs:41-49 (same wrap as Mixer::new)
     const uint64_t turns = mix_to_turns(phase);
+    std::vector<double2> tab(1024);
+    for (int k = 0; k < 1024; ++k) {
+        const long double a = 2.0L * 3.14159265358979323846264338327950288L * static_cast<long double>(k) / 1024.0L;
+        tab[k] = make_double2(static_cast<double>(cosl(a)), static_cast<double>(sinl(a)));
+    }
     hipError_t e = hipMalloc(&h->d_phase, sizeof(uint64_t));
     if (e == hipSuccess) e = hipMemcpy(h->d_phase, &turns, sizeof(uint64_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&h->d_tab, tab.size() * sizeof(double2));
+    if (e == hipSuccess) e = hipMemcpy(h->d_tab, tab.data(), tab.size() * sizeof(double2), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        h->fini();
-        delete h;
+        comms_nco_destroy(h);
         return fail(COMMS_ERR_DEVICE, "nco state alloc: %s", hipGetErrorString(e));
     }
     *out = h;
@@ -372,17 +556,22 @@ comms_status_t comms_nco_run_dev(comms_nco_t* h, const double* d_perr, size_t n,
     COMMS_ARG(!ranges_overlap(d_perr, n * 8, d_out, n * 16), "nco cannot run in place");
     hipStream_t s = nullptr;
     COMMS_TRY(h->enter(stream, &s));
+    COMMS_ARG((reinterpret_cast<uintptr_t>(d_perr) & 15) == 0, "phase errors must be 16-byte aligned");
     const size_t ntiles = (n + NCO_TILE - 1) / NCO_TILE;
     COMMS_ARG(ntiles <= 0x7fffffffu, "block too long");
     COMMS_TRY(h->tiles.reserve(ntiles * sizeof(uint64_t)));
     uint64_t* tiles = static_cast<uint64_t*>(h->tiles.p);
+    // persistent grids: the apply kernel stages a 16 KiB rotor table per workgroup (8 workgroups per CU)
+    const size_t slots = static_cast<size_t>(8) * kNumCU;
+    const unsigned blocks = static_cast<unsigned>(ntiles < slots ? ntiles : slots);
     h->tic(s);
-    nco_sum_kernel<<<dim3(static_cast<unsigned>(ntiles)), dim3(NCO_WG), 0, s>>>(d_perr, n, h->dphase, tiles);
+    nco_sum_kernel<<<dim3(blocks), dim3(NCO_WG), 0, s>>>(d_perr, n, h->dphase, tiles, ntiles);
     nco_scan_kernel<<<dim3(1), dim3(1024), 0, s>>>(tiles, ntiles, h->d_phase);
-    nco_apply_kernel<<<dim3(static_cast<unsigned>(ntiles)), dim3(NCO_WG), 0, s>>>(d_perr, n, h->dphase, tiles,
-                                                                                 reinterpret_cast<double2*>(d_out));
+    nco_apply_kernel<<<dim3(blocks), dim3(NCO_WG), 0, s>>>(d_perr, n, h->dphase, tiles, ntiles, h->d_tab,
+                                                          reinterpret_cast<double2*>(d_out));
     h->toc(s);
-    return launch_ok("nco kernels");
+    COMMS_TRY(launch_ok("nco kernels"));
+    return COMMS_OK;
 }
 
 comms_status_t comms_nco_run(comms_nco_t* h, const double* perr, size_t n, double* out) {
@@ -404,7 +593,7 @@ comms_status_t comms_nco_get_phase(comms_nco_t* h, double* phase) {
     COMMS_ARG(h != nullptr && phase != nullptr, "NULL argument");
     COMMS_TRY(use_device(h->device));
     uint64_t turns = 0;
-    COMMS_HIP_TRY(hipDeviceSynchronize());
+    COMMS_TRY(h->quiesce());
     COMMS_HIP_TRY(hipMemcpy(&turns, h->d_phase, sizeof(uint64_t), hipMemcpyDeviceToHost));
     *phase = static_cast<double>(turns >> 11) * (kMixT * 0x1.0p-53);
     return COMMS_OK;
@@ -414,6 +603,7 @@ comms_status_t comms_nco_destroy(comms_nco_t* h) {
     if (!h) return COMMS_OK;
     (void)use_device(h->device);
     if (h->d_phase) (void)hipFree(h->d_phase);
+    if (h->d_tab) (void)hipFree(h->d_tab);
     h->tiles.release();
     h->fini();
     delete h;

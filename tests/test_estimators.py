@@ -119,7 +119,8 @@ def test_device_timing_estimator_vs_oracle():
 
     rng = np.random.default_rng(3)
     x = timing_stream(rng)
-    for n, d, alpha, off in ((10, 5, 0.5, 2), (10, 5, 0.5, 0), (10, 30, 0.25, 3), (2, 5, 0.25, 0), (4, 1, 1.0, 1)):
+    for n, d, alpha, off in ((10, 5, 0.5, 2), (10, 5, 0.5, 0), (10, 30, 0.25, 3), (2, 5, 0.25, 0), (4, 1, 1.0, 1),
+                             (10, 60, 0.3, 1)):  # 1201 taps: two passes of the one-pass kernel
         est = c.TimingEstimatorNode(n, d, alpha)
         got = est.run(x[off:])
         want = oracle.timing_push(x[off:], n, d, alpha)
@@ -130,6 +131,9 @@ def test_device_timing_estimator_vs_oracle():
     for ln in (1, 7, 100, 257, 513):
         y = rng.standard_normal(ln) + 1j * rng.standard_normal(ln)
         assert abs(c.TimingEstimatorNode(10, 5, 0.5).run(y) - oracle.timing_push(y, 10, 5, 0.5)) < 1e-9
+    # a long block: the rotor angle -pi*i/n reaches 6.6e5 rad, sample indices cross many tiles
+    long = np.tile(x, 200)[: (1 << 21) + 333]
+    assert abs(c.TimingEstimatorNode(10, 5, 0.5).run(long) - oracle.timing_push(long, 10, 5, 0.5)) < 1e-9
     with pytest.raises(c.CommsError):
         c.TimingEstimatorNode(10, 5, 1.5)
     with pytest.raises(c.CommsError):
@@ -153,3 +157,34 @@ def test_device_nco_vs_oracle():
     assert c.NcoNode(0.1).run(np.zeros(0)).size == 0
     with pytest.raises(c.CommsError):
         c.NcoNode(float("nan"))
+
+
+@pytest.mark.gpu
+def test_device_nco_long_block():
+    """2^24 + 777 phase errors, device-resident, twice in a row on one node: 8193 tiles (sum / scan / apply over a
+    persistent grid, the rotor from the 1024-entry table + Taylor remainder).  With a constant error the phase has the closed
+    form phase0 + (i + 1) * (dphase + e); checked in extended precision at the tile seams and at random places."""
+    import torch
+
+    import comms_rs_amd as c
+
+    n = (1 << 24) + 777
+    dphase, phase0, e = 0.1234567, 0.5, 1e-3
+    perr = torch.full((n,), e, dtype=torch.float64, device="cuda:0")
+    out = torch.empty(n, dtype=torch.complex128, device="cuda:0")
+    node = c.NcoNode(dphase, phase0)
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(1)
+    idx = np.unique(np.concatenate([[0, 1, 2047, 2048, 2049, 4095, 4096, n - 2, n - 1], rng.integers(0, n, 4000),
+                                    2048 * rng.integers(1, n // 2048, 500), 2048 * rng.integers(1, n // 2048, 500) - 1]))
+    two_pi = 2 * np.longdouble(np.pi)
+    inc = np.longdouble(dphase) + np.longdouble(e)
+    for call in range(2):
+        node.run_dev(perr.data_ptr(), n, out.data_ptr(), s)
+        torch.cuda.synchronize()
+        got = out[torch.from_numpy(idx).cuda()].cpu().numpy()
+        ph = np.fmod(np.longdouble(phase0) + (np.longdouble(call) * n + idx.astype(np.longdouble) + 1) * inc, two_pi)
+        want = np.cos(ph).astype(np.float64) + 1j * np.sin(ph).astype(np.float64)
+        assert np.max(np.abs(got - want)) < 1e-9, call
+    end = np.fmod(np.longdouble(phase0) + 2 * np.longdouble(n) * inc, two_pi)
+    assert abs(np.exp(1j * node.phase) - np.exp(1j * float(end))) < 1e-9
