@@ -85,7 +85,7 @@ __device__ __forceinline__ int te_slot(int e) { return e + (e >> 2); }
 // q(t) filter slides a four-element register window over the LDS image: one 16-byte LDS read feeds the taps of
 // all four outputs (4 complex x real MACs = 8 f64 FMAs), the taps themselves arrive by scalar loads.  Taps are
 // walked in the reference's order (k ascending); the MACs are fused (the reference's are not: the estimate
-// moves by < 1e-12, the oracle comparison allows 1e-9).
+// moves by < 1e-12, the parity tests allow 1e-9).
 __global__ __launch_bounds__(TE_WG, 4) void timing_kernel(const double2* __restrict__ x, size_t len,
                                                        const double* __restrict__ qtaps, uint32_t n_q, uint32_t k_lo,
                                                        uint32_t nd, double n_sps, int with_delay,
