@@ -139,6 +139,29 @@ __global__ __launch_bounds__(256) void probe_valu_kernel(float* out, int iters, 
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// f64 issue rates: KIND 40 v_fma_f64 (16 independent chains), 41 v_add_f64, 42 v_mul_f64, 43 v_fma_f64 with an SGPR factor
+template <int KIND>
+__global__ __launch_bounds__(256) void probe_f64_kernel(float* out, int iters, double a, double b) {
+    double r[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = threadIdx.x * 0.001 + i;
+    double bv = b;
+    asm volatile("" : "+v"(bv));
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (KIND == 40) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(bv), "v"(bv));
+            if (KIND == 41) asm volatile("v_add_f64 %0, %0, %1" : "+v"(r[i]) : "v"(bv));
+            if (KIND == 42) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(r[i]) : "v"(bv));
+            if (KIND == 43) asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(r[i]) : "s"(a), "v"(bv));
+        }
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += r[i];
+    out[blockIdx.x * 256 + threadIdx.x] = static_cast<float>(s);
+}
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 // KIND 3: v_pk_fma_f32; KIND 4: complex multiply as 2 packed ops with op_sel/neg modifiers
 template <int KIND>
@@ -302,6 +325,10 @@ extern "C" comms_status_t comms_debug_valu(float* d_out, int kind, int iters, in
     else if (kind == 2) comms::probe_valu_kernel<2><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 1.0001f, 0.5f);
     else if (kind == 5) comms::probe_swap_kernel<5><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters);
     else if (kind == 6) comms::probe_swap_kernel<6><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters);
+    else if (kind == 40) comms::probe_f64_kernel<40><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 0.9999, 1e-3);
+    else if (kind == 41) comms::probe_f64_kernel<41><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 0.9999, 1e-3);
+    else if (kind == 42) comms::probe_f64_kernel<42><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 0.9999, 1.0000001);
+    else if (kind == 43) comms::probe_f64_kernel<43><<<dim3(blocks), dim3(256), 0, s>>>(d_out, iters, 0.9999, 1e-3);
     else if (kind >= 20 && kind <= 33) {
         comms::MacProbeArgs a;
         for (int i = 0; i < 32; ++i) a.t[i] = 1e-3f * (i + 1);

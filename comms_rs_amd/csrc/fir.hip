@@ -521,8 +521,8 @@ struct WaveTrace {
 // HR = halo rows of 64 samples: 4 (up to 257 taps, 768 new samples per segment) or, for the plain
 // FIR, as few as the taps need: 3 / 2 / 1 rows for <= 193 / 129 / 65 taps (832 / 896 / 960 new samples
 // per segment from the same two transforms).
-template <int WPB, int MINW, int MODE, int HR = 4>
-__global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(const float2* __restrict__ in,
+template <int WPB, int MINW, int MODE, int HR = 4, class In = const float2*>
+__global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(In in,
                                                                     const float2* __restrict__ hist,
                                                                     int hist_len,
                                                                     float2* __restrict__ out, size_t n,
@@ -1046,8 +1046,8 @@ static void free_fir(comms_fir* h) {
 // One launch of fir_os1024_kernel<.., MODE>: 16-wave workgroups (one per CU, 156 KiB of
 // LDS: shared tables + 16 private exchange buffers) by default, 4-wave workgroups
 // (three per CU) with COMMS_OS1024_WPB=4.
-template <int MODE, int HR = 4>
-static comms_status_t launch_os1024(int wpb, size_t runs, hipStream_t s, const float2* in, const float2* hist,
+template <int MODE, int HR = 4, class In = const float2*>
+static comms_status_t launch_os1024(int wpb, size_t runs, hipStream_t s, In in, const float2* hist,
                                     int n_eff, float2* o, size_t n, size_t nseg, const comms::WTables& tb,
                                     float2* nh, const comms::ChainArgs& ch, hipEvent_t ev_start = nullptr,
                                     hipEvent_t ev_stop = nullptr) {
@@ -1056,20 +1056,20 @@ static comms_status_t launch_os1024(int wpb, size_t runs, hipStream_t s, const f
         const size_t lds = (2112 + 16 * W_LDS) * sizeof(float2);
         static DeviceOnce attr_once;
         if (attr_once.need()) {
-            COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os1024_kernel<16, 4, MODE, HR>),
+            COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os1024_kernel<16, 4, MODE, HR, In>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         }
         if (ev_start) {  // timed launch: the events take the kernel's own begin / end timestamps
-            hipExtLaunchKernelGGL((fir_os1024_kernel<16, 4, MODE, HR>), dim3(static_cast<unsigned>((runs + 15) / 16)),
+            hipExtLaunchKernelGGL((fir_os1024_kernel<16, 4, MODE, HR, In>), dim3(static_cast<unsigned>((runs + 15) / 16)),
                                   dim3(1024), static_cast<uint32_t>(lds), s, ev_start, ev_stop, 0u, in, hist, n_eff, o, n,
                                   nseg, runs, tb, nh, ch);
             return COMMS_OK;
         }
-        fir_os1024_kernel<16, 4, MODE, HR><<<dim3(static_cast<unsigned>((runs + 15) / 16)), dim3(1024), lds, s>>>(
+        fir_os1024_kernel<16, 4, MODE, HR, In><<<dim3(static_cast<unsigned>((runs + 15) / 16)), dim3(1024), lds, s>>>(
             in, hist, n_eff, o, n, nseg, runs, tb, nh, ch);
     } else {
         const size_t lds = (2112 + 4 * W_LDS) * sizeof(float2);
-        fir_os1024_kernel<4, 3, MODE, HR><<<dim3(static_cast<unsigned>((runs + 3) / 4)), dim3(256), lds, s>>>(
+        fir_os1024_kernel<4, 3, MODE, HR, In><<<dim3(static_cast<unsigned>((runs + 3) / 4)), dim3(256), lds, s>>>(
             in, hist, n_eff, o, n, nseg, runs, tb, nh, ch);
     }
     return COMMS_OK;
@@ -1500,6 +1500,16 @@ static comms_status_t launch_dyn_hr(int hr, hipStream_t s, In in, comms_fir* h, 
     }
 }
 template <class In>
+static comms_status_t launch_fixed_hr(int hr, int wpb, size_t runs, hipStream_t s, In in, const float2* hist, int n_eff, float2* o,
+                                      size_t n, size_t nseg, const WTables& tb, float2* nh, hipEvent_t ea, hipEvent_t eb) {
+    switch (hr) {
+        case 1: return launch_os1024<0, 1, In>(wpb, runs, s, in, hist, n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb);
+        case 2: return launch_os1024<0, 2, In>(wpb, runs, s, in, hist, n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb);
+        case 3: return launch_os1024<0, 3, In>(wpb, runs, s, in, hist, n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb);
+        default: return launch_os1024<0, 4, In>(wpb, runs, s, in, hist, n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb);
+    }
+}
+template <class In>
 static void launch_direct_in(comms_fir* h, In in, const float2* hist, float2* o, size_t n, float2* nh, unsigned blocks,
                              size_t lds, int vec4, hipStream_t s) {
     if (h->real_taps)
@@ -1527,7 +1537,7 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
     const float2* hist = h->d_hist[h->cur];
     float2* nh = h->d_hist[h->cur ^ 1];  // the kernel's workgroup 0 advances the history into it
     const int algo = fir_pick(h, n);
-    const bool fused_fmt = algo == COMMS_FIR_DIRECT || (algo == COMMS_FIR_OS1024 && os1024_plan(h, n).dyn);
+    const bool fused_fmt = algo == COMMS_FIR_DIRECT || algo == COMMS_FIR_OS1024;  // their load stages read raw IQ
     const float2* in = nullptr;  // Complex<f32> view of the input (the conversion pass, where the kernel needs one)
     if (!fused_fmt || h->in_fmt == COMMS_IQ_C32) COMMS_TRY(fir_converted_input(h, d_in, n, s, &in));
     if (algo == COMMS_FIR_DIRECT) {
@@ -1561,13 +1571,12 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
                 COMMS_TRY(launch_dyn_hr(pl.hr, s, InU8{static_cast<const uchar2*>(d_in)}, h, o, n, tb, nh, ea, eb));
             else
                 COMMS_TRY(launch_dyn_hr(pl.hr, s, in, h, o, n, tb, nh, ea, eb));
+        } else if (h->in_fmt == COMMS_IQ_I16) {
+            COMMS_TRY(launch_fixed_hr(pl.hr, pl.wpb, runs, s, InI16{static_cast<const short2*>(d_in), h->in_scale}, hist, h->n_eff, o, n, nseg, tb, nh, ea, eb));
+        } else if (h->in_fmt == COMMS_IQ_U8) {
+            COMMS_TRY(launch_fixed_hr(pl.hr, pl.wpb, runs, s, InU8{static_cast<const uchar2*>(d_in)}, hist, h->n_eff, o, n, nseg, tb, nh, ea, eb));
         } else {
-            switch (pl.hr) {
-                case 1: COMMS_TRY((launch_os1024<0, 1>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb))); break;
-                case 2: COMMS_TRY((launch_os1024<0, 2>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb))); break;
-                case 3: COMMS_TRY((launch_os1024<0, 3>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb))); break;
-                default: COMMS_TRY((launch_os1024<0, 4>(pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb))); break;
-            }
+            COMMS_TRY(launch_fixed_hr(pl.hr, pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ea, eb));
         }
         if (!ea) h->toc(s);
         COMMS_TRY(launch_ok("fir_os1024_kernel"));

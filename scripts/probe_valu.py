@@ -7,11 +7,12 @@ l = c.lib()
 f = l.comms_debug_valu; f.restype = C.c_int32; f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
 out = torch.empty(256 * 8 * 256, dtype=torch.float32, device="cuda:0")
 iters = 20000
-KINDS = [int(k) for k in os.environ.get("KINDS", "0,3,4,5,6,7,8,9,10,11,12").split(",")]
+KINDS = [int(k) for k in os.environ.get("KINDS", "0,3,4,5,6,7,8,9,10,11,12,40,41,42,43").split(",")]
 for kind, nm in [(k, n) for k, n in [(0, "v_fma_f32"), (3, "v_pk_fma_f32"), (7, "MAC pk_fma acc+=u*SGPRpair, 2 chains"), (8, "MAC pk_fma acc+=u*VGPRpair, 2 chains"),
                  (20, "form0 acc=u*tV+acc plain"), (21, "form1 +op_sel_hi[1,0,1] on tap"), (22, "form2 +op_sel hi-broadcast on tap"),
                  (23, "form3 acc=acc*tV+u (dst==src0) plain"), (24, "form4 dst==src0 + op_sel_hi[1,0,1]"), (25, "form5 plain, SGPR tap"),
                  (26, "form6 2x v_fma_f32 SGPR tap (2 instr)"), (27, "form7 pk_mul(op_sel)+pk_add (2 instr)"), (28, "form8 acc=u*u+acc (2 VGPR pairs)"),
+                 (40, "v_fma_f64"), (41, "v_add_f64"), (42, "v_mul_f64"), (43, "v_fmac_f64 SGPR factor"),
                  (29, "form9 pk_mul only"), (30, "form10 lo/hi alternating, same VGPR pair twice"), (31, "form11 lo/hi alternating, new pair each"),
                  (32, "form12 lo,lo same pair twice"), (33, "form13 lo/hi alternating SGPR pair"),
                  (9, "MAC SGPR taps, 16 chains"), (10, "MAC VGPR taps, 16 chains"), (11, "MAC SGPR taps, 4 chains"), (12, "MAC VGPR taps, 4 chains"), (4, "cmul=pk_mul+pk_fma (2 instr)"), (5, "v_permlane32_swap (8 per 16 slots)"), (6, "v_permlane16_swap (8 per 16 slots)")] if k in KINDS]:
