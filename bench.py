@@ -166,6 +166,10 @@ class Ctx:
     """Rank, device, process group and the timed-loop helper shared by every config."""
 
     def __init__(self, args):
+        # before anything initialises the GPU runtime: the host driver supports dmabuf IPC only, and RCCL /
+        # cross-process device memory fails without this (it is exported on the GPU boxes already)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import torch
         import torch.distributed as dist
 
@@ -182,8 +186,6 @@ class Ctx:
         self.local_rank = local_rank
         torch.cuda.set_device(local_rank)
         if self.world > 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             if args.backend == "nccl":  # RCCL over xGMI
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
                                         device_id=torch.device("cuda", local_rank))
