@@ -27,7 +27,7 @@
 
 namespace comms {
 
-constexpr int DC_TILE = 512;        // outputs per tile
+constexpr int DC_TILE = 512;        // outputs per tile (DcGeom<.., TILE>: 1024 in the diagnostic build's wide variant)
 constexpr int DC_NMAX = 257;        // taps (kernel-argument budget)
 constexpr int DC_AMAX = 384;        // padded tap array: OPL*R*nd + (OPL-1)*R + pair slack (worst: R = 12, OPL = 4: 376)
 constexpr int DC_RMAX = 16;
@@ -38,15 +38,15 @@ constexpr int DC_OPLMAX = 4;
 // the LDS array is as busy as the vector ALU (the two do not overlap perfectly: ~10 cycles per MAC and SIMD
 // measured against 4.9 for the FMA alone); OPL = 4 halves the LDS traffic for the same FMAs, at half the
 // waves per CU (the staged inputs of a tile bound how many outputs can be resident).
-template <int R, int OPL>
+template <int R, int OPL, int TILE = DC_TILE>
 struct DcGeom {
     static constexpr int PR = OPL * R;                             // phases
-    static constexpr int WG = DC_TILE / OPL;                       // lanes per workgroup
+    static constexpr int WG = TILE / OPL;                          // lanes per workgroup
     static constexpr int HLQ_MAX = (DC_NMAX - 1 + PR - 1) / PR;    // halo in phase-array elements
     static constexpr int HROWS = (HLQ_MAX * PR + WG - 1) / WG;     // halo rows of WG samples
     static constexpr int S = (WG + HLQ_MAX + 1) | 1;               // phase-array stride (odd: staging writes spread over the banks)
     static constexpr size_t LDS = static_cast<size_t>(PR) * S * sizeof(float2);
-    static constexpr int WGPC = R <= 8 ? 4 : R <= 12 ? 3 : 2;     // workgroups per CU that fit in LDS
+    static constexpr int WGPC = (R <= 8 ? 4 : R <= 12 ? 3 : 2) * DC_TILE / TILE;  // workgroups per CU that fit in LDS
     static constexpr int WAVES_PER_SIMD = (WGPC * WG / 64 + 3) / 4;  // __launch_bounds__' second argument: sets the VGPR budget
     static_assert(PR * (HLQ_MAX + 1) + (OPL - 1) * R + 4 <= DC_AMAX, "tap table too small");
 };
@@ -118,9 +118,9 @@ __device__ __forceinline__ void lds_barrier() {  // (kept light: nothing global 
 
 // PRE: the mixer sits in front of the FIR (samples are mixed on their way into LDS); otherwise it
 // follows the FIR (or is absent).
-template <int R, int OPL, bool REAL, bool PRE>
-__global__ __launch_bounds__((DcGeom<R, OPL>::WG), (DcGeom<R, OPL>::WAVES_PER_SIMD)) void fir_decim_kernel(const DecimArgs a) {
-    using G = DcGeom<R, OPL>;
+template <int R, int OPL, bool REAL, bool PRE, int TILE = DC_TILE>
+__global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::WAVES_PER_SIMD)) void fir_decim_kernel(const DecimArgs a) {
+    using G = DcGeom<R, OPL, TILE>;
     constexpr int PR = G::PR, S = G::S, WG = G::WG, HROWS = G::HROWS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* sh = reinterpret_cast<cf*>(smem);  // [PR][S]
@@ -136,7 +136,7 @@ __global__ __launch_bounds__((DcGeom<R, OPL>::WG), (DcGeom<R, OPL>::WAVES_PER_SI
     const bool post = !PRE && (a.mode & COMMS_CHAIN_POST) != 0;
     const bool fm = (a.mode & COMMS_CHAIN_FM) != 0;
     const int ovl = fm ? 1 : 0;           // FM tiles recompute the previous tile's last output
-    const long long ts = DC_TILE - ovl;   // stored outputs per tile
+    const long long ts = TILE - ovl;      // stored outputs per tile
     const int hl = a.hlq * PR;            // halo samples staged to the left of the tile
 
     const size_t t0 = static_cast<size_t>(blockIdx.x) * a.n_tiles / gridDim.x;
@@ -353,18 +353,18 @@ __global__ __launch_bounds__((DcGeom<R, OPL>::WG), (DcGeom<R, OPL>::WAVES_PER_SI
 #undef DC_STAMP
 }
 
-template <int R, int OPL, bool REAL, bool PRE>
+template <int R, int OPL, bool REAL, bool PRE, int TILE = DC_TILE>
 static comms_status_t launch_decim_v(const DecimArgs& a, hipStream_t s) {
-    using G = DcGeom<R, OPL>;
+    using G = DcGeom<R, OPL, TILE>;
     constexpr size_t lds = G::LDS;
     // persistent grid: every workgroup slot of the chip gets a contiguous run of tiles
     const size_t slots = static_cast<size_t>(G::WGPC) * kNumCU;
     const unsigned blocks = static_cast<unsigned>(a.n_tiles < slots ? a.n_tiles : slots);
     static DeviceOnce attr_once;
     if (attr_once.need())
-        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_decim_kernel<R, OPL, REAL, PRE>),
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_decim_kernel<R, OPL, REAL, PRE, TILE>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    fir_decim_kernel<R, OPL, REAL, PRE><<<dim3(blocks), dim3(G::WG), lds, s>>>(a);
+    fir_decim_kernel<R, OPL, REAL, PRE, TILE><<<dim3(blocks), dim3(G::WG), lds, s>>>(a);
     return launch_ok("fir_decim_kernel");
 }
 
@@ -387,9 +387,31 @@ static int decim_opl(bool real, int macs_per_input) {
     return 2;
 }
 
+// Tile width (diagnostic build: COMMS_DECIM_TILE=1024 = 512-lane workgroups, two per CU, so that the waves a
+// SIMD holds are in the same phase more often)
+static int decim_tile(bool real, int R, int opl) {
+#ifdef COMMS_DIAG
+    static const int forced = [] {
+        const char* v = getenv("COMMS_DECIM_TILE");
+        return v && *v ? atoi(v) : 0;
+    }();
+    if (real && opl == 2 && R == 8 && forced == 1024) return 1024;
+#else
+    (void)real; (void)R; (void)opl;
+#endif
+    return DC_TILE;
+}
+
 template <int R>
-static comms_status_t launch_decim(const DecimArgs& a, bool real, int opl, hipStream_t s) {
+static comms_status_t launch_decim(const DecimArgs& a, bool real, int opl, int tile, hipStream_t s) {
     const bool pre = (a.mode & COMMS_CHAIN_PRE) != 0;
+#ifdef COMMS_DIAG
+    if constexpr (R == 8) {
+        if (tile == 1024) return pre ? launch_decim_v<R, 2, true, true, 1024>(a, s) : launch_decim_v<R, 2, true, false, 1024>(a, s);
+    }
+#else
+    (void)tile;
+#endif
     if (!real) return pre ? launch_decim_v<R, 2, false, true>(a, s) : launch_decim_v<R, 2, false, false>(a, s);
 #ifdef COMMS_DIAG
     if constexpr (R <= 8) {
@@ -451,7 +473,8 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
     const bool real = h->real_taps;
     const int R = static_cast<int>(rate), N = h->n_eff;
     const int opl = R <= 8 ? decim_opl(real, (N + R - 1) / R) : 2;  // (the tap pairs of 4 outputs need R <= 8: SGPR budget)
-    const int PR = opl * R, WG = DC_TILE / opl;
+    const int tile = decim_tile(real, R, opl);
+    const int PR = opl * R, WG = tile / opl;
     DecimArgs a{};
     a.in = d_in;
     a.fmt = h->in_fmt;
@@ -464,7 +487,7 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
     a.n = n;
     a.n_out = n / rate;
     const bool fm = (mode & COMMS_CHAIN_FM) != 0;
-    const size_t ts = DC_TILE - (fm ? 1 : 0);
+    const size_t ts = static_cast<size_t>(tile) - (fm ? 1 : 0);
     a.n_tiles = (a.n_out + ts - 1) / ts;
     a.hist_len = h->n_eff;
     a.hlq = (N - 1 + PR - 1) / PR;
@@ -494,15 +517,15 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
     h->tic(s);
     comms_status_t st;
     switch (R) {
-        case 2: st = launch_decim<2>(a, real, opl, s); break;
-        case 3: st = launch_decim<3>(a, real, opl, s); break;
-        case 4: st = launch_decim<4>(a, real, opl, s); break;
-        case 5: st = launch_decim<5>(a, real, opl, s); break;
-        case 6: st = launch_decim<6>(a, real, opl, s); break;
-        case 8: st = launch_decim<8>(a, real, opl, s); break;
-        case 10: st = launch_decim<10>(a, real, 2, s); break;
-        case 12: st = launch_decim<12>(a, real, 2, s); break;
-        case 16: st = launch_decim<16>(a, real, 2, s); break;
+        case 2: st = launch_decim<2>(a, real, opl, tile, s); break;
+        case 3: st = launch_decim<3>(a, real, opl, tile, s); break;
+        case 4: st = launch_decim<4>(a, real, opl, tile, s); break;
+        case 5: st = launch_decim<5>(a, real, opl, tile, s); break;
+        case 6: st = launch_decim<6>(a, real, opl, tile, s); break;
+        case 8: st = launch_decim<8>(a, real, opl, tile, s); break;
+        case 10: st = launch_decim<10>(a, real, 2, tile, s); break;
+        case 12: st = launch_decim<12>(a, real, 2, tile, s); break;
+        case 16: st = launch_decim<16>(a, real, 2, tile, s); break;
         default: return fail(COMMS_ERR_ARG, "no decimating kernel for rate %d", R);
     }
     h->toc(s);
