@@ -118,7 +118,7 @@ __device__ __forceinline__ void lds_barrier() {  // (kept light: nothing global 
 
 // PRE: the mixer sits in front of the FIR (samples are mixed on their way into LDS); otherwise it
 // follows the FIR (or is absent).
-template <int R, int OPL, bool REAL, bool PRE, int TILE = DC_TILE>
+template <int R, int OPL, bool REAL, bool PRE, int TILE = DC_TILE, int CHX = 0>
 __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::WAVES_PER_SIMD)) void fir_decim_kernel(const DecimArgs a) {
     using G = DcGeom<R, OPL, TILE>;
     constexpr int PR = G::PR, S = G::S, WG = G::WG, HROWS = G::HROWS;
@@ -257,9 +257,9 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
 #pragma unroll
         for (int c = 0; c < OPL; ++c) acc[c] = cf{0.f, 0.f};
         const cf* up = sh + tid + a.hlq;
-        constexpr int CH = OPL == 2 ? (R <= 10 ? R : R / 2) : (R <= 4 ? R : R % 4 == 0 ? R / 2 : R <= 6 ? R : R / 2);  // taps per chunk
-        static_assert(PR % CH == 0 && (PR / CH) % 2 == 0, "chunks must pair up inside a block");
+        constexpr int CH = CHX ? CHX : OPL == 2 ? (R <= 10 ? R : R / 2) : (R <= 4 ? R : R % 4 == 0 ? R / 2 : R <= 6 ? R : R / 2);  // taps per chunk
         constexpr int NCH = PR / CH;
+        static_assert(PR % CH == 0 && (NCH == 1 || NCH % 2 == 0), "chunks must pair up inside a block (or be whole blocks)");
         constexpr int NP = ((CH & 1) + CH + (OPL - 1) * R + 1) / 2;  // SGPR pairs (A[2i], A[2i+1]) covering the chunk's taps of all OPL outputs (an odd chunk may start in a pair's hi half)
         cf ua[CH], ub[CH];
         v2f ra[NP], rb[NP], ia[NP], ib_[NP];
@@ -290,6 +290,21 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
             }
         };
         fetch(0, 0, ua, ra, ia);
+        if constexpr (NCH == 1) {  // whole blocks as chunks (diagnostic variant): blocks pair up, an odd last one runs alone
+            int d = 0;
+            for (; d + 1 < a.nd; d += 2) {
+                landed(ua, ra, ia);
+                fetch(d + 1, 0, ub, rb, ib_);
+                macs(0, ua, ra, ia);
+                landed(ub, rb, ib_);
+                if (d + 2 < a.nd) fetch(d + 2, 0, ua, ra, ia);
+                macs(0, ub, rb, ib_);
+            }
+            if (d < a.nd) {
+                landed(ua, ra, ia);
+                macs(0, ua, ra, ia);
+            }
+        } else
         for (int d = 0; d < a.nd; ++d) {
 #pragma unroll
             for (int g = 0; g < NCH; g += 2) {
@@ -353,7 +368,7 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
 #undef DC_STAMP
 }
 
-template <int R, int OPL, bool REAL, bool PRE, int TILE = DC_TILE>
+template <int R, int OPL, bool REAL, bool PRE, int TILE = DC_TILE, int CHX = 0>
 static comms_status_t launch_decim_v(const DecimArgs& a, hipStream_t s) {
     using G = DcGeom<R, OPL, TILE>;
     constexpr size_t lds = G::LDS;
@@ -362,9 +377,9 @@ static comms_status_t launch_decim_v(const DecimArgs& a, hipStream_t s) {
     const unsigned blocks = static_cast<unsigned>(a.n_tiles < slots ? a.n_tiles : slots);
     static DeviceOnce attr_once;
     if (attr_once.need())
-        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_decim_kernel<R, OPL, REAL, PRE, TILE>),
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_decim_kernel<R, OPL, REAL, PRE, TILE, CHX>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    fir_decim_kernel<R, OPL, REAL, PRE, TILE><<<dim3(blocks), dim3(G::WG), lds, s>>>(a);
+    fir_decim_kernel<R, OPL, REAL, PRE, TILE, CHX><<<dim3(blocks), dim3(G::WG), lds, s>>>(a);
     return launch_ok("fir_decim_kernel");
 }
 
@@ -407,6 +422,8 @@ static comms_status_t launch_decim(const DecimArgs& a, bool real, int opl, int t
     const bool pre = (a.mode & COMMS_CHAIN_PRE) != 0;
 #ifdef COMMS_DIAG
     if constexpr (R == 8) {
+        static const int chx = [] { const char* v = getenv("COMMS_DECIM_CH"); return v && *v ? atoi(v) : 0; }();
+        if (chx == 16 && real && opl == 2 && !pre && tile == DC_TILE) return launch_decim_v<R, 2, true, false, DC_TILE, 16>(a, s);
         if (tile == 1024) return pre ? launch_decim_v<R, 2, true, true, 1024>(a, s) : launch_decim_v<R, 2, true, false, 1024>(a, s);
     }
 #else
