@@ -781,6 +781,35 @@ __global__ __launch_bounds__(1024, 4) void fft_cols_kernel(const cf* in, cf* out
     }
 }
 
+// ---------------------------------------------------------------- N = 2^21 ... 2^24: third launch
+// For N = 1024 * N2 (N2 = 2048 ... 16384) the four-step runs as columns (1024 points at stride N2, on
+// fft1024x16_kernel with the twiddle) -> rows (N2 points, contiguous, in place, on the single-pass
+// fft_rx1024_kernel) -> this transpose, X[k1 + 1024 k2] = Z[k1][k2]: a row pass with a transposed store would
+// write 16 KiB / N2 = 8 ... 1 complex values per piece, so the transposition is its own coalesced pass
+// (64 x 64 tiles through LDS, 16 B/point) -- 48 B/point in all, every launch on a kernel that runs near
+// the rate its access pattern allows, instead of two passes of the generic radix-4 tile kernel.
+constexpr int TR_T = 64;
+__global__ __launch_bounds__(256) void fft_transpose_kernel(const cf* __restrict__ in, cf* __restrict__ out,
+                                                            unsigned rows, unsigned cols, size_t n_tiles) {
+    __shared__ cf tile[TR_T][TR_T + 1];
+    const unsigned tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const unsigned tiles_c = cols / TR_T, tiles_r = rows / TR_T;
+    const size_t per = static_cast<size_t>(tiles_c) * tiles_r, mat = static_cast<size_t>(rows) * cols;
+    for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const size_t b = t / per;
+        const unsigned tt = static_cast<unsigned>(t - b * per);
+        const unsigned r0 = (tt / tiles_c) * TR_T, c0 = (tt % tiles_c) * TR_T;
+        const cf* src = in + b * mat + static_cast<size_t>(r0) * cols + c0;
+        cf* dst = out + b * mat + static_cast<size_t>(c0) * rows + r0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TR_T / 4; ++j) tile[ty + 4 * j][tx] = src[static_cast<size_t>(ty + 4 * j) * cols + tx];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TR_T / 4; ++j) dst[static_cast<size_t>(ty + 4 * j) * rows + tx] = tile[tx][ty + 4 * j];
+    }
+}
+
 // Exact-index O(N^2) DFT, one transform per workgroup, f64 accumulation.
 // Short lengths (N <= 128): a 256-lane workgroup takes G = 256 / N transforms at a time, one lane
 // per output bin, so that e.g. a 10-point batch keeps 250 lanes busy instead of 10.
@@ -907,8 +936,14 @@ struct Pow2Plan {
     float2* d_colr = nullptr;  //   W_N1^{r}, r < N1/2 (radix-2 front stage of 128 / 512)
     int threads[2] = {0, 0};
     size_t lds[2] = {0, 0};
+    Pow2Plan* rows = nullptr;  // N = 2^21 ... 2^24: the plan of the N2-point row transforms (columns: pass[0]; then the transpose)
 
     void release() {
+        if (rows) {
+            rows->release();
+            delete rows;
+            rows = nullptr;
+        }
         for (auto& p : d_tw)
             if (p) {
                 (void)hipFree(p);
@@ -975,6 +1010,33 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
         p.N = static_cast<size_t>(p.C) * N;
         COMMS_TRY(upload_tw(N, N, 1, &pl.d_tw[0]));
         p.twL = reinterpret_cast<const cf*>(pl.d_tw[0]);
+    } else if (logN > 20) {
+        // 2^21 .. 2^24: columns of 1024 points (stride N2) -> rows of N2 = N / 1024 points -> transpose
+        pl.n_pass = 2;  // (pass[1] is unused; the row transforms have a plan of their own)
+        const size_t N2 = N >> 10;
+        FftTileParams& a = pl.pass[0];
+        memset(&a, 0, sizeof(a));
+        memset(&pl.pass[1], 0, sizeof(pl.pass[1]));
+        tile_geometry(a, 1024, 16);
+        a.in_c_fast = 1;
+        a.out_c_fast = 1;
+        a.in_cs = 1;
+        a.in_ls = N2;
+        a.out_cs = 1;
+        a.out_ks = N2;
+        a.tiles_per_xform = N2 / a.C;
+        a.tile_step_in = a.tile_step_out = a.C;
+        a.N = N;
+        a.apply_tw = 1;
+        COMMS_TRY(upload_tw(1024, 1024, 1, &pl.d_tw[0]));
+        COMMS_TRY(upload_tw(4096, N, 1, &pl.d_tw[2]));
+        COMMS_TRY(upload_tw(N / 4096, N, 4096, &pl.d_tw[3]));
+        a.twL = reinterpret_cast<const cf*>(pl.d_tw[0]);
+        a.tw_lo = reinterpret_cast<const cf*>(pl.d_tw[2]);
+        a.tw_hi = reinterpret_cast<const cf*>(pl.d_tw[3]);
+        pl.rows = new (std::nothrow) Pow2Plan;
+        COMMS_ARG(pl.rows != nullptr, "out of host memory");
+        COMMS_TRY(pow2_plan_build(*pl.rows, N2));
     } else {
         pl.n_pass = 2;
         // 2^15 .. 2^20: N2 = 1024 so that pass 2 (and for 2^20 pass 1 too) runs on fft1024x16_kernel;
@@ -1251,6 +1313,19 @@ static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size
         return v && *v && *v != '0';
     }();
     if (pl.rx_rad && !no_rx) return run_rx(pl, in, out, batch * pl.N, inverse, s);
+    if (pl.rows) {  // N = 2^21 ... 2^24: columns (in -> scratch), rows (in place), transpose (scratch -> out)
+        FftTileParams p = pl.pass[0];
+        p.n_tiles = batch * p.tiles_per_xform;
+        COMMS_TRY(launch_fast(pl, in, scratch, p, inverse, s));
+        COMMS_TRY(run_rx(*pl.rows, scratch, scratch, batch * pl.N, inverse, s));
+        const unsigned cols = static_cast<unsigned>(pl.N >> 10);
+        const size_t n_tiles = batch * (1024 / TR_T) * (cols / TR_T);
+        const size_t slots = static_cast<size_t>(16) * kNumCU;
+        const unsigned blocks = static_cast<unsigned>(n_tiles < slots ? n_tiles : slots);
+        fft_transpose_kernel<<<dim3(blocks), dim3(256), 0, s>>>(reinterpret_cast<const cf*>(scratch), reinterpret_cast<cf*>(out), 1024u,
+                                                               cols, n_tiles);
+        return launch_ok("fft_transpose_kernel");
+    }
     for (int i = 0; i < pl.n_pass; ++i) {
         FftTileParams p = pl.pass[i];
         const float2* src = in;

@@ -588,6 +588,31 @@ def test_fft_four_step_column_pass(c, logn, inverse):
     fft_close(c.FFTBatchNode(n, inverse).run(x), f(x.astype(np.complex128).reshape(batch, n)).reshape(-1))
 
 
+@pytest.mark.parametrize("logn,batch", [(21, 3), (22, 2), (23, 1), (24, 2)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_fft_above_2p20_columns_rows_transpose(c, logn, batch, inverse):
+    """N = 2^21 ... 2^24 (fft_node.rs:65-74 accepts any size): 1024-point columns at stride N / 1024 with the
+    four-step twiddle, N / 1024-point rows in place, a tiled transpose.  Device-resident, out of place and in
+    place; against numpy's f64 FFT of the same counter-based input (the oracle's own FFT is checked against
+    numpy in the CPU suite)."""
+    import torch
+
+    n = 1 << logn
+    x = torch.empty(n * batch, dtype=torch.complex64, device="cuda:0")
+    c.synth_iq_dev(x.data_ptr(), n * batch, 0, 50 + logn)
+    y = torch.empty_like(x)
+    s = torch.cuda.current_stream().cuda_stream
+    node = c.FFTBatchNode(n, inverse)
+    node.run_dev(x.data_ptr(), n * batch, y.data_ptr(), s)
+    torch.cuda.synchronize()
+    xs = c.synth_iq(n * batch, 0, 50 + logn).astype(np.complex128).reshape(batch, n)
+    want = (np.fft.ifft(xs, axis=1) * n if inverse else np.fft.fft(xs, axis=1)).reshape(-1)
+    fft_close(y.cpu().numpy(), want)
+    node.run_dev(x.data_ptr(), n * batch, x.data_ptr(), s)   # in place
+    torch.cuda.synchronize()
+    assert torch.equal(torch.view_as_real(x), torch.view_as_real(y))
+
+
 def test_fft_config4_size_roundtrip(c):
     # BASELINE config 4 length (2^20), small batch: forward vs oracle, then inverse / N == input
     import torch
