@@ -14,7 +14,9 @@
 //   * 2^15 ... 2^20 (four-step, N = N1 * 1024): pass 1 = fft_cols_kernel (N1 = 32 ... 512: the same
 //     wave forms on columns, x W_N^{n2*k1}) or fft1024x16_kernel (N1 = 1024, config 4);
 //     pass 2 = fft1024x16_kernel on the rows with the transposed store.
-//   * > 2^20, and the ragged tail of a batch: fft_tile_kernel -- radix-4 Stockham passes in LDS on
+//   * 2^21 ... 2^24: fft1024x16_kernel on 1024-point columns (stride N/1024, four-step twiddle), fft_rx1024_kernel on
+//     the N/1024-point rows in place, fft_transpose_kernel for the output order (three launches, 48 B/point).
+//   * the ragged tail of a batch (and the COMMS_FFT_NO_* fallbacks): fft_tile_kernel -- radix-4 Stockham passes in LDS on
 //     tiles of C sub-transforms of length L (C*L <= 16384 points), one pass or four-step.
 //   * other lengths: exact-index O(N^2) DFT with f64 accumulation (N <= 64) or Bluestein's
 //     chirp-z on the power-of-two kernels (N > 64).
