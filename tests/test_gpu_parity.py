@@ -613,6 +613,16 @@ def test_fft_above_2p20_columns_rows_transpose(c, logn, batch, inverse):
     assert torch.equal(torch.view_as_real(x), torch.view_as_real(y))
 
 
+def test_fft_bluestein_on_a_padded_length_above_2p20(c):
+    """A non-power-of-two length whose chirp-z padding (2^21) runs on the columns / rows / transpose path,
+    forward and inverse, against numpy's f64 FFT."""
+    n = 600011
+    x = c.synth_iq(2 * n, 0, 77)
+    xs = x.astype(np.complex128).reshape(2, n)
+    fft_close(c.FFTBatchNode(n, False).run(x), np.fft.fft(xs, axis=1).reshape(-1))
+    fft_close(c.FFTBatchNode(n, True).run(x), (np.fft.ifft(xs, axis=1) * n).reshape(-1))
+
+
 def test_fft_config4_size_roundtrip(c):
     # BASELINE config 4 length (2^20), small batch: forward vs oracle, then inverse / N == input
     import torch
