@@ -84,6 +84,7 @@ _PROTOS = {
     "comms_pulse_run_dev": [_vp, _vp, _sz, _vp, _vp],
     "comms_pulse_set_mixer": [_vp, _f64, _f64],
     "comms_pulse_get_phase": [_vp, C.POINTER(_f64)],
+    "comms_pulse_set_output_format": [_vp, _i32, C.c_float],
     "comms_pulse_destroy": [_vp],
     "comms_mixer_create": [_f64, _f64, _i32, _pp],
     "comms_mixer_run": [_vp, _vp, _sz, _vp],

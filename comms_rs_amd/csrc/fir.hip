@@ -895,6 +895,8 @@ struct PulseMix {
     uint64_t turns0, frac;
     double sweep_c, sweep_s;  // rot(outputs per grid sweep * frac)
     int on;
+    int out_i16;              // store `(out_scale * y) as i16` pairs instead of Complex<f32> (comms_pulse_set_output_format)
+    float out_scale;
 };
 __device__ __forceinline__ void pulse_rotor_at(uint64_t turns, double& c, double& s) {
     sincos(static_cast<double>(turns >> 11) * (kTwoPiF * 0x1.0p-53), &s, &c);
@@ -935,7 +937,10 @@ __global__ __launch_bounds__(256) void pulse_kernel(const float2* __restrict__ s
             rs = rc * mx.sweep_s + rs * mx.sweep_c;
             rc = nc;
         }
-        out[i] = acc;
+        if (mx.out_i16)
+            reinterpret_cast<short2*>(out)[i] = c32_as_i16(acc, mx.out_scale);
+        else
+            out[i] = acc;
     }
 }
 
@@ -1010,9 +1015,15 @@ __global__ __launch_bounds__(256) void pulse_poly_kernel(const PulseArgs a) {
             rc = nc;
         }
         if (m < a.n_sym) {
-            float2* o = a.out + m * SPS;
+            if (a.mx.out_i16) {  // the transmit chain straight into the IQOutput wire format: 4 B per output
+                short2* o = reinterpret_cast<short2*>(a.out) + m * SPS;
 #pragma unroll
-            for (int p = 0; p < SPS; ++p) o[p] = to_f2(acc[p]);
+                for (int p = 0; p < SPS; ++p) o[p] = c32_as_i16(to_f2(acc[p]), a.mx.out_scale);
+            } else {
+                float2* o = a.out + m * SPS;
+#pragma unroll
+                for (int p = 0; p < SPS; ++p) o[p] = to_f2(acc[p]);
+            }
         }
     }
 }
@@ -1763,6 +1774,8 @@ struct comms_pulse : Handle {
     // fused output mixer (comms_pulse_set_mixer): phase of the next output, step per output
     bool mix = false;
     uint64_t turns = 0, frac = 0;
+    bool out_i16 = false;  // comms_pulse_set_output_format
+    float out_scale = 1.0f;
 };
 
 // Launches pulse_poly_kernel if (sps, taps) fit it; false -> the caller runs the generic kernel.
@@ -1790,6 +1803,8 @@ static bool pulse_poly_try(comms_pulse* h, const float2* sym, size_t n_sym, floa
         }
     const size_t ntiles = (n_sym + 255) / 256;
     const unsigned blocks = static_cast<unsigned>(ntiles < 8u * comms::kNumCU ? ntiles : 8u * comms::kNumCU);
+    a.mx.out_i16 = h->out_i16 ? 1 : 0;
+    a.mx.out_scale = h->out_scale;
     if (h->mix) {
         a.mx.on = 1;
         a.mx.turns0 = h->turns;
@@ -1888,7 +1903,7 @@ comms_status_t comms_pulse_run_dev(comms_pulse_t* h, const comms_c32* d_sym, siz
     if (!n_sym) return COMMS_OK;
     COMMS_ARG(n_sym <= SIZE_MAX / 8 / h->sps, "n_sym * sam_per_sym overflows");
     const size_t n_out = n_sym * h->sps;
-    COMMS_ARG(!ranges_overlap(d_sym, n_sym * 8, d_out, n_out * 8), "pulse shaping cannot run in place");
+    COMMS_ARG(!ranges_overlap(d_sym, n_sym * 8, d_out, n_out * (h->out_i16 ? 4 : 8)), "pulse shaping cannot run in place");
     hipStream_t s = nullptr;
     COMMS_TRY(h->enter(stream, &s));
     const float2* sym = reinterpret_cast<const float2*>(d_sym);
@@ -1897,6 +1912,8 @@ comms_status_t comms_pulse_run_dev(comms_pulse_t* h, const comms_c32* d_sym, siz
         size_t blocks = (n_out + 255) / 256;
         if (blocks > 8u * kNumCU) blocks = 8u * kNumCU;
         PulseMix mx{};
+        mx.out_i16 = h->out_i16 ? 1 : 0;
+        mx.out_scale = h->out_scale;
         if (h->mix) {
             mx.on = 1;
             mx.turns0 = h->turns;
@@ -1925,6 +1942,18 @@ comms_status_t comms_pulse_set_mixer(comms_pulse_t* h, double dphase, double pha
     return COMMS_OK;
 }
 
+// The transmit chain straight into the wire format IQOutput writes (src/io/raw_iq.rs:173-178):
+// every later run stores `(scale * y) as i16` pairs (examples/single_thread_bpsk.rs:40-44) instead of
+// Complex<f32> -- 4 B per output sample instead of 8 written + 8 read + 4 written by a conversion pass.
+comms_status_t comms_pulse_set_output_format(comms_pulse_t* h, int32_t format, float scale) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG(format == COMMS_IQ_C32 || format == COMMS_IQ_I16, "the pulse node writes Complex<f32> or i16 (got format %d)", format);
+    COMMS_ARG(format != COMMS_IQ_I16 || std::isfinite(scale), "scale must be finite");
+    h->out_i16 = format == COMMS_IQ_I16;
+    h->out_scale = h->out_i16 ? scale : 1.0f;
+    return COMMS_OK;
+}
+
 comms_status_t comms_pulse_get_phase(const comms_pulse_t* h, double* out_phase) {
     COMMS_ARG(h && out_phase, "NULL argument");
     COMMS_ARG(h->mix, "no mixer is fused into this pulse node");
@@ -1938,7 +1967,7 @@ comms_status_t comms_pulse_run(comms_pulse_t* h, const comms_c32* sym, size_t n_
     COMMS_ARG((sym && out) || !n_sym, "NULL host pointer");
     COMMS_TRY(use_device(h->device));
     if (!n_sym) return COMMS_OK;
-    return h->run_host(sym, n_sym * sizeof(comms_c32), out, n_sym * h->sps * sizeof(comms_c32), [&](void* d_in, void* d_out) {
+    return h->run_host(sym, n_sym * sizeof(comms_c32), out, n_sym * h->sps * (h->out_i16 ? 4 : sizeof(comms_c32)), [&](void* d_in, void* d_out) {
         return comms_pulse_run_dev(h, static_cast<const comms_c32*>(d_in), n_sym, static_cast<comms_c32*>(d_out), COMMS_STREAM_HANDLE);
     });
 }

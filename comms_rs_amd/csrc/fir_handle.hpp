@@ -43,6 +43,19 @@ struct InU8 {
     }
 };
 
+// `(scale * x) as i16` (examples/single_thread_bpsk.rs:40-44): Rust's float -> int `as` truncates toward zero,
+// saturates, and maps NaN to 0 -- what IQOutput then writes (src/io/raw_iq.rs:173-178).  Shared by the
+// stand-alone conversion kernel (iqformat.hip) and the pulse shaper's i16 store stage.
+__device__ __forceinline__ short rust_as_i16(float v) {
+    if (v != v) return 0;                 // NaN -> 0
+    if (v >= 32767.0f) return 32767;      // saturate
+    if (v <= -32768.0f) return -32768;
+    return static_cast<short>(static_cast<int>(v));  // truncation toward zero
+}
+__device__ __forceinline__ short2 c32_as_i16(float2 v, float scale) {
+    return make_short2(rust_as_i16(scale * v.x), rust_as_i16(scale * v.y));
+}
+
 // Folded into every FIR kernel (workgroup 0): new_hist = last HL samples of
 // concat(old_hist[HL], in[n]) -- the reference's `state` after the batch.
 template <class In = const float2*>

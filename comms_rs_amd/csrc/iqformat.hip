@@ -7,6 +7,7 @@
 //       Rust `as`: truncate toward zero, saturate, NaN -> 0);
 //   u8 pairs from an RTL-SDR -- examples/fm_radio.rs:82-90: (x as f32 - 127.5) / 127.5.
 #include "common.hpp"
+#include "fir_handle.hpp"
 
 namespace comms {
 
@@ -19,12 +20,6 @@ __global__ __launch_bounds__(256) void i16_to_c32_kernel(const short2* __restric
     }
 }
 
-__device__ __forceinline__ short rust_as_i16(float v) {
-    if (v != v) return 0;                 // NaN -> 0
-    if (v >= 32767.0f) return 32767;      // saturate
-    if (v <= -32768.0f) return -32768;
-    return static_cast<short>(static_cast<int>(v));  // truncation toward zero
-}
 __global__ __launch_bounds__(256) void c32_to_i16_kernel(const float2* __restrict__ in, short2* __restrict__ out,
                                                          size_t n, float scale) {
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;

@@ -168,6 +168,7 @@ public:
         return *this;
     }
 
+    // (the i16 store stage, comms_pulse_set_output_format, is offered on the device-resident node below)
     Result<std::vector<Complex32>> run(const Complex32& sym) {
         std::vector<Complex32> out(sps_);
         comms_status_t st = comms_pulse_run(h_, c32(&sym), 1, c32(out.data()));

@@ -193,13 +193,24 @@ class PulseNode(_Handle):
         check(lib().comms_pulse_get_phase(self._h, C.byref(p)))
         return p.value
 
+    _out_i16 = False
+
+    def set_output_format(self, fmt, scale=1.0):
+        """"i16": run() returns int16 (n, 2) = `(scale * y) as i16`, the IQOutput wire format, written by the
+        kernel's store stage; "c32" restores the default."""
+        check(lib().comms_pulse_set_output_format(self._h, _IQ[fmt][0], float(scale)))
+        self._out_i16 = fmt == "i16"
+        return self
+
     def run(self, sym):
         """One symbol (scalar) -> sam_per_sym samples, or a batch of symbols."""
-        scalar = np.isscalar(sym) or np.ndim(sym) == 0
         s = _as_c64(np.atleast_1d(sym))
-        out = np.empty(s.size * self.sam_per_sym, np.complex64)
+        if self._out_i16:
+            out = np.empty((s.size * self.sam_per_sym, 2), np.int16)
+        else:
+            out = np.empty(s.size * self.sam_per_sym, np.complex64)
         check(lib().comms_pulse_run(self._h, _ptr(s), s.size, _ptr(out)))
-        return out if not scalar else out
+        return out
 
     def run_dev(self, sym_ptr, n_sym, out_ptr, stream=0):
         check(lib().comms_pulse_run_dev(self._h, sym_ptr, n_sym, out_ptr, stream))

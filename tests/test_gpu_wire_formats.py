@@ -119,3 +119,34 @@ def test_metric_chain_from_i16_full_size(c):
     torch.cuda.synchronize()
     assert torch.equal(torch.view_as_real(za), torch.view_as_real(zb))
     assert float(za.abs().max()) > 0.1
+
+
+@pytest.mark.parametrize("n_taps,sps,mix", [(63, 4, True), (63, 4, False), (32, 4, False), (17, 3, True), (100, 7, True)])
+def test_transmit_chain_writes_the_i16_wire_format(c, n_taps, sps, mix):
+    """examples/single_thread_bpsk.rs:29-44: symbols -> pulse shaping [-> mixer] -> `(8192.0 * x) as i16` -> IQOutput.
+    The pulse node's store stage writes the i16 pairs itself (polyphase kernel at sps 3 / 4, generic kernel at 7):
+    bit-identical to comms_iq_c32_to_i16 of the same node's Complex<f32> output, across two calls, and within one
+    LSB of the oracle chain (the f32 outputs differ by rounding, the truncation can then differ by one)."""
+    rng = np.random.default_rng(n_taps + sps)
+    taps = oracle.rrc_taps(n_taps, float(sps), 0.25)
+    sym = ((2 * rng.integers(0, 2, 20000) - 1) + 1j * (2 * rng.integers(0, 2, 20000) - 1)).astype(np.complex64)
+    a, b = c.PulseNode(taps, sps), c.PulseNode(taps, sps)
+    if mix:
+        a.set_mixer(2 * np.pi * 0.1, 0.3)
+        b.set_mixer(2 * np.pi * 0.1, 0.3)
+    a.set_output_format("i16", 8192.0)
+    got = np.concatenate([a.run(sym[:7777]), a.run(sym[7777:])])
+    ref = np.concatenate([b.run(sym[:7777]), b.run(sym[7777:])])
+    assert got.dtype == np.int16 and got.shape == (sym.size * sps, 2)
+    assert np.array_equal(got, c.iq_c32_to_i16(ref, 8192.0))
+    y = oracle.batch_fir(oracle.upsample(sym, sps), taps, oracle.default_state(taps), norotate=True)
+    if mix:
+        y = oracle.Mixer(0.3, 2 * np.pi * 0.1).mix(y)
+    want = oracle.iq_c32_to_i16(y, 8192.0)
+    assert np.max(np.abs(got.astype(np.int32) - want.astype(np.int32))) <= 1
+    # saturation and the default again
+    a.set_output_format("i16", 1e9)
+    sat = a.run(sym[:16])
+    assert set(np.unique(sat)) <= {-32768, 32767, 0}
+    a.set_output_format("c32")
+    assert a.run(sym[:16]).dtype == np.complex64
