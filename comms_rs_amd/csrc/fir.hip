@@ -1035,6 +1035,7 @@ using namespace comms;
 // ================================================================= FIR handle (struct comms_fir: fir_handle.hpp)
 static void free_fir(comms_fir* h) {
     h->conv.release();
+    if (h->d_qt) (void)hipFree(h->d_qt);
     (void)use_device(h->device);
     if (h->d_taps_pad) (void)hipFree(h->d_taps_pad);
     if (h->d_wtw1) (void)hipFree(h->d_wtw1);

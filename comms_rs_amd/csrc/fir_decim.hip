@@ -19,6 +19,7 @@
 // half): no tap ever occupies a VGPR or an LDS slot.  Four workgroups per CU (37 KiB of LDS
 // each at R = 8) cover each other's load / compute / store phases.
 #include <cmath>
+#include <vector>
 
 #include "common.hpp"
 #include "fft_radix.hpp"
@@ -68,6 +69,7 @@ struct DecimArgs {
     float2 step[DC_OPLMAX * DC_RMAX];  // e^{i * WG m * dphi}, staging row m
     float are[DC_AMAX];            // A[m] = Re h[m - (PR-1)], zero outside [0, N)
     float aim[DC_AMAX];
+    const float* qt;               // OPL = 4: the taps of one LDS read stored together, Q[m][c] = A[m + R c] (device memory)
     unsigned long long* stamps;    // diagnostic (scripts/stamp_decim.py): per-wave cycles per phase, or NULL
 };
 
@@ -257,6 +259,50 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
 #pragma unroll
         for (int c = 0; c < OPL; ++c) acc[c] = cf{0.f, 0.f};
         const cf* up = sh + tid + a.hlq;
+        if constexpr (OPL == 4) {
+            // Four outputs per lane: the taps of the four outputs that one LDS read feeds, A[m + R c] (c = 0..3), sit
+            // together in a device-resident table, so a chunk of four reads needs ONE s_load_dwordx16 and 8 SGPR
+            // pairs (the sliding window of the two-output form would need 14 and spill).  Real taps only.
+            static_assert(REAL, "the four-output form is built for real taps");
+            typedef const __attribute__((address_space(4))) float* cptr;  // constant address space: scalar loads
+            const cptr qt = (cptr)(a.qt);
+            constexpr int CH4 = PR % 16 == 0 ? 8 : 4, NCH4 = PR / CH4;  // reads per chunk (8: two s_load_dwordx16, 32 MACs of cover)
+            static_assert(PR % CH4 == 0 && NCH4 % 2 == 0, "chunks must pair up inside a block (even R)");
+            cf ua[CH4], ub[CH4];
+            v2f ra[2 * CH4], rb[2 * CH4];
+            auto fetch4 = [&](int d, int g, cf (&u)[CH4], v2f (&tr)[2 * CH4]) {
+                const int m0 = PR * d + g * CH4;
+#pragma unroll
+                for (int i = 0; i < 2 * CH4; ++i) tr[i] = v2f{qt[4 * m0 + 2 * i], qt[4 * m0 + 2 * i + 1]};
+#pragma unroll
+                for (int i = 0; i < CH4; ++i) u[i] = up[(PR - 1 - (g * CH4 + i)) * S - d];
+            };
+            auto landed4 = [&](cf (&u)[CH4], v2f (&tr)[2 * CH4]) { asm volatile("" ::"v"(u[CH4 - 1]), "s"(tr[2 * CH4 - 1])); };
+            auto macs4 = [&](const cf (&u)[CH4], const v2f (&tr)[2 * CH4]) {
+#pragma unroll
+                for (int i = 0; i < CH4; ++i) {
+                    mac_s_lo(acc[0], u[i], tr[2 * i]);
+                    mac_s_hi(acc[1], u[i], tr[2 * i]);
+                    mac_s_lo(acc[2], u[i], tr[2 * i + 1]);
+                    mac_s_hi(acc[3], u[i], tr[2 * i + 1]);
+                }
+            };
+            fetch4(0, 0, ua, ra);
+            for (int d = 0; d < a.nd; ++d) {
+#pragma unroll
+                for (int g = 0; g < NCH4; g += 2) {
+                    landed4(ua, ra);
+                    fetch4(d, g + 1, ub, rb);
+                    macs4(ua, ra);
+                    landed4(ub, rb);
+                    if (g + 2 < NCH4)
+                        fetch4(d, g + 2, ua, ra);
+                    else if (d + 1 < a.nd)
+                        fetch4(d + 1, 0, ua, ra);
+                    macs4(ub, rb);
+                }
+            }
+        } else {
         constexpr int CH = CHX ? CHX : OPL == 2 ? (R <= 10 ? R : R / 2) : (R <= 4 ? R : R % 4 == 0 ? R / 2 : R <= 6 ? R : R / 2);  // taps per chunk
         constexpr int NCH = PR / CH;
         static_assert(PR % CH == 0 && (NCH == 1 || NCH % 2 == 0), "chunks must pair up inside a block (or be whole blocks)");
@@ -318,6 +364,8 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
                     fetch(d + 1, 0, ua, ra, ia);
                 macs(g + 1, ub, rb, ib_);
             }
+        }
+
         }
 
         // ---- epilogue: mixer after the FIR, FM demod, stores
@@ -431,7 +479,7 @@ static comms_status_t launch_decim(const DecimArgs& a, bool real, int opl, int t
 #endif
     if (!real) return pre ? launch_decim_v<R, 2, false, true>(a, s) : launch_decim_v<R, 2, false, false>(a, s);
 #ifdef COMMS_DIAG
-    if constexpr (R <= 8) {
+    if constexpr (R <= 8 && R % 2 == 0) {
         if (opl == 4) return pre ? launch_decim_v<R, 4, true, true>(a, s) : launch_decim_v<R, 4, true, false>(a, s);
     }
 #else
@@ -489,7 +537,7 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
     COMMS_TRY(h->enter(stream, &s));
     const bool real = h->real_taps;
     const int R = static_cast<int>(rate), N = h->n_eff;
-    const int opl = R <= 8 ? decim_opl(real, (N + R - 1) / R) : 2;  // (the tap pairs of 4 outputs need R <= 8: SGPR budget)
+    const int opl = (R <= 8 && R % 2 == 0) ? decim_opl(real, (N + R - 1) / R) : 2;  // (four outputs per lane: even R up to 8)
     const int tile = decim_tile(real, R, opl);
     const int PR = opl * R, WG = tile / opl;
     DecimArgs a{};
@@ -525,6 +573,24 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
         a.step[m] = make_float2(static_cast<float>(c), static_cast<float>(sn));
     }
     COMMS_ARG(PR * (a.hlq + 1) + (opl - 1) * R + 4 <= DC_AMAX, "tap table overflow");
+    if (opl == 4) {  // tap quadruples Q[m][c] = A[m + R c], A[m] = h[m - (PR-1)]: built once per rate, device resident
+        if (h->qt_rate != R) {
+            const int rows = PR * (a.hlq + 1);
+            std::vector<float> q(static_cast<size_t>(rows) * 4, 0.f);
+            for (int m = 0; m < rows; ++m)
+                for (int c = 0; c < 4; ++c) {
+                    const int k = m + R * c - (PR - 1);
+                    if (k >= 0 && k < N) q[4 * m + c] = h->taps[k].re;
+                }
+            COMMS_TRY(h->quiesce());
+            if (h->d_qt) (void)hipFree(h->d_qt);
+            h->d_qt = nullptr;
+            COMMS_HIP_TRY(hipMalloc(&h->d_qt, q.size() * sizeof(float)));
+            COMMS_HIP_TRY(hipMemcpy(h->d_qt, q.data(), q.size() * sizeof(float), hipMemcpyHostToDevice));
+            h->qt_rate = R;
+        }
+        a.qt = h->d_qt;
+    }
     for (int m = 0; m < DC_AMAX; ++m) {
         const int k = m - (PR - 1);
         const bool in_range = k >= 0 && k < N;

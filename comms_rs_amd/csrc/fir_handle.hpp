@@ -94,6 +94,8 @@ struct comms_fir : comms::Handle {
     int in_fmt = 0;             // COMMS_IQ_C32 / _I16 / _U8: what d_in of the run entries points to
     float in_scale = 1.0f;      // i16 only
     comms::Scratch conv;        // converted copy, for the kernels that do not read wire formats themselves
+    float* d_qt = nullptr;      // decimating chain kernel, four outputs per lane: tap quadruples for rate qt_rate
+    int qt_rate = 0;
     // direct form
     int NP = 0;          // taps padded to a multiple of 8
     float2* d_taps_pad = nullptr;
