@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <thread>
 
 #include "../../comms_rs_amd/host/comms/nodes.hpp"
 
@@ -305,6 +306,61 @@ static void test_device_resident_stream_many_messages() {
     CHECK(comms_buf_pool_trim(0) == COMMS_OK);
 }
 
+static void test_device_resident_fan_out() {
+    // One producer, two consumers of the SAME buffers (NodeSender clones once per sender, node_derive/src/lib.rs:156
+    // = comms_buf_retain): FIR -> {mixer, decimate}.  Each consumer waits for the producer's event on its own stream
+    // and records its own use; a buffer's memory is recycled only after both launches -- while 120 more messages are
+    // in flight behind it.  Results equal the host-vector nodes bit for bit.
+    const size_t m = 1 << 16, k = 120;
+    auto taps = rrc_taps(63, 4.0, 0.25);
+    std::vector<C> x(m * k);
+    comms_synth_iq_host(c32(x.data()), x.size(), 0, 11);
+    BatchFirNode f(taps);
+    BatchMixerNode mx(0.3, 1.0);
+    DecimateNode<C> d(5);
+    std::vector<C> want_m, want_d;
+    std::vector<DeviceBuf<C>> msgs;
+    for (size_t i = 0; i < k; ++i) {
+        std::vector<C> part(x.begin() + i * m, x.begin() + (i + 1) * m);
+        msgs.push_back(DeviceBuf<C>::from_host(part));
+        auto y = f.run(part).value();
+        auto a = mx.run(y).value();
+        auto b = d.run(y).value();
+        want_m.insert(want_m.end(), a.begin(), a.end());
+        want_d.insert(want_d.end(), b.begin(), b.end());
+    }
+    Replay<DeviceBuf<C>> src(std::move(msgs));
+    BatchFirNodeDev fd(taps);
+    BatchMixerNodeDev md(0.3, 1.0);
+    DecimateNodeDev dd(5);
+    Collect<DeviceBuf<C>> cm, cd;
+    connect_nodes(src.output, fd.input);
+    connect_nodes(fd.output, md.input);
+    connect_nodes(fd.output, dd.input);   // second sender on the same output: every message is cloned
+    connect_nodes(md.output, cm.input);
+    connect_nodes(dd.output, cd.input);
+    start_nodes(std::move(src), std::move(fd), std::move(md), std::move(dd));
+    std::thread t([&] {
+        while (cd.call().is_ok()) {
+        }
+    });
+    while (cm.call().is_ok()) {
+    }
+    t.join();
+    CHECK(cm.got.size() == k && cd.got.size() == k);
+    std::vector<C> got_m, got_d;
+    for (auto& b : cm.got) {
+        auto v = b.to_host();
+        got_m.insert(got_m.end(), v.begin(), v.end());
+    }
+    for (auto& b : cd.got) {
+        auto v = b.to_host();
+        got_d.insert(got_d.end(), v.begin(), v.end());
+    }
+    CHECK(got_m == want_m);
+    CHECK(got_d == want_d);
+}
+
 static void test_device_resident_chain_and_fft() {
     // config 3 as a graph of device-resident messages: source -> fused chain (mixer, 127-tap LPF, /8,
     // FM demod) -> sink, against the four host-vector nodes in series; then FFT -> IFFT round trip
@@ -452,6 +508,7 @@ int main() {
     test_demod_nodes();
     test_device_resident_graph();
     test_device_resident_stream_many_messages();
+    test_device_resident_fan_out();
     test_device_resident_chain_and_fft();
     test_per_sample_nodes_keep_up();
     if (g_fail) {
