@@ -750,19 +750,10 @@ __global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(In in,
 
     size_t count = 0;
     cf v[16];
-    size_t seg = draw();
-    while (seg < hi) {
-        fetch(seg, v);
-        const size_t seg_next = draw();  // the ticket's LDS round trip hides behind the loads
-        os1024_core(v, lds, tw1, hsp, tw2, l, nostamp);
-        float2* o = out + seg * WVK + l;
-#pragma unroll
-        for (int a = HR; a < 16; ++a) o[64 * (a - HR)] = to_f2(v[R16_POS(a)]);
-        seg = seg_next;
-        ++count;
-    }
-
-    // the stream's first segment (halo from the history) and its partial last one: guarded
+    // The stream's first segment (halo from the history) and its partial last one, on a guarded path, by wave 0 of
+    // the first / last workgroup BEFORE it joins the ticket loop: the other fifteen waves simply draw more tickets
+    // meanwhile.  (Done after the loop, as it was, that wave worked alone for one more segment -- ~5 us at the
+    // single-wave rate -- while the rest of the chip had finished.)
     if (wave == 0) {
         const size_t nseg = (n + WVK - 1) / WVK;
         for (int e = 0; e < 2; ++e) {
@@ -785,6 +776,18 @@ __global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(In in,
             ++count;
         }
     }
+    size_t seg = draw();
+    while (seg < hi) {
+        fetch(seg, v);
+        const size_t seg_next = draw();  // the ticket's LDS round trip hides behind the loads
+        os1024_core(v, lds, tw1, hsp, tw2, l, nostamp);
+        float2* o = out + seg * WVK + l;
+#pragma unroll
+        for (int a = HR; a < 16; ++a) o[64 * (a - HR)] = to_f2(v[R16_POS(a)]);
+        seg = seg_next;
+        ++count;
+    }
+
     if (TRACE) trace.write(trace_buf, blockIdx.x * 16 + wave, l, count);
 }
 
