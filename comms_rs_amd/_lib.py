@@ -79,6 +79,15 @@ _PROTOS = {
     "comms_fir_get_state": [_vp, _vp, _sz],
     "comms_fir_set_state": [_vp, _vp, _sz],
     "comms_fir_destroy": [_vp],
+    "comms_fir_i16_create": [_vp, _sz, _vp, _sz, _i32, _pp],
+    "comms_fir_i16_run": [_vp, _vp, _sz, _vp],
+    "comms_fir_i16_run_dev": [_vp, _vp, _sz, _vp, _vp],
+    "comms_fir_i16_get_state": [_vp, _vp, _sz],
+    "comms_fir_i16_destroy": [_vp],
+    "comms_pulse_i16_create": [_vp, _sz, _sz, _i32, _pp],
+    "comms_pulse_i16_run": [_vp, _vp, _sz, _vp],
+    "comms_pulse_i16_run_dev": [_vp, _vp, _sz, _vp, _vp],
+    "comms_pulse_i16_destroy": [_vp],
     "comms_pulse_create": [_vp, _sz, _sz, _i32, _pp],
     "comms_pulse_run": [_vp, _vp, _sz, _vp],
     "comms_pulse_run_dev": [_vp, _vp, _sz, _vp, _vp],

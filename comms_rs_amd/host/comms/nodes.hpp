@@ -150,6 +150,100 @@ private:
     comms_fir_t* h_ = nullptr;
 };
 
+// ---------------------------------------------------------------- Complex<i16> instantiations
+// FirNode<i16> / BatchFirNode<i16> / PulseNode<i16>: the reference's nodes are generic over the sample type and its own
+// tests run on Complex<i16> (fir_node.rs:259-313, pulse.rs:129-183); wrapping arithmetic (comms_fir_i16_*).
+using Complex16 = std::complex<int16_t>;
+static_assert(sizeof(Complex16) == sizeof(comms_c16), "Complex<i16> must be interleaved {re, im}");
+inline const comms_c16* c16(const Complex16* p) { return reinterpret_cast<const comms_c16*>(p); }
+inline comms_c16* c16(Complex16* p) { return reinterpret_cast<comms_c16*>(p); }
+
+class BatchFirNodeI16 : public DeriveNode<BatchFirNodeI16> {
+public:
+    NodeReceiver<std::vector<Complex16>> input;
+    NodeSender<std::vector<Complex16>> output;
+    BatchFirNodeI16(const std::vector<Complex16>& taps, const std::optional<std::vector<Complex16>>& state = std::nullopt,
+                    int device = 0) {
+        throw_on(comms_fir_i16_create(c16(taps.data()), taps.size(), state ? c16(state->data()) : nullptr,
+                                      state ? state->size() : 0, device, &h_),
+                 "BatchFirNode<i16>::new");
+    }
+    BatchFirNodeI16(BatchFirNodeI16&& o) noexcept : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_) { o.h_ = nullptr; }
+    ~BatchFirNodeI16() { comms_fir_i16_destroy(h_); }
+    Result<std::vector<Complex16>> run(const std::vector<Complex16>& in) {
+        std::vector<Complex16> out(in.size());
+        comms_status_t st = comms_fir_i16_run(h_, c16(in.data()), in.size(), c16(out.data()));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_fir_i16_t* h_ = nullptr;
+};
+
+class FirNodeI16 : public DeriveNode<FirNodeI16> {
+public:
+    NodeReceiver<Complex16> input;
+    NodeSender<Complex16> output;
+    FirNodeI16(const std::vector<Complex16>& taps, const std::optional<std::vector<Complex16>>& state = std::nullopt, int device = 0) {
+        throw_on(comms_fir_i16_create(c16(taps.data()), taps.size(), state ? c16(state->data()) : nullptr,
+                                      state ? state->size() : 0, device, &h_),
+                 "FirNode<i16>::new");
+    }
+    FirNodeI16(FirNodeI16&& o) noexcept : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_) { o.h_ = nullptr; }
+    ~FirNodeI16() { comms_fir_i16_destroy(h_); }
+    Result<Complex16> run(const Complex16& in) {
+        Complex16 out;
+        comms_status_t st = comms_fir_i16_run(h_, c16(&in), 1, c16(&out));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    Result<std::vector<Complex16>> run_block(const std::vector<Complex16>& ins) {  // queued samples in one launch
+        std::vector<Complex16> out(ins.size());
+        comms_status_t st = comms_fir_i16_run(h_, c16(ins.data()), ins.size(), c16(out.data()));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_fir_i16_t* h_ = nullptr;
+};
+
+class PulseNodeI16 : public DeriveNode<PulseNodeI16> {
+public:
+    NodeReceiver<Complex16> input;
+    NodeSender<std::vector<Complex16>> output;
+    PulseNodeI16(const std::vector<Complex16>& taps, size_t sam_per_sym, int device = 0) : sps_(sam_per_sym) {
+        throw_on(comms_pulse_i16_create(c16(taps.data()), taps.size(), sam_per_sym, device, &h_), "PulseNode<i16>::new");
+    }
+    PulseNodeI16(PulseNodeI16&& o) noexcept : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), sps_(o.sps_) { o.h_ = nullptr; }
+    ~PulseNodeI16() { comms_pulse_i16_destroy(h_); }
+    Result<std::vector<Complex16>> run(const Complex16& sym) {
+        std::vector<Complex16> out(sps_);
+        comms_status_t st = comms_pulse_i16_run(h_, c16(&sym), 1, c16(out.data()));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    Result<std::vector<std::vector<Complex16>>> run_block(const std::vector<Complex16>& syms) {
+        std::vector<Complex16> flat(syms.size() * sps_);
+        comms_status_t st = comms_pulse_i16_run(h_, c16(syms.data()), syms.size(), c16(flat.data()));
+        if (st != COMMS_OK) return to_node_error(st);
+        std::vector<std::vector<Complex16>> out(syms.size());
+        for (size_t i = 0; i < syms.size(); ++i) out[i].assign(flat.begin() + i * sps_, flat.begin() + (i + 1) * sps_);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_pulse_i16_t* h_ = nullptr;
+    size_t sps_;
+};
+
 // ---------------------------------------------------------------- pulse shaping
 class PulseNode : public DeriveNode<PulseNode> {
 public:

@@ -216,6 +216,65 @@ class PulseNode(_Handle):
         check(lib().comms_pulse_run_dev(self._h, sym_ptr, n_sym, out_ptr, stream))
 
 
+# ------------------------------------------------------------------ Complex<i16> instantiations
+def _as_c16(a):
+    a = np.ascontiguousarray(a, dtype=np.int16)
+    return a.reshape(-1, 2)
+
+
+class BatchFirNodeI16(_Handle):
+    """BatchFirNode<i16>::new(taps, state) / run (fir_node.rs:193-220) on Complex<i16> = int16 (n, 2) arrays,
+    wrapping arithmetic.  A single sample (shape (2,)) in gives a single sample out: FirNode<i16>."""
+    _destroy = "comms_fir_i16_destroy"
+
+    def __init__(self, taps, state=None, device=0):
+        super().__init__()
+        taps = _as_c16(taps)
+        if state is None:
+            check(lib().comms_fir_i16_create(_ptr(taps), taps.shape[0], None, 0, device, C.byref(self._h)))
+        else:
+            state = _as_c16(state)
+            check(lib().comms_fir_i16_create(_ptr(taps), taps.shape[0], _ptr(state), state.shape[0], device, C.byref(self._h)))
+
+    def run(self, x):
+        single = np.ndim(x) == 1 and np.size(x) == 2
+        x = _as_c16(x)
+        out = np.empty_like(x)
+        check(lib().comms_fir_i16_run(self._h, _ptr(x), x.shape[0], _ptr(out)))
+        return out[0] if single else out
+
+    def run_dev(self, in_ptr, n, out_ptr, stream=0):
+        check(lib().comms_fir_i16_run_dev(self._h, in_ptr, n, out_ptr, stream))
+
+    def state(self, n_state):
+        st = np.empty((int(n_state), 2), np.int16)
+        check(lib().comms_fir_i16_get_state(self._h, _ptr(st), int(n_state)))
+        return st
+
+
+FirNodeI16 = BatchFirNodeI16
+
+
+class PulseNodeI16(_Handle):
+    """PulseNode<i16>::new(taps, sam_per_sym) / run (pulse.rs:71-92) on Complex<i16>."""
+    _destroy = "comms_pulse_i16_destroy"
+
+    def __init__(self, taps, sam_per_sym, device=0):
+        super().__init__()
+        taps = _as_c16(taps)
+        self.sam_per_sym = int(sam_per_sym)
+        check(lib().comms_pulse_i16_create(_ptr(taps), taps.shape[0], self.sam_per_sym, device, C.byref(self._h)))
+
+    def run(self, sym):
+        s = _as_c16(sym)
+        out = np.empty((s.shape[0] * self.sam_per_sym, 2), np.int16)
+        check(lib().comms_pulse_i16_run(self._h, _ptr(s), s.shape[0], _ptr(out)))
+        return out
+
+    def run_dev(self, sym_ptr, n_sym, out_ptr, stream=0):
+        check(lib().comms_pulse_i16_run_dev(self._h, sym_ptr, n_sym, out_ptr, stream))
+
+
 # ------------------------------------------------------------------ mixer
 class MixerNode(_Handle):
     """MixerNode::new(dphase, phase) (mixer.rs:128-141); run() mixes a slice."""
