@@ -98,6 +98,31 @@ impl BatchFirNode {
     }
 }
 
+/// BatchFirNode<i16>: the reference's node instantiated on the sample type of its own tests (fir_node.rs:342-449);
+/// wrapping i16 arithmetic as in a release build.
+#[derive(Node)]
+#[pass_by_ref]
+pub struct BatchFirNodeI16 {
+    pub input: NodeReceiver<Vec<Complex<i16>>>,
+    h: *mut comms_fir_i16_t,
+    pub output: NodeSender<Vec<Complex<i16>>>,
+}
+handle_node!(BatchFirNodeI16, comms_fir_i16_t, comms_fir_i16_destroy);
+impl BatchFirNodeI16 {
+    pub fn new(taps: Vec<Complex<i16>>, state: Option<Vec<Complex<i16>>>) -> Self {
+        let mut h = ptr::null_mut();
+        let (sp, sn) = match &state { Some(s) => (s.as_ptr(), s.len()), None => (ptr::null(), 0) };
+        let st = unsafe { comms_fir_i16_create(taps.as_ptr(), taps.len(), sp, sn, 0, &mut h) };
+        assert_eq!(st, COMMS_OK, "comms_fir_i16_create failed");
+        BatchFirNodeI16 { input: Default::default(), h, output: Default::default() }
+    }
+    pub fn run(&mut self, input: &[Complex<i16>]) -> Result<Vec<Complex<i16>>, NodeError> {
+        let mut out = vec![Complex::new(0i16, 0); input.len()];
+        let st = unsafe { comms_fir_i16_run(self.h, input.as_ptr(), input.len(), out.as_mut_ptr()) };
+        if st == COMMS_OK { Ok(out) } else { Err(to_err(st)) }
+    }
+}
+
 /// fir_node.rs:45-114 (one sample per message; queued samples run as one launch, see `drained_node!`)
 pub struct FirNode {
     pub input: NodeReceiver<Complex<f32>>,
