@@ -671,8 +671,8 @@ def run_config4(ctx):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)   # 0.12 s of timed region at config 2: long enough for an outside
+    ap.add_argument("--warmup", type=int, default=50)    # utilisation sampler to see; the whole default run stays ~10 s
     ap.add_argument("--config", type=int, choices=[2, 3, 4, 5], default=2)
     ap.add_argument("--variant", choices=["inplace", "scatter"], default="inplace")
     ap.add_argument("--stream-log2", type=int, default=30,
@@ -683,7 +683,7 @@ def main():
     # rehearsal aid: "gloo" runs the N>1 logic with CPU-side messages, ranks sharing the visible GPUs
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     args = ap.parse_args()
-    if args.config != 2 and args.steps == 200:
+    if args.config != 2 and args.steps == 1000 and args.warmup == 50:
         args.steps, args.warmup = 20, 3   # the other configs' steps are 10-100x longer
 
     ctx = Ctx(args)
