@@ -15,7 +15,9 @@ __global__ __launch_bounds__(256) void probe_copy_kernel(const V* __restrict__ i
 
 // mode 2: the os1024 access pattern without the math: a wave owns a run of 768-sample
 // tiles; per tile 12 x (64 lanes x 8 B) loads, then 12 x 512-B stores.
-template <int TPL>
+typedef float nt_f2 __attribute__((ext_vector_type(2)));
+// NT bit 0: nontemporal loads, bit 1: nontemporal stores (modes 6 / 7 / 8)
+template <int TPL, int NT = 0>
 __global__ __launch_bounds__(256) void probe_tile_kernel(const float2* __restrict__ in, float2* __restrict__ out,
                                                          size_t ntiles, size_t n_runs) {
     const int l = threadIdx.x & 63;
@@ -23,6 +25,37 @@ __global__ __launch_bounds__(256) void probe_tile_kernel(const float2* __restric
     if (run >= n_runs) return;
     const size_t t0 = run * ntiles / n_runs, t1 = (run + 1) * ntiles / n_runs;
     for (size_t t = t0; t < t1; ++t) {
+        float2 v[TPL];
+        const size_t base = t * (64 * TPL);
+#pragma unroll
+        for (int a = 0; a < TPL; ++a) {
+            if (NT & 1) {
+                const nt_f2 q = __builtin_nontemporal_load(reinterpret_cast<const nt_f2*>(&in[base + 64 * a + l]));
+                v[a] = make_float2(q.x, q.y);
+            }
+            else v[a] = in[base + 64 * a + l];
+        }
+#pragma unroll
+        for (int a = 0; a < TPL; ++a) {
+            if (NT & 2) {
+                nt_f2 q;
+                q.x = v[a].x;
+                q.y = v[a].y;
+                __builtin_nontemporal_store(q, reinterpret_cast<nt_f2*>(&out[base + 64 * a + l]));
+            }
+            else out[base + 64 * a + l] = v[a];
+        }
+    }
+}
+
+// modes 100 + K: tiles of K x 512 B dealt round-robin over the waves (wave g: tiles g, g + W, ...) instead of a
+// contiguous run of tiles per wave
+template <int TPL>
+__global__ __launch_bounds__(256) void probe_tile_rr_kernel(const float2* __restrict__ in, float2* __restrict__ out,
+                                                            size_t ntiles, size_t n_waves) {
+    const int l = threadIdx.x & 63;
+    const size_t g = static_cast<size_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    for (size_t t = g; t < ntiles; t += n_waves) {
         float2 v[TPL];
         const size_t base = t * (64 * TPL);
 #pragma unroll
@@ -104,6 +137,28 @@ extern "C" comms_status_t comms_debug_copy(const void* d_in, void* d_out, size_t
     } else if (mode == 2) {
         const size_t ntiles = n_c32 / 768, runs = static_cast<size_t>(waves_per_cu) * kNumCU;
         probe_tile_kernel<12><<<dim3((runs + 3) / 4), dim3(256), 0, s>>>(static_cast<const float2*>(d_in), static_cast<float2*>(d_out), ntiles, runs);
+    } else if (mode >= 100) {
+        const int K = mode - 100;
+        const size_t n_waves = static_cast<size_t>(waves_per_cu) * kNumCU, ntiles = n_c32 / (64 * static_cast<size_t>(K));
+        const dim3 g(static_cast<unsigned>(n_waves / 4)), b(256);
+        const float2* in = static_cast<const float2*>(d_in);
+        float2* out = static_cast<float2*>(d_out);
+        switch (K) {
+            case 1: probe_tile_rr_kernel<1><<<g, b, 0, s>>>(in, out, ntiles, n_waves); break;
+            case 2: probe_tile_rr_kernel<2><<<g, b, 0, s>>>(in, out, ntiles, n_waves); break;
+            case 4: probe_tile_rr_kernel<4><<<g, b, 0, s>>>(in, out, ntiles, n_waves); break;
+            case 12: probe_tile_rr_kernel<12><<<g, b, 0, s>>>(in, out, ntiles, n_waves); break;
+            case 16: probe_tile_rr_kernel<16><<<g, b, 0, s>>>(in, out, ntiles, n_waves); break;
+            default: return COMMS_ERR_ARG;
+        }
+    } else if (mode >= 6 && mode <= 8) {
+        const size_t ntiles = n_c32 / 768, runs = static_cast<size_t>(waves_per_cu) * kNumCU;
+        const dim3 g((runs + 3) / 4), b(256);
+        const float2* in = static_cast<const float2*>(d_in);
+        float2* out = static_cast<float2*>(d_out);
+        if (mode == 6) probe_tile_kernel<12, 1><<<g, b, 0, s>>>(in, out, ntiles, runs);
+        else if (mode == 7) probe_tile_kernel<12, 2><<<g, b, 0, s>>>(in, out, ntiles, runs);
+        else probe_tile_kernel<12, 3><<<g, b, 0, s>>>(in, out, ntiles, runs);
     } else if (mode == 4 || mode == 5) {
         const size_t n_tiles = (n_c32 >> 20) * 64;  // 64 tiles of 16 transforms per 2^20-point matrix
         const unsigned blocks = static_cast<unsigned>(waves_per_cu > 0 ? waves_per_cu : kNumCU);

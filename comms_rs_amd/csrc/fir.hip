@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, WPS) void fir_os4096_kernel(const float2* __re
                                                             int hist_len, float2* __restrict__ out,
                                                             size_t n, int hblk, size_t nseg,
                                                             OsTables tb, float2* __restrict__ new_hist,
-                                                            int delay, int accumulate) {
+                                                            int delay, int accumulate, int interleave) {
     __shared__ __attribute__((aligned(16))) cf lds[OS_LDS + 256];
     const int t = threadIdx.x;
     if (!accumulate) hist_advance(hist, in, n, new_hist, hist_len);  // once per call (first partition)
@@ -209,9 +209,11 @@ __global__ __launch_bounds__(256, WPS) void fir_os4096_kernel(const float2* __re
     cf v[16];
 
     // workgroup b of the persistent grid owns segments [b*nseg/G, (b+1)*nseg/G)
-    const size_t seg_lo = static_cast<size_t>(blockIdx.x) * nseg / gridDim.x;
-    const size_t seg_hi = static_cast<size_t>(blockIdx.x + 1) * nseg / gridDim.x;
-    for (size_t seg = seg_lo; seg < seg_hi; ++seg) {
+    // (interleave: segments b, b + G, ... instead -- segments are independent, every one loads its own halo)
+    const size_t seg_lo = interleave ? blockIdx.x : static_cast<size_t>(blockIdx.x) * nseg / gridDim.x;
+    const size_t seg_hi = interleave ? nseg : static_cast<size_t>(blockIdx.x + 1) * nseg / gridDim.x;
+    const size_t seg_step = interleave ? gridDim.x : 1;
+    for (size_t seg = seg_lo; seg < seg_hi; seg += seg_step) {
         // partition p of a long filter sees the stream delayed by p*2049 samples
         const long long base = static_cast<long long>(seg) * V - H - delay;
         // ---- forward stage 1: lane (b,c) = t holds x[256a + t]; DFT over a -> k0
@@ -1614,8 +1616,11 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
         COMMS_TRY(fir_prepare_os(h));
         const size_t V = OSF - 256 * static_cast<size_t>(h->hblk);
         const size_t nseg = (n + V - 1) / V;
-        // persistent grid: WPS workgroups per CU (one wave of each per SIMD), segments split evenly
+        // persistent grid: WPS workgroups per CU (one wave of each per SIMD), segments dealt round-robin
         static const int wps = tune_int("COMMS_OS4096_WPS", 3);
+        // segments b, b + G, ... per workgroup (the chip sweeps the stream as one window: 2-4 % faster at 2^24 ...
+        // 2^26 than a contiguous run per workgroup, 1 % at 2^28); 0 restores the runs
+        static const int il = tune_int("COMMS_OS4096_INTERLEAVE", 1);
         const size_t slots = static_cast<size_t>(wps) * kNumCU;
         const unsigned blocks = static_cast<unsigned>(nseg < slots ? nseg : slots);
         h->tic(s);
@@ -1623,11 +1628,11 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
             OsTables tb{reinterpret_cast<const cf*>(h->d_tw1), reinterpret_cast<const cf*>(h->d_tw2),
                         reinterpret_cast<const cf*>(h->d_hparts[pt])};
             if (wps == 4)
-                fir_os4096_kernel<4><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, pt * OS_PART, pt ? 1 : 0);
+                fir_os4096_kernel<4><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, pt * OS_PART, pt ? 1 : 0, il);
             else if (wps == 3)
-                fir_os4096_kernel<3><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, pt * OS_PART, pt ? 1 : 0);
+                fir_os4096_kernel<3><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, pt * OS_PART, pt ? 1 : 0, il);
             else
-                fir_os4096_kernel<2><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, pt * OS_PART, pt ? 1 : 0);
+                fir_os4096_kernel<2><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, pt * OS_PART, pt ? 1 : 0, il);
         }
         h->toc(s);
         COMMS_TRY(launch_ok("fir_os4096_kernel"));

@@ -60,6 +60,7 @@ struct DecimArgs {
     const float2* fm_prev;
     float2* fm_prev_new;
     size_t n, n_out, n_tiles;
+    int interleave;  // tile t of workgroup b: b + i gridDim.x instead of a contiguous run
     int hist_len, hlq, nd, mode;   // hlq = ceil((N-1)/PR); nd = hlq + 1 tap blocks of PR
     int fmt;                       // COMMS_IQ_*
     float in_scale;
@@ -141,8 +142,11 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
     const long long ts = TILE - ovl;      // stored outputs per tile
     const int hl = a.hlq * PR;            // halo samples staged to the left of the tile
 
-    const size_t t0 = static_cast<size_t>(blockIdx.x) * a.n_tiles / gridDim.x;
-    const size_t t1 = static_cast<size_t>(blockIdx.x + 1) * a.n_tiles / gridDim.x;
+    // tiles of a workgroup: a contiguous run, or (a.interleave) every gridDim.x-th tile, so that the chip
+    // sweeps the stream as one window
+    const size_t t0 = a.interleave ? blockIdx.x : static_cast<size_t>(blockIdx.x) * a.n_tiles / gridDim.x;
+    const size_t t1 = a.interleave ? a.n_tiles : static_cast<size_t>(blockIdx.x + 1) * a.n_tiles / gridDim.x;
+    const size_t tstep = a.interleave ? gridDim.x : 1;
     if (t0 >= t1) return;
 
     // Mixer rotors.  The phase of input sample i = ib + tid + WG m of a tile splits into a part
@@ -153,6 +157,8 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
     constexpr int NROW = PRE ? PR : 1;
     cf lrow[NROW], lhalo[HROWS];
     double tt_c = 1.0, tt_s = 0.0, ro_c = 1.0, ro_s = 0.0;
+    double tile_c = a.tile_c, tile_s = a.tile_s;  // rotor of one step of this workgroup's tile sequence
+    if (a.interleave && (pre || post)) rotor_at(static_cast<uint64_t>(R * ts) * tstep * a.frac, tile_c, tile_s);
     {
         const long long jb0 = static_cast<long long>(t0) * ts - ovl;
         if (pre) {
@@ -227,7 +233,7 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
     }
     if (a.stamps) st_prev = __builtin_amdgcn_s_memtime();
 
-    for (size_t t = t0; t < t1; ++t) {
+    for (size_t t = t0; t < t1; t += tstep) {
         const long long jb = static_cast<long long>(t) * ts - ovl;  // first output computed by this tile
         // ---- stage the tile: PR rows of new samples, then the halo
         load_tile(t);
@@ -377,13 +383,13 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
             const cf tt = cf{static_cast<float>(tt_c), static_cast<float>(tt_s)};
 #pragma unroll
             for (int c = 0; c < OPL; ++c) y[c] = to_f2(cmulf(acc[c], tt));
-            rotor_step(tt_c, tt_s, a.tile_c, a.tile_s);
+            rotor_step(tt_c, tt_s, tile_c, tile_s);
         }
         if (post) {
             const cf ro = cf{static_cast<float>(ro_c), static_cast<float>(ro_s)};
 #pragma unroll
             for (int c = 0; c < OPL; ++c) y[c] = to_f2(cmulf(acc[c], c ? cmulf(ro, to_cf(a.step_r[c])) : ro));
-            rotor_step(ro_c, ro_s, a.tile_c, a.tile_s);
+            rotor_step(ro_c, ro_s, tile_c, tile_s);
         }
         const long long j0 = jb + OPL * tid;
         if (fm) {
@@ -420,7 +426,7 @@ template <int R, int OPL, bool REAL, bool PRE, int TILE = DC_TILE, int CHX = 0>
 static comms_status_t launch_decim_v(const DecimArgs& a, hipStream_t s) {
     using G = DcGeom<R, OPL, TILE>;
     constexpr size_t lds = G::LDS;
-    // persistent grid: every workgroup slot of the chip gets a contiguous run of tiles
+    // persistent grid: one workgroup per slot of the chip; tile b, b + slots, ... (or a contiguous run) each
     const size_t slots = static_cast<size_t>(G::WGPC) * kNumCU;
     const unsigned blocks = static_cast<unsigned>(a.n_tiles < slots ? a.n_tiles : slots);
     static DeviceOnce attr_once;
@@ -562,6 +568,10 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
     a.frac = frac;
     a.stamps = g_decim_stamps;
     if (getenv("COMMS_DECIM_DEBUG_NOMAC")) a.nd = 0;  // diagnostic: staging + epilogue only
+    // tile order: interleaved over the workgroups by default (config 3 at 2^26: 145 -> 142 us per step, neutral
+    // at 2^24); COMMS_DECIM_INTERLEAVE=0 gives every workgroup a contiguous run again
+    static const int interleave = [] { const char* v = getenv("COMMS_DECIM_INTERLEAVE"); return v && *v ? atoi(v) : 1; }();
+    a.interleave = interleave;
     mix_host_rotor(static_cast<uint64_t>(R) * ts * frac, a.tile_c, a.tile_s);
     double c, sn;
     for (int k = 0; k < opl; ++k) {
