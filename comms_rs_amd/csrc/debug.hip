@@ -13,6 +13,13 @@ __global__ __launch_bounds__(256) void probe_copy_kernel(const V* __restrict__ i
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i];
 }
 
+// modes 9 / 10: pure fill (no reads) with 8 / 16 bytes per lane -- what a write-only kernel (upsample's zeros) can reach
+template <typename V>
+__global__ __launch_bounds__(256) void probe_fill_kernel(V* __restrict__ out, size_t n, V val) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = val;
+}
+
 // mode 2: the os1024 access pattern without the math: a wave owns a run of 768-sample
 // tiles; per tile 12 x (64 lanes x 8 B) loads, then 12 x 512-B stores.
 typedef float nt_f2 __attribute__((ext_vector_type(2)));
@@ -137,6 +144,10 @@ extern "C" comms_status_t comms_debug_copy(const void* d_in, void* d_out, size_t
     } else if (mode == 2) {
         const size_t ntiles = n_c32 / 768, runs = static_cast<size_t>(waves_per_cu) * kNumCU;
         probe_tile_kernel<12><<<dim3((runs + 3) / 4), dim3(256), 0, s>>>(static_cast<const float2*>(d_in), static_cast<float2*>(d_out), ntiles, runs);
+    } else if (mode == 9) {
+        probe_fill_kernel<float2><<<dim3(8 * kNumCU), dim3(256), 0, s>>>(static_cast<float2*>(d_out), n_c32, make_float2(1.f, 2.f));
+    } else if (mode == 10) {
+        probe_fill_kernel<float4><<<dim3(8 * kNumCU), dim3(256), 0, s>>>(static_cast<float4*>(d_out), n_c32 / 2, make_float4(1.f, 2.f, 3.f, 4.f));
     } else if (mode >= 100) {
         const int K = mode - 100;
         const size_t n_waves = static_cast<size_t>(waves_per_cu) * kNumCU, ntiles = n_c32 / (64 * static_cast<size_t>(K));

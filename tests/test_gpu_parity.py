@@ -446,6 +446,32 @@ def test_resample_vs_oracle_bit_exact(c, dtype, rate):
             assert got.tobytes() == oracle.upsample(x, rate).tobytes()
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.int16, np.float32, np.complex64, np.complex128])
+def test_upsample_device_pointers_alignment_and_rates(c, dtype):
+    """Both upsample kernels (16 output bytes per lane when the output is 16-byte aligned, one element per lane
+    otherwise) against the oracle, at rates beyond the host-path test and output lengths that end in a partial
+    16-byte chunk.  resample_node.rs:120-131 -- bit-exact."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    item = np.dtype(dtype).itemsize
+    s = torch.cuda.current_stream().cuda_stream
+    for rate in (2, 3, 4, 5, 7, 16, 100):
+        for n in (1, 33, 4097, 100003):
+            x = rng.integers(0, 256, n * item, dtype=np.uint8).view(dtype)
+            want = oracle.upsample(x, rate).tobytes()
+            d_in = torch.from_numpy(x.view(np.uint8).copy()).cuda()
+            for shift in (0, item):  # item: an output pointer that is aligned to the element only (for elements < 16 bytes)
+                d_out = torch.full((n * rate * item + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+                m = c.UpsampleNode(rate).run_dev(d_in.data_ptr(), n, item, d_out.data_ptr() + 16 + shift, s)
+                torch.cuda.synchronize()
+                assert m == n * rate
+                got = d_out.cpu().numpy()
+                assert got[16 + shift:16 + shift + n * rate * item].tobytes() == want, (rate, n, shift)
+                # nothing written outside the output range
+                assert (got[:16 + shift] == 0xA5).all() and (got[16 + shift + n * rate * item:] == 0xA5).all()
+
+
 def test_resample_bad_elem(c):
     with pytest.raises(c.CommsError) as e:
         c.DecimateNode(2).run(np.zeros((4, 3), np.uint8))  # 3-byte element
