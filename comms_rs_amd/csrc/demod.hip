@@ -35,7 +35,7 @@ constexpr double kPi = 3.14159265358979323846264338327950288;
 
 // ---------------------------------------------------------------- timing estimator
 constexpr int TE_WG = 256;                  // lanes per workgroup
-constexpr int TE_OPL = 4;                   // consecutive outputs per lane
+constexpr int TE_OPL = 8;                   // consecutive outputs per lane
 constexpr int TE_TILE = TE_WG * TE_OPL;     // outputs per tile
 constexpr int TE_QMAX = 1020;               // q(t) taps one pass stages (a multiple of 12; 2*n*d + 1 taps in all: longer filters take several passes)
 
@@ -76,68 +76,51 @@ __device__ __forceinline__ double2 te_rotor(long long i, double n_sps) {
     return make_double2(c, s);
 }
 
-// LDS image of the mixed window: element e at e + (e >> 2) -- one pad slot per four elements, so that lanes
-// reading at a stride of four elements (their OPL consecutive outputs) spread over all the banks
-__device__ __forceinline__ int te_slot(int e) { return e + (e >> 2); }
+// LDS image of the mixed window: element e at e + (e >> 3) -- one pad slot per eight elements, so that lanes
+// reading at a stride of eight elements (their OPL consecutive outputs; 144 bytes apart) spread over all the banks
+__device__ __forceinline__ int te_slot(int e) { return e + (e >> 3); }
 
-// A 256-lane workgroup owns 1024 consecutive outputs, four per lane.  The mixed window (qin) of the tile and
-// the delayed mixed samples (din) are staged in LDS once -- one rotor per staged sample serves both -- and the
-// q(t) filter slides a four-element register window over the LDS image: one 16-byte LDS read feeds the taps of
-// all four outputs (4 complex x real MACs = 8 f64 FMAs), the taps themselves arrive by scalar loads.  Taps are
-// walked in the reference's order (k ascending); the MACs are fused (the reference's are not: the estimate
-// moves by < 1e-12, the parity tests allow 1e-9).
+// A 256-lane workgroup owns 2048 consecutive outputs, eight per lane.  The mixed window (qin) of the tile is staged
+// in LDS once and the q(t) filter slides a register window over the LDS image: one 16-byte LDS read feeds a tap of
+// all eight outputs (8 complex x real MACs = 16 f64 FMAs; four outputs per lane, 8 FMAs per read, kept the LDS as
+// busy as the FP64 pipe: 281 us at 2^24 samples), the taps themselves arrive by scalar loads.  Taps are walked in
+// the reference's order (k ascending); the MACs are fused (the reference's are not: the estimate moves by < 1e-12,
+// the parity tests allow 1e-9).  The delayed sample din[i] = x[i - nd] r[i - nd] of the final product is formed
+// from memory again (the tile's samples are still in L2) -- 16 LDS bytes per output less, which is what lets
+// four such workgroups share a CU.
 __global__ __launch_bounds__(TE_WG, 4) void timing_kernel(const double2* __restrict__ x, size_t len,
                                                        const double* __restrict__ qtaps, uint32_t n_q, uint32_t k_lo,
-                                                       uint32_t nd, double n_sps, int with_delay,
+                                                       uint32_t nd, double n_sps, double2 w_wg, double2 w_1, int with_delay,
                                                        double2* __restrict__ qacc, double2* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) char te_smem[];
     double2* sh_q = reinterpret_cast<double2*>(te_smem);                       // window, padded image
     const int nk = static_cast<int>(n_q);                                      // taps of this pass
-    const int win = TE_TILE + nk - 1;                                          // (+ 1 element staged past it: position -4 of the last lane)
-    double2* sh_d = sh_q + te_slot(win + 1) + 1;                               // din of the tile's outputs
+    const int win = TE_TILE + nk - 1;                                          // (+ 2 elements staged past it: positions -8 .. -1 of the last lane)
     __shared__ double2 wsum[TE_WG / 64];
     const int tid = threadIdx.x;
     const size_t ntiles = (len + TE_TILE - 1) / TE_TILE;
     double2 total = make_double2(0.0, 0.0);
-    // the usual case (one pass, delay n*d inside the filter's reach): the window already holds every sample din needs
-    const bool din_in_window = with_delay && k_lo == 0 && static_cast<int>(nd) <= nk - 1;
     for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long i0 = static_cast<long long>(tile) * TE_TILE;
         __syncthreads();
-        // ---- stage qin over [i0 - k_lo - (nk - 1), i0 - k_lo + TILE) and din over [i0 - nd, i0 - nd + TILE)
+        // ---- stage qin over [i0 - k_lo - (nk - 1), i0 - k_lo + TILE]
         const long long w0 = i0 - static_cast<long long>(k_lo) - (nk - 1);
-        for (int j = tid; j <= win; j += TE_WG) {
+        // (one sincos per lane and tile: the lane's further elements sit TE_WG samples apart, their rotor is the
+        // previous one times w_wg = e^{-i pi TE_WG / n}; a sincos + f64 division per element cost as much as the filter)
+        double2 r = te_rotor(w0 + tid, n_sps);
+        for (int j = tid; j <= win + 1; j += TE_WG) {
             const long long idx = w0 + j;
             double2 v = make_double2(0.0, 0.0);
             if (idx >= 0 && idx < static_cast<long long>(len)) {
                 const double2 sm = x[idx];
-                const double2 r = te_rotor(idx, n_sps);
                 const double ci = -sm.y;  // conj
                 v = make_double2(sm.x * r.x - ci * r.y, sm.x * r.y + ci * r.x);
-                if (din_in_window) {  // the delayed sample of some output of this tile: same rotor, no conjugate
-                    const long long dj = idx - (i0 - static_cast<long long>(nd));
-                    if (dj >= 0 && dj < TE_TILE) sh_d[dj] = make_double2(sm.x * r.x - sm.y * r.y, sm.x * r.y + sm.y * r.x);
-                }
-            } else if (din_in_window) {
-                const long long dj = idx - (i0 - static_cast<long long>(nd));
-                if (dj >= 0 && dj < TE_TILE) sh_d[dj] = make_double2(0.0, 0.0);
             }
             sh_q[te_slot(j)] = v;
-        }
-        if (with_delay && !din_in_window) {
-            for (int j = tid; j < TE_TILE; j += TE_WG) {
-                const long long idx = i0 - static_cast<long long>(nd) + j;
-                double2 v = make_double2(0.0, 0.0);
-                if (idx >= 0 && idx < static_cast<long long>(len)) {
-                    const double2 sm = x[idx];
-                    const double2 r = te_rotor(idx, n_sps);
-                    v = make_double2(sm.x * r.x - sm.y * r.y, sm.x * r.y + sm.y * r.x);
-                }
-                sh_d[j] = v;
-            }
+            r = make_double2(r.x * w_wg.x - r.y * w_wg.y, r.x * w_wg.y + r.y * w_wg.x);
         }
         __syncthreads();
-        // ---- q_c = sum_k t[k] v[n_c - k],  n_c = i0 + 4 tid + c:  window element of (c, k) is e0 + c - k
+        // ---- q_c = sum_k t[k] v[n_c - k],  n_c = i0 + 8 tid + c:  window element of (c, k) is e0 + c - k
         const int e0 = (nk - 1) + TE_OPL * tid;
         double2 q[TE_OPL];
         if (qacc && k_lo) {
@@ -151,50 +134,65 @@ __global__ __launch_bounds__(TE_WG, 4) void timing_kernel(const double2* __restr
             for (int c = 0; c < TE_OPL; ++c) q[c] = make_double2(0.0, 0.0);
         }
         // Window positions p = e0 - e grow with k: tap k of output c reads position k - c.  Positions live in
-        // register blocks of four; the taps of block b (k = 4b .. 4b + 3) touch blocks b - 1 and b.  Three
-        // blocks per loop iteration rotate through three register sets (R0, R1), (R1, R2), (R2, R0), so no
-        // value is ever moved between registers.  (The host pads the taps with zeros to a multiple of 12.)
-        auto load_block = [&](int blk, double2 (&R)[4]) {
+        // register blocks of four; the taps of block b (k = 4b .. 4b + 3) touch blocks b - 2, b - 1 and b.  Three
+        // blocks per loop iteration rotate through three register sets (R0, R1, R2), (R1, R2, R0), (R2, R0, R1),
+        // so no value is ever moved between registers.  (The host pads the taps with zeros to a multiple of 12.)
+        // Block b holds the elements e0 - 4b - m, m < 4 (0 <= e <= win + 1: nk is a multiple of 12, the image holds
+        // win + 2 elements).  e0 + 8 is 3 or 7 modulo 8 in every lane, so a block never straddles a pad slot and the
+        // blocks' lowest slots lie alternately 4 and 5 slots apart: one subtraction of a wave-uniform step per block
+        // instead of a padded-index computation per read.
+        int blk_addr = (te_slot(e0 + 8) - 3) * static_cast<int>(sizeof(double2));  // block -2
+        int blk_step = ((nk - 1) & 7) == 7 ? 4 * static_cast<int>(sizeof(double2)) : 5 * static_cast<int>(sizeof(double2));
+        auto load_block = [&](int, double2 (&R)[4]) {  // called for blocks -2, -1, 0, 1, ... in this order
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                R[m] = sh_q[te_slot(e0 - (4 * blk + m))];  // 0 <= e <= win: nk is a multiple of 12, the image holds win + 1 elements
-            }
+            for (int m = 0; m < 4; ++m)
+                R[m] = *reinterpret_cast<const double2*>(te_smem + blk_addr + (3 - m) * static_cast<int>(sizeof(double2)));
+            blk_addr -= blk_step;
+            blk_step = 9 * static_cast<int>(sizeof(double2)) - blk_step;
         };
-        auto mac_block = [&](int blk, const double2 (&P)[4], const double2 (&Q)[4]) {
+        auto mac_block = [&](int blk, const double2 (&P2)[4], const double2 (&P1)[4], const double2 (&Q)[4]) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const double t = qtaps[4 * blk + m];  // wave-uniform: a scalar load
 #pragma unroll
                 for (int c = 0; c < TE_OPL; ++c) {
-                    const double2 v = m - c >= 0 ? Q[m - c] : P[4 + m - c];
+                    const int d = m - c;
+                    const double2 v = d >= 0 ? Q[d] : d >= -4 ? P1[4 + d] : P2[8 + d];
                     q[c].x = __fma_rn(t, v.x, q[c].x);
                     q[c].y = __fma_rn(t, v.y, q[c].y);
                 }
             }
         };
         double2 R0[4], R1[4], R2[4];
-        load_block(-1, R0);
+        load_block(-2, R0);
+        load_block(-1, R1);
         const int nblk = nk / 4;  // a multiple of 3
         for (int blk = 0; blk < nblk; blk += 3) {
-            load_block(blk, R1);
-            mac_block(blk, R0, R1);
-            load_block(blk + 1, R2);
-            mac_block(blk + 1, R1, R2);
-            load_block(blk + 2, R0);
-            mac_block(blk + 2, R2, R0);
+            load_block(blk, R2);
+            mac_block(blk, R0, R1, R2);
+            load_block(blk + 1, R0);
+            mac_block(blk + 1, R1, R2, R0);
+            load_block(blk + 2, R1);
+            mac_block(blk + 2, R2, R0, R1);
         }
         // ---- delayed product, or (a pass that is not the last) the running filter sums back to memory
+        // (the rotor of the lane's first delayed sample by sincos, the next seven by steps of w_1 = e^{-i pi / n})
+        double2 rd = make_double2(1.0, 0.0);
+        if (with_delay) rd = te_rotor(i0 + TE_OPL * tid - static_cast<long long>(nd), n_sps);
 #pragma unroll
         for (int c = 0; c < TE_OPL; ++c) {
             const long long i = i0 + TE_OPL * tid + c;
-            if (i >= static_cast<long long>(len)) continue;
-            if (!with_delay) {
-                qacc[i] = q[c];
-            } else if (i >= static_cast<long long>(nd)) {
-                const double2 d = sh_d[TE_OPL * tid + c];
-                total.x += q[c].x * d.x - q[c].y * d.y;
-                total.y += q[c].x * d.y + q[c].y * d.x;
+            if (i < static_cast<long long>(len)) {
+                if (!with_delay) {
+                    qacc[i] = q[c];
+                } else if (i >= static_cast<long long>(nd)) {
+                    const double2 sm = x[i - static_cast<long long>(nd)];
+                    const double2 d = make_double2(sm.x * rd.x - sm.y * rd.y, sm.x * rd.y + sm.y * rd.x);
+                    total.x += q[c].x * d.x - q[c].y * d.y;
+                    total.y += q[c].x * d.y + q[c].y * d.x;
+                }
             }
+            rd = make_double2(rd.x * w_1.x - rd.y * w_1.y, rd.x * w_1.y + rd.y * w_1.x);
         }
     }
 #pragma unroll
@@ -304,22 +302,35 @@ __global__ __launch_bounds__(NCO_WG) void nco_sum_kernel(const double* __restric
 // the total (phase after the block) goes to *phase_io.
 __global__ __launch_bounds__(1024) void nco_scan_kernel(uint64_t* __restrict__ tile_sum, size_t ntiles,
                                                         uint64_t* __restrict__ phase_io) {
+    // a lane owns 8 consecutive tile sums per sweep (8192 per sweep: one sweep up to 2^24 samples); its 8 loads are in
+    // flight together, the lane totals are scanned per wave by shuffles and across the 16 waves through LDS
+    constexpr int PER = 8;
     __shared__ uint64_t wtot[16];
     __shared__ uint64_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) carry_s = *phase_io;
     __syncthreads();
-    for (size_t b0 = 0; b0 < ntiles; b0 += 1024) {
-        const size_t i = b0 + tid;
-        const uint64_t v = i < ntiles ? tile_sum[i] : 0;
-        const uint64_t inc = wave_incl_scan(v, lane);
+    for (size_t b0 = 0; b0 < ntiles; b0 += 1024 * PER) {
+        const size_t i0 = b0 + static_cast<size_t>(tid) * PER;
+        uint64_t v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) v[k] = i0 + k < ntiles ? tile_sum[i0 + k] : 0;
+        uint64_t tot = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) tot += v[k];
+        const uint64_t inc = wave_incl_scan(tot, lane);
         if (lane == 63) wtot[w] = inc;
         __syncthreads();
-        uint64_t off = carry_s;
+        uint64_t off = carry_s + inc - tot;  // exclusive prefix of this lane's first element
         for (int k = 0; k < w; ++k) off += wtot[k];
-        if (i < ntiles) tile_sum[i] = off + inc - v;
+        uint64_t run = off;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if (i0 + k < ntiles) tile_sum[i0 + k] = run;
+            run += v[k];
+        }
         __syncthreads();
-        if (tid == 1023) carry_s = off + inc;
+        if (tid == 1023) carry_s = run;
         __syncthreads();
     }
     if (tid == 0) *phase_io = carry_s;
@@ -469,15 +480,19 @@ comms_status_t comms_timing_push_dev(comms_timing_t* h, const double* d_samples,
             COMMS_TRY(h->qacc.reserve(len * sizeof(double2)));
             qacc = static_cast<double2*>(h->qacc.p);
         }
+        // rotor steps e^{-i pi m / n} for m = TE_WG and 1 (the kernel's lanes walk their samples with them)
+        const double a_wg = -kPi * static_cast<double>(TE_WG % (2 * static_cast<uint64_t>(h->n))) / static_cast<double>(h->n);
+        const double a_1 = -kPi / static_cast<double>(h->n);
+        const double2 w_wg = make_double2(std::cos(a_wg), std::sin(a_wg)), w_1 = make_double2(std::cos(a_1), std::sin(a_1));
         h->tic(s);
         for (uint32_t p = 0; p < n_pass; ++p) {
             const uint32_t k_lo = p * TE_QMAX;
             const uint32_t nk = nq12 - k_lo < static_cast<uint32_t>(TE_QMAX) ? nq12 - k_lo : TE_QMAX;
             const int win = TE_TILE + static_cast<int>(nk) - 1;
-            const size_t lds = (static_cast<size_t>(win + 1 + ((win + 1) >> 2)) + 1 + TE_TILE) * sizeof(double2);
+            const size_t lds = (static_cast<size_t>(win + 1 + ((win + 1) >> 3)) + 1) * sizeof(double2);  // te_slot(win + 1) + 1 slots
             timing_kernel<<<dim3(static_cast<unsigned>(blocks)), dim3(TE_WG), lds, s>>>(
                 reinterpret_cast<const double2*>(d_samples), len, h->d_taps + k_lo, nk, k_lo, h->n * h->d,
-                static_cast<double>(h->n), p + 1 == n_pass ? 1 : 0, qacc, h->d_part);
+                static_cast<double>(h->n), w_wg, w_1, p + 1 == n_pass ? 1 : 0, qacc, h->d_part);
         }
         h->toc(s);
         COMMS_TRY(launch_ok("timing_kernel"));
