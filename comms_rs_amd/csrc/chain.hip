@@ -123,7 +123,7 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
         h->turns = mix_to_turns(phase);
         for (int i = 0; i < 2 && st == COMMS_OK; ++i) {
             hipError_t e = hipMalloc(&h->d_prev[i], sizeof(float2));
-            if (e == hipSuccess) e = hipMemset(h->d_prev[i], 0, sizeof(float2));
+            if (e == hipSuccess) e = zero_device(h->d_prev[i], sizeof(float2));
             if (e != hipSuccess) st = fail(COMMS_ERR_DEVICE, "chain state alloc: %s", hipGetErrorString(e));
         }
     } else if (st == COMMS_OK) {
@@ -132,7 +132,7 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
         for (int i = 0; i < 2 && st == COMMS_OK && !h->mixer_after; ++i) {
             const size_t bytes = static_cast<size_t>(h->fir->n_eff) * sizeof(float2);
             hipError_t e = hipMalloc(&h->raw_hist[i], bytes);
-            if (e == hipSuccess) e = hipMemset(h->raw_hist[i], 0, bytes);
+            if (e == hipSuccess) e = zero_device(h->raw_hist[i], bytes);
             if (e != hipSuccess) st = fail(COMMS_ERR_DEVICE, "chain state alloc: %s", hipGetErrorString(e));
         }
     }

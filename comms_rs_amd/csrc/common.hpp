@@ -128,7 +128,9 @@ struct Pinned {
         if (bytes <= cap) return COMMS_OK;
         release();
         const size_t want = bytes < 65536 ? 65536 : bytes;
-        COMMS_HIP_TRY(hipHostMalloc(&h, want, hipHostMallocMapped));
+        // coherent (fine-grained) on purpose, not by the HIP_HOST_COHERENT default: the GPU must not keep lines of a
+        // staging buffer in its L2 from one call to the next, the CPU rewrites the buffer between them
+        COMMS_HIP_TRY(hipHostMalloc(&h, want, hipHostMallocMapped | hipHostMallocCoherent));
         hipError_t e = hipHostGetDevicePointer(&d, h, 0);
         if (e != hipSuccess) {
             (void)hipHostFree(h);
@@ -144,6 +146,15 @@ struct Pinned {
         cap = 0;
     }
 };
+// Create-time zeroing of device state (FIR history, FM.prev).  hipMemset on device memory returns before the fill
+// has run, on the legacy stream -- which the handles' own non-blocking streams (and PyTorch's side streams) do not
+// wait for: a first launch could read the allocation's old bytes.  So the fill is waited for here, once per create.
+inline hipError_t zero_device(void* p, size_t bytes) {
+    hipError_t e = hipMemsetAsync(p, 0, bytes, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    return e;
+}
+
 // calls moving at most this many bytes each way take the zero-copy route (COMMS_ZERO_COPY_BYTES)
 size_t zero_copy_limit();
 

@@ -1528,7 +1528,7 @@ comms_status_t comms_fft_run_dev(comms_fft_t* h, const comms_c32* d_in, size_t n
     float2* o = reinterpret_cast<float2*>(d_out);
     const size_t batch = n / h->N;
     if (h->N == 1) {
-        if (d_in != d_out) COMMS_HIP_TRY(hipMemcpyAsync(o, in, n * sizeof(float2), hipMemcpyDeviceToDevice, s));
+        if (d_in != d_out) COMMS_HIP_TRY(hipMemcpyAsync(o, in, n * sizeof(float2), hipMemcpyDefault, s));
         return COMMS_OK;
     }
     if (h->kind == 0) {

@@ -1403,7 +1403,7 @@ comms_status_t comms_fir_create(const comms_c32* taps, size_t n_taps, const comm
         if (taps[k].im != 0.0f) h->real_taps = false;
     for (int i = 0; i < 2; ++i) {
         hipError_t e = hipMalloc(&h->d_hist[i], n_eff * sizeof(float2));
-        if (e == hipSuccess) e = hipMemset(h->d_hist[i], 0, n_eff * sizeof(float2));
+        if (e == hipSuccess) e = zero_device(h->d_hist[i], n_eff * sizeof(float2));
         if (e != hipSuccess) {
             free_fir(h);
             return fail(COMMS_ERR_DEVICE, "FIR history alloc: %s", hipGetErrorString(e));
@@ -1894,7 +1894,7 @@ comms_status_t comms_pulse_create(const comms_c32* taps, size_t n_taps, size_t s
     if (e == hipSuccess) e = hipMemcpy(h->d_taps, taps, n_taps * sizeof(float2), hipMemcpyHostToDevice);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         e = hipMalloc(&h->d_hist[i], h->hist_len * sizeof(float2));
-        if (e == hipSuccess) e = hipMemset(h->d_hist[i], 0, h->hist_len * sizeof(float2));
+        if (e == hipSuccess) e = zero_device(h->d_hist[i], h->hist_len * sizeof(float2));
     }
     if (e != hipSuccess) {
         free_pulse(h);

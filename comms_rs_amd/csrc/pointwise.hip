@@ -226,11 +226,15 @@ __device__ inline float fm1(float2 x, float2 p) {
     return atan2f(im, re);
 }
 
+// prev / prev_new: FM.prev before and after this batch (two words of the handle, swapped per call, so that the
+// lane that stores the new value can never overtake the lane that reads the old one)
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void fmdemod_kernel(const float2* __restrict__ in,
                                                       const float2* __restrict__ prev,
+                                                      float2* __restrict__ prev_new,
                                                       float* __restrict__ out, size_t n) {
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x * 4;
+    if (blockIdx.x == 0 && threadIdx.x == 0) prev_new[0] = in[n - 1];
     for (size_t i0 = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 4; i0 < n;
          i0 += stride) {
         float2 p = (i0 == 0) ? prev[0] : in[i0 - 1];
@@ -403,7 +407,7 @@ comms_status_t comms_decimate_run_dev(const void* d_in, size_t n, size_t elem, s
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (rate <= 1) {
         if (d_in != d_out)
-            COMMS_HIP_TRY(hipMemcpyAsync(d_out, d_in, n * elem, hipMemcpyDeviceToDevice, s));
+            COMMS_HIP_TRY(hipMemcpyAsync(d_out, d_in, n * elem, hipMemcpyDefault, s));
         return COMMS_OK;
     }
     COMMS_ARG(!ranges_overlap(d_in, n * elem, d_out, n_out * elem), "decimate cannot run in place");
@@ -426,7 +430,7 @@ comms_status_t comms_upsample_run_dev(const void* d_in, size_t n, size_t elem, s
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (rate <= 1) {
         if (d_in != d_out)
-            COMMS_HIP_TRY(hipMemcpyAsync(d_out, d_in, n * elem, hipMemcpyDeviceToDevice, s));
+            COMMS_HIP_TRY(hipMemcpyAsync(d_out, d_in, n * elem, hipMemcpyDefault, s));
         return COMMS_OK;
     }
     COMMS_ARG(!ranges_overlap(d_in, n * elem, d_out, n_out * elem), "upsample cannot run in place");
@@ -474,7 +478,8 @@ comms_status_t comms_upsample_run(const void* in, size_t n, size_t elem, size_t 
 
 // ------------------------------------------------------------------ FM demod handle
 struct comms_fmdemod : Handle {
-    float2* d_prev = nullptr;  // FM.prev (analog.rs:9), starts 0+0i
+    float2* d_prev = nullptr;  // FM.prev (analog.rs:9), starts 0+0i: two words, d_prev[cur] is the current one
+    int cur = 0;
 };
 
 extern "C" {
@@ -489,8 +494,8 @@ comms_status_t comms_fmdemod_create(int32_t device, comms_fmdemod_t** out) {
         delete h;
         return st;
     }
-    hipError_t e = hipMalloc(&h->d_prev, sizeof(float2));
-    if (e == hipSuccess) e = hipMemset(h->d_prev, 0, sizeof(float2));
+    hipError_t e = hipMalloc(&h->d_prev, 2 * sizeof(float2));
+    if (e == hipSuccess) e = zero_device(h->d_prev, 2 * sizeof(float2));
     if (e != hipSuccess) {
         h->fini();
         delete h;
@@ -514,12 +519,12 @@ comms_status_t comms_fmdemod_run_dev(comms_fmdemod_t* h, const comms_c32* d_in, 
     bool aligned = ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0;
     h->tic(s);
     if (aligned)
-        fmdemod_kernel<true><<<dim3(blocks), dim3(256), 0, s>>>(in, h->d_prev, d_out, n);
+        fmdemod_kernel<true><<<dim3(blocks), dim3(256), 0, s>>>(in, h->d_prev + h->cur, h->d_prev + (h->cur ^ 1), d_out, n);
     else
-        fmdemod_kernel<false><<<dim3(blocks), dim3(256), 0, s>>>(in, h->d_prev, d_out, n);
+        fmdemod_kernel<false><<<dim3(blocks), dim3(256), 0, s>>>(in, h->d_prev + h->cur, h->d_prev + (h->cur ^ 1), d_out, n);
     h->toc(s);
     COMMS_TRY(launch_ok("fmdemod_kernel"));
-    COMMS_HIP_TRY(hipMemcpyAsync(h->d_prev, in + (n - 1), sizeof(float2), hipMemcpyDeviceToDevice, s));
+    h->cur ^= 1;  // the kernel stored the batch's last sample in the other word (no separate copy command)
     return COMMS_OK;
 }
 
@@ -539,7 +544,7 @@ comms_status_t comms_fmdemod_get_prev(comms_fmdemod_t* h, comms_c32* out_prev) {
     COMMS_ARG(h && out_prev, "NULL argument");
     COMMS_TRY(use_device(h->device));
     COMMS_TRY(h->quiesce());
-    COMMS_HIP_TRY(hipMemcpy(out_prev, h->d_prev, sizeof(float2), hipMemcpyDeviceToHost));
+    COMMS_HIP_TRY(hipMemcpy(out_prev, h->d_prev + h->cur, sizeof(float2), hipMemcpyDeviceToHost));
     return COMMS_OK;
 }
 
@@ -547,7 +552,7 @@ comms_status_t comms_fmdemod_set_prev(comms_fmdemod_t* h, const comms_c32* prev)
     COMMS_ARG(h && prev, "NULL argument");
     COMMS_TRY(use_device(h->device));
     COMMS_TRY(h->quiesce());
-    COMMS_HIP_TRY(hipMemcpy(h->d_prev, prev, sizeof(float2), hipMemcpyHostToDevice));
+    COMMS_HIP_TRY(hipMemcpy(h->d_prev + h->cur, prev, sizeof(float2), hipMemcpyHostToDevice));
     return COMMS_OK;
 }
 

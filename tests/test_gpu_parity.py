@@ -491,7 +491,9 @@ def test_fm_demod_vs_oracle(c):
     cuts = [0, 1, 2, 5, 4096, 4099, 100003]
     for a, b in zip(cuts[:-1], cuts[1:]):
         got, want = node.run(x[a:b]), orc.demod(x[a:b])
-        assert np.max(circ(got.astype(np.float64) - want)) <= TOL
+        d = circ(got.astype(np.float64) - want)
+        k = int(np.argmax(d))
+        assert d[k] <= TOL, (a, b, k, float(got[k]), float(want[k]), int(np.count_nonzero(d > TOL)))
 
 
 def test_fm_demod_signed_zero_first_sample(c):
