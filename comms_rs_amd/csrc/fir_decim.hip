@@ -60,7 +60,6 @@ struct DecimArgs {
     const float2* fm_prev;
     float2* fm_prev_new;
     size_t n, n_out, n_tiles;
-    int interleave;  // tile t of workgroup b: b + i gridDim.x instead of a contiguous run
     int hist_len, hlq, nd, mode;   // hlq = ceil((N-1)/PR); nd = hlq + 1 tap blocks of PR
     int fmt;                       // COMMS_IQ_*
     float in_scale;
@@ -72,6 +71,8 @@ struct DecimArgs {
     float aim[DC_AMAX];
     const float* qt;               // OPL = 4: the taps of one LDS read stored together, Q[m][c] = A[m + R c] (device memory)
     unsigned long long* stamps;    // diagnostic (scripts/stamp_decim.py): per-wave cycles per phase, or NULL
+    int interleave;                // tile t of workgroup b: b + i gridDim.x instead of a contiguous run (kept last: the tap
+                                   // arrays' offsets decide how many scalar-cache lines a 64-byte tap load touches)
 };
 
 constexpr double kTwoPiD = 2.0 * 3.14159265358979323846264338327950288;
@@ -157,8 +158,6 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
     constexpr int NROW = PRE ? PR : 1;
     cf lrow[NROW], lhalo[HROWS];
     double tt_c = 1.0, tt_s = 0.0, ro_c = 1.0, ro_s = 0.0;
-    double tile_c = a.tile_c, tile_s = a.tile_s;  // rotor of one step of this workgroup's tile sequence
-    if (a.interleave && (pre || post)) rotor_at(static_cast<uint64_t>(R * ts) * tstep * a.frac, tile_c, tile_s);
     {
         const long long jb0 = static_cast<long long>(t0) * ts - ovl;
         if (pre) {
@@ -383,13 +382,13 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
             const cf tt = cf{static_cast<float>(tt_c), static_cast<float>(tt_s)};
 #pragma unroll
             for (int c = 0; c < OPL; ++c) y[c] = to_f2(cmulf(acc[c], tt));
-            rotor_step(tt_c, tt_s, tile_c, tile_s);
+            rotor_step(tt_c, tt_s, a.tile_c, a.tile_s);
         }
         if (post) {
             const cf ro = cf{static_cast<float>(ro_c), static_cast<float>(ro_s)};
 #pragma unroll
             for (int c = 0; c < OPL; ++c) y[c] = to_f2(cmulf(acc[c], c ? cmulf(ro, to_cf(a.step_r[c])) : ro));
-            rotor_step(ro_c, ro_s, tile_c, tile_s);
+            rotor_step(ro_c, ro_s, a.tile_c, a.tile_s);
         }
         const long long j0 = jb + OPL * tid;
         if (fm) {
@@ -433,7 +432,15 @@ static comms_status_t launch_decim_v(const DecimArgs& a, hipStream_t s) {
     if (attr_once.need())
         COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_decim_kernel<R, OPL, REAL, PRE, TILE, CHX>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    fir_decim_kernel<R, OPL, REAL, PRE, TILE, CHX><<<dim3(blocks), dim3(G::WG), lds, s>>>(a);
+    if (a.interleave) {
+        // a workgroup's next tile is `blocks` tiles on: the per-step rotor of its tile-wide phase follows the grid
+        DecimArgs b = a;
+        const uint64_t ts = static_cast<uint64_t>(TILE) - ((a.mode & COMMS_CHAIN_FM) ? 1 : 0);
+        mix_host_rotor(static_cast<uint64_t>(R) * ts * blocks * a.frac, b.tile_c, b.tile_s);
+        fir_decim_kernel<R, OPL, REAL, PRE, TILE, CHX><<<dim3(blocks), dim3(G::WG), lds, s>>>(b);
+    } else {
+        fir_decim_kernel<R, OPL, REAL, PRE, TILE, CHX><<<dim3(blocks), dim3(G::WG), lds, s>>>(a);
+    }
     return launch_ok("fir_decim_kernel");
 }
 
