@@ -188,3 +188,39 @@ def test_device_nco_long_block():
         assert np.max(np.abs(got - want)) < 1e-9, call
     end = np.fmod(np.longdouble(phase0) + 2 * np.longdouble(n) * inc, two_pi)
     assert abs(np.exp(1j * node.phase) - np.exp(1j * float(end))) < 1e-9
+
+
+@pytest.mark.gpu
+def test_block_rate_carrier_loop_device_vs_oracle():
+    """the NCO inside a feedback loop, run at block rate.  Per block: the NCO (device)
+    produces exp(i phase) from the loop's per-sample phase error, the block is de-rotated by it, the frequency
+    estimator (device) measures the residual offset, a first-order loop filter feeds it back as the next block's
+    phase error (Nco::push's perr input, nco.rs:71-77; the feedback edge is what connect_nodes_feedback! wires,
+    node/mod.rs:213-219).  The same loop runs on the oracle's Nco + frequency_offset_estimate: the two
+    trajectories must agree block by block, and the loop must pull in the carrier offset."""
+    import comms_rs_amd as c
+
+    rng = np.random.default_rng(11)
+    block, n_blocks = 4096, 40
+    w_true, w_nco, mu = 0.1234, 0.1, 0.5   # rad / sample: the carrier, the NCO's nominal rate, the loop gain
+    n = block * n_blocks
+    x = np.exp(1j * (w_true * np.arange(n) + 0.7)) + 0.05 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    dev, ref = c.NcoNode(w_nco, 0.3), oracle.Nco(w_nco, 0.3)
+    e_dev = e_ref = 0.0
+    res_dev, res_ref = [], []
+    for b in range(n_blocks):
+        xb = x[b * block:(b + 1) * block]
+        y_dev = xb * np.conj(dev.run(np.full(block, e_dev)))
+        y_ref = xb * np.conj(ref.push(np.full(block, e_ref)))
+        r_dev = c.frequency_offset_estimate(y_dev)
+        r_ref = oracle.frequency_offset_estimate(y_ref)
+        res_dev.append(r_dev)
+        res_ref.append(r_ref)
+        e_dev += mu * r_dev
+        e_ref += mu * r_ref
+    res_dev, res_ref = np.array(res_dev), np.array(res_ref)
+    assert np.max(np.abs(res_dev - res_ref)) < 1e-9          # the closed loops follow the same trajectory
+    assert abs(e_dev - e_ref) < 1e-9
+    assert abs(res_dev[0] - (w_true - w_nco)) < 1e-3           # open-loop residual = the offset
+    assert np.max(np.abs(res_dev[-10:])) < 1e-3                # pulled in
+    assert abs(w_nco + e_dev - w_true) < 1e-3                  # the loop's frequency = the carrier's
