@@ -165,7 +165,7 @@ from comms_rs_amd.sharding import (chain_prefix_len, gather_shards, halo_exchang
                                    state_from_halo, shard_mixer_phase)
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-total, n_taps, rate = 50000, 255, 8
+total, n_taps, rate = 51200, 255, 8                      # 51200 / world is a multiple of the rate for world = 2, 4, 8
 taps = oracle.rrc_taps(n_taps, 8.0, 0.35)
 a, b = shard_range(total, world, rank)
 x = synth_iq(b - a, a)                                   # shard generated in place
@@ -214,21 +214,32 @@ sys.exit(0 if ok.item() == 1.0 else 3)
 """
 
 
-def test_sharded_stream_equals_unsharded_gloo_world2(tmp_path):
-    """Two CPU ranks (gloo): contiguous shards + one halo hand-over reproduce the
-    un-sharded filter output exactly; scatter -> prefix-primed FM chain -> gather reproduces the
-    un-sharded chain -- the N>1 logic of bench.py and sharding.py, minus the GPU (the same logic
-    with the product nodes: tests/test_gpu_sharding.py)."""
+def _run_gloo_world(tmp_path, world, port):
     import __graft_entry__ as g
 
     g.build()
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", WORLD_SIZE="2",
-               COMMS_NO_TORCH_PRELOAD="1")
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r))) for r in range(2)]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
+               COMMS_NO_TORCH_PRELOAD="1", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r))) for r in range(world)]
     rcs = [p.wait(timeout=300) for p in procs]
-    assert rcs == [0, 0], rcs
+    assert rcs == [0] * world, rcs
+
+
+def test_sharded_stream_equals_unsharded_gloo_world2(tmp_path):
+    """Two CPU ranks (gloo): contiguous shards + one halo hand-over reproduce the
+    un-sharded filter output exactly; scatter -> prefix-primed FM chain -> gather reproduces the
+    un-sharded chain -- the N>1 logic of bench.py and sharding.py, minus the GPU (the same logic
+    with the product nodes: tests/test_gpu_sharding.py)."""
+    _run_gloo_world(tmp_path, 2, 29517)
+
+
+@pytest.mark.parametrize("world,port", [(4, 29518), (8, 29519)])
+def test_sharded_stream_equals_unsharded_gloo_world4_and_8(tmp_path, world, port):
+    """The same with four and eight ranks -- the driver's scaling run goes to N = 8: interior ranks both send
+    and receive a halo, the root scatters to / gathers from seven peers."""
+    _run_gloo_world(tmp_path, world, port)
 
 
 def test_rust_shim_declares_every_header_symbol():
