@@ -172,6 +172,13 @@ struct comms_timer {
 namespace comms {
 
 // Base of every node handle: device + own stream + scratch for host-pointer runs.
+// Streams of handles and host-graph nodes come from a per-device pool and go back to it instead of being destroyed
+// (runtime.hip): a HIP event keeps referring to the stream it was last recorded on, and the events that travel with
+// pooled buffers outlive the node -- and so the stream -- that recorded them.  On this runtime, synchronising such an
+// event after hipStreamDestroy intermittently failed with "operation not permitted when stream is capturing".
+COMMS_INTERNAL comms_status_t stream_acquire(int32_t device, hipStream_t* out);
+COMMS_INTERNAL void stream_release(int32_t device, hipStream_t s);
+
 struct Handle {
     int32_t device = 0;
     hipStream_t stream = nullptr;
@@ -202,8 +209,7 @@ struct Handle {
     comms_status_t init(int32_t dev) {
         COMMS_TRY(use_device(dev));
         device = dev;
-        COMMS_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        return COMMS_OK;
+        return stream_acquire(dev, &stream);
     }
     // `stream` arguments of the C ABI are passed through as HIP does: NULL is the
     // legacy default stream; COMMS_STREAM_HANDLE selects the handle's own stream.
@@ -258,7 +264,7 @@ struct Handle {
         out_scratch.release();
         pin_in.release();
         pin_out.release();
-        if (stream) (void)hipStreamDestroy(stream);
+        if (stream) stream_release(device, stream);
         stream = nullptr;
     }
 };

@@ -51,6 +51,35 @@ __global__ void synth_iq_kernel(float2* out, size_t n, uint64_t first, uint64_t 
     }
 }
 
+// ---- stream pool (common.hpp: why streams are recycled rather than destroyed)
+namespace {
+std::mutex g_stream_m;
+std::vector<hipStream_t> g_free_streams[64];
+}  // namespace
+
+comms_status_t stream_acquire(int32_t device, hipStream_t* out) {
+    COMMS_ARG(device >= 0 && device < 64, "device index out of range");
+    COMMS_TRY(use_device(device));
+    {
+        std::lock_guard<std::mutex> lk(g_stream_m);
+        auto& fl = g_free_streams[device];
+        if (!fl.empty()) {
+            *out = fl.back();
+            fl.pop_back();
+            return COMMS_OK;
+        }
+    }
+    COMMS_HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return COMMS_OK;
+}
+
+void stream_release(int32_t device, hipStream_t s) {
+    if (!s || device < 0 || device >= 64) return;
+    if (use_device(device) == COMMS_OK) (void)hipStreamSynchronize(s);  // the next owner starts on an idle stream
+    std::lock_guard<std::mutex> lk(g_stream_m);
+    g_free_streams[device].push_back(s);
+}
+
 }  // namespace comms
 
 using namespace comms;
@@ -307,13 +336,12 @@ comms_status_t comms_buf_sync(comms_buf_t* b) {
     return COMMS_OK;
 }
 
-// ---- plain streams for host graph nodes (one per node thread)
+// ---- plain streams for host graph nodes (one per node thread); recycled, see stream_acquire
 comms_status_t comms_stream_create(int32_t device, void** out_stream) {
     COMMS_ARG(out_stream != nullptr, "out_stream is NULL");
     *out_stream = nullptr;
-    COMMS_TRY(use_device(device));
     hipStream_t s = nullptr;
-    COMMS_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    COMMS_TRY(comms::stream_acquire(device, &s));
     *out_stream = s;
     return COMMS_OK;
 }
@@ -324,8 +352,8 @@ comms_status_t comms_stream_synchronize(int32_t device, void* stream) {
 }
 comms_status_t comms_stream_destroy(int32_t device, void* stream) {
     if (!stream) return COMMS_OK;
-    COMMS_TRY(use_device(device));
-    COMMS_HIP_TRY(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)));
+    COMMS_ARG(device >= 0 && device < 64, "device index out of range");
+    comms::stream_release(device, reinterpret_cast<hipStream_t>(stream));
     return COMMS_OK;
 }
 comms_status_t comms_buf_upload(comms_buf_t* b, size_t offset, const void* host, size_t bytes) {
