@@ -109,11 +109,15 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
     h->fm_demod = (flags & COMMS_CHAIN_FM_DEMOD) != 0;
     h->mixer_after = (flags & COMMS_CHAIN_MIXER_AFTER_FIR) != 0;
     st = comms_fir_create(taps, n_taps, nullptr, 0, device, &h->fir);
-    const int decim_ok = st == COMMS_OK && rate <= 16 ? comms_fir_decim_supported(h->fir, static_cast<uint32_t>(rate)) : 0;
-    const bool can_decim = !(flags & (COMMS_CHAIN_UNFUSED | COMMS_CHAIN_FREQ_DOMAIN)) &&
-                           (decim_ok == 2 || (decim_ok == 1 && (flags & COMMS_CHAIN_TIME_DOMAIN)));
     const bool can_fuse = !(flags & COMMS_CHAIN_UNFUSED) && n_taps <= 257 && rate <= (1u << 20) &&
                           (!h->fm_demod || (rate <= 64 && n_taps + rate <= 257));
+    // the time-domain kernel against what would run otherwise: the overlap-save fusion, or (FM demod with
+    // taps + rate > 257) the four kernels in series, which it beats up to many more MACs per input sample
+    const int decim_ok = st == COMMS_OK && rate <= 16
+                             ? comms_fir_decim_supported_for(h->fir, static_cast<uint32_t>(rate), h->fm_demod ? 1 : 0, can_fuse ? 1 : 0)
+                             : 0;
+    const bool can_decim = !(flags & (COMMS_CHAIN_UNFUSED | COMMS_CHAIN_FREQ_DOMAIN)) &&
+                           (decim_ok == 2 || (decim_ok == 1 && (flags & COMMS_CHAIN_TIME_DOMAIN)));
     if (st == COMMS_OK && (can_fuse || can_decim)) {
         h->fused = true;
         h->decim = can_decim;

@@ -29,6 +29,7 @@ extern "C" COMMS_INTERNAL comms_status_t comms_fir_run_fused_dev(comms_fir_t* h,
 
 // the same chain on the time-domain decimating kernel (fir_decim.hip), where it applies
 extern "C" COMMS_INTERNAL int32_t comms_fir_decim_supported(const comms_fir_t* h, uint32_t rate);
+extern "C" COMMS_INTERNAL int32_t comms_fir_decim_supported_for(const comms_fir_t* h, uint32_t rate, int32_t fm_demod, int32_t can_fuse);
 extern "C" COMMS_INTERNAL comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t n, void* d_out,
                                                   int32_t mode, uint64_t turns0, uint64_t frac, uint32_t rate,
                                                   const void* fm_prev, void* fm_prev_new, void* stream);

@@ -1617,7 +1617,9 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
         const size_t V = OSF - 256 * static_cast<size_t>(h->hblk);
         const size_t nseg = (n + V - 1) / V;
         // persistent grid: WPS workgroups per CU (one wave of each per SIMD), segments dealt round-robin
-        static const int wps = tune_int("COMMS_OS4096_WPS", 3);
+        // two workgroups per CU: at three the kernel no longer fits its 170-register budget (24 spilled registers
+        // since the input views were templated) and runs 4-21 % slower (300-511 taps at 2^24: 86.8 -> 68.4 us)
+        static const int wps = tune_int("COMMS_OS4096_WPS", 2);
         // segments b, b + G, ... per workgroup (the chip sweeps the stream as one window: 2-4 % faster at 2^24 ...
         // 2^26 than a contiguous run per workgroup, 1 % at 2^28); 0 restores the runs
         static const int il = tune_int("COMMS_OS4096_INTERLEAVE", 1);

@@ -514,21 +514,34 @@ extern "C" {
 void comms_debug_decim_stamps(void* d_buf) { g_decim_stamps = static_cast<unsigned long long*>(d_buf); }
 #endif
 
-// Whether (taps, rate) runs on the decimating kernel: 0 = no (no instantiation for the rate, or
-// taps beyond the kernel-argument budget), 1 = it can, 2 = and with few enough MACs per input
-// sample that it beats the fused overlap-save launch (measured crossover).
-int32_t comms_fir_decim_supported(const comms_fir_t* h, uint32_t rate) {
-    if (!h || h->n_eff < 1 || h->n_eff > DC_NMAX) return 0;
+// MACs per input sample of (taps, rate) on the decimating kernel, or -1 when it cannot run there (no
+// instantiation for the rate, or taps beyond the kernel-argument budget).
+static int32_t decim_macs(const comms_fir_t* h, uint32_t rate) {
+    if (!h || h->n_eff < 1 || h->n_eff > DC_NMAX) return -1;
     switch (rate) {
         case 2: case 3: case 4: case 5: case 6: case 8: case 10: case 12: case 16: break;
-        default: return 0;
+        default: return -1;
     }
+    return (h->n_eff + static_cast<int>(rate) - 1) / static_cast<int>(rate) * (h->real_taps ? 1 : 2);
+}
+// Whether (taps, rate) runs on the decimating kernel: 0 = no, 1 = it can, 2 = and with few enough MACs per
+// input sample that it beats the alternative (measured at 2^24 samples, scripts under gpurun / DESIGN.md section 3):
+//   * the fused overlap-save launch, where that exists: 67 us without FM demod (crossover 44 MACs), 82-92 us with
+//     it (127 taps / 3: 42 MACs, 62 us; 255 / 4: 64 MACs, 93 us -> crossover ~56);
+//   * the four kernels in series, where it does not (FM demod and taps + rate > 257): 135-152 us, against
+//     101 us at 85 MACs (255 taps / 3) and 186 us at 128 (255 / 2) -> 96.
+int32_t comms_fir_decim_supported_for(const comms_fir_t* h, uint32_t rate, int32_t fm_demod, int32_t can_fuse) {
+    const int macs = decim_macs(h, rate);
+    if (macs < 0) return 0;
     static const int max_macs = [] {
         const char* v = getenv("COMMS_DECIM_MAX_MACS");
-        return v && *v ? atoi(v) : 44;
+        return v && *v ? atoi(v) : 0;
     }();
-    const int macs = (h->n_eff + static_cast<int>(rate) - 1) / static_cast<int>(rate) * (h->real_taps ? 1 : 2);
-    return macs <= max_macs ? 2 : 1;
+    const int limit = max_macs > 0 ? max_macs : !can_fuse ? 96 : fm_demod ? 56 : 44;
+    return macs <= limit ? 2 : 1;
+}
+int32_t comms_fir_decim_supported(const comms_fir_t* h, uint32_t rate) {
+    return comms_fir_decim_supported_for(h, rate, 0, 1);
 }
 
 comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t n, void* d_out, int32_t mode,
