@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void chain_raw_hist_kernel(const float2* __res
 struct comms_chain : Handle {
     bool fused = false;
     bool decim = false;  // fused on the time-domain decimating kernel
+    bool fm_separate = false;  // fused mixer / FIR / decimate launch, FM demod as its own (small) kernel behind it
     int mode = 0;
     // fused path state
     comms_fir_t* fir = nullptr;
@@ -109,20 +110,30 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
     h->fm_demod = (flags & COMMS_CHAIN_FM_DEMOD) != 0;
     h->mixer_after = (flags & COMMS_CHAIN_MIXER_AFTER_FIR) != 0;
     st = comms_fir_create(taps, n_taps, nullptr, 0, device, &h->fir);
-    const bool can_fuse = !(flags & COMMS_CHAIN_UNFUSED) && n_taps <= 257 && rate <= (1u << 20) &&
-                          (!h->fm_demod || (rate <= 64 && n_taps + rate <= 257));
-    // the time-domain kernel against what would run otherwise: the overlap-save fusion, or (FM demod with
-    // taps + rate > 257) the four kernels in series, which it beats up to many more MACs per input sample
+    const bool can_fuse_nofm = !(flags & COMMS_CHAIN_UNFUSED) && n_taps <= 257 && rate <= (1u << 20);
+    // FM chains on the overlap-save path: mixer / FIR / decimate as the one fused launch, the demodulator as its
+    // own kernel over the n / rate decimated samples.  That beats demodulating inside the overlap-save kernel at
+    // every rate (2^24 samples, 127 taps: /2 85.8 against 95.9 us, /3 68 against 83, /8 60 against 82 -- the fused
+    // form needs `rate` more halo samples per segment and an atan2 per output in a kernel short of issue slots) and
+    // has no limit on taps + rate; COMMS_CHAIN_FM_SEPARATE=0 brings the in-kernel form back for comparison.
+    static const int fm_sep = [] { const char* v = getenv("COMMS_CHAIN_FM_SEPARATE"); return v && *v ? atoi(v) : 1; }();
+    const bool can_fuse = can_fuse_nofm && (!h->fm_demod || (!fm_sep && rate <= 64 && n_taps + rate <= 257));
+    const bool can_hybrid = h->fm_demod && can_fuse_nofm && !can_fuse;
+    // the time-domain kernel against what would run otherwise: an overlap-save fusion, or the four kernels in
+    // series, which it beats up to many more MACs per input sample
     const int decim_ok = st == COMMS_OK && rate <= 16
-                             ? comms_fir_decim_supported_for(h->fir, static_cast<uint32_t>(rate), h->fm_demod ? 1 : 0, can_fuse ? 1 : 0)
+                             ? comms_fir_decim_supported_for(h->fir, static_cast<uint32_t>(rate), h->fm_demod ? 1 : 0,
+                                                             can_fuse || can_hybrid ? 1 : 0)
                              : 0;
     const bool can_decim = !(flags & (COMMS_CHAIN_UNFUSED | COMMS_CHAIN_FREQ_DOMAIN)) &&
                            (decim_ok == 2 || (decim_ok == 1 && (flags & COMMS_CHAIN_TIME_DOMAIN)));
-    if (st == COMMS_OK && (can_fuse || can_decim)) {
+    if (st == COMMS_OK && (can_fuse || can_decim || can_hybrid)) {
         h->fused = true;
         h->decim = can_decim;
+        h->fm_separate = !can_decim && !can_fuse;
         h->mode = (h->mixer_after ? COMMS_CHAIN_POST : COMMS_CHAIN_PRE) | COMMS_CHAIN_DEC |
-                  (h->fm_demod ? COMMS_CHAIN_FM : 0);
+                  (h->fm_demod && !h->fm_separate ? COMMS_CHAIN_FM : 0);
+        if (h->fm_separate) st = comms_fmdemod_create(device, &h->fm);
         h->frac = mix_to_turns(mix_wrap_dphase(dphase));
         h->turns = mix_to_turns(phase);
         for (int i = 0; i < 2 && st == COMMS_OK; ++i) {
@@ -187,18 +198,25 @@ comms_status_t comms_chain_run_dev(comms_chain_t* h, const comms_c32* d_in_any, 
             COMMS_TRY(comms_iq_u8_to_c32_dev(reinterpret_cast<const uint8_t*>(d_in), n, c, h->device, s));
         d_in = c;
     }
+    const size_t n_dec = n / h->rate;
     if (h->fused) {
+        void* stage_out = d_out;
+        if (h->fm_separate) {  // decimated filter output to scratch, the demodulator reads it
+            COMMS_TRY(h->t3.reserve(n_dec * sizeof(comms_c32)));
+            stage_out = h->t3.p;
+        }
         if (h->decim)
-            COMMS_TRY(comms_fir_run_decim_dev(h->fir, d_in, n, d_out, h->mode, h->turns, h->frac, static_cast<uint32_t>(h->rate),
+            COMMS_TRY(comms_fir_run_decim_dev(h->fir, d_in, n, stage_out, h->mode, h->turns, h->frac, static_cast<uint32_t>(h->rate),
                                               h->d_prev[h->cur], h->d_prev[h->cur ^ 1], s));
         else
-            COMMS_TRY(comms_fir_run_fused_dev(h->fir, d_in, n, d_out, h->mode, h->turns, h->frac, static_cast<uint32_t>(h->rate),
+            COMMS_TRY(comms_fir_run_fused_dev(h->fir, d_in, n, stage_out, h->mode, h->turns, h->frac, static_cast<uint32_t>(h->rate),
                                               h->d_prev[h->cur], h->d_prev[h->cur ^ 1], s));
         h->turns += static_cast<uint64_t>(n) * h->frac;
+        if (h->fm_separate)
+            return comms_fmdemod_run_dev(h->fm, static_cast<const comms_c32*>(stage_out), n_dec, static_cast<float*>(d_out), s);
         if (h->fm_demod) h->cur ^= 1;
         return COMMS_OK;
     }
-    const size_t n_dec = n / h->rate;
     COMMS_TRY(h->t1.reserve(n * sizeof(comms_c32)));
     COMMS_TRY(h->t2.reserve(n * sizeof(comms_c32)));
     comms_c32* a = static_cast<comms_c32*>(h->t1.p);
@@ -307,7 +325,7 @@ comms_status_t comms_chain_set_phase(comms_chain_t* h, double phase) {
 comms_status_t comms_chain_get_fm_prev(comms_chain_t* h, comms_c32* out_prev) {
     COMMS_ARG(h && out_prev, "NULL argument");
     COMMS_ARG(h->fm_demod, "this chain has no FM demodulator");
-    if (!h->fused) return comms_fmdemod_get_prev(h->fm, out_prev);
+    if (!h->fused || h->fm_separate) return comms_fmdemod_get_prev(h->fm, out_prev);
     COMMS_TRY(use_device(h->device));
     COMMS_TRY(h->quiesce());
     COMMS_HIP_TRY(hipMemcpy(out_prev, h->d_prev[h->cur], sizeof(float2), hipMemcpyDeviceToHost));
@@ -317,7 +335,7 @@ comms_status_t comms_chain_get_fm_prev(comms_chain_t* h, comms_c32* out_prev) {
 comms_status_t comms_chain_set_fm_prev(comms_chain_t* h, const comms_c32* prev) {
     COMMS_ARG(h && prev, "NULL argument");
     COMMS_ARG(h->fm_demod, "this chain has no FM demodulator");
-    if (!h->fused) return comms_fmdemod_set_prev(h->fm, prev);
+    if (!h->fused || h->fm_separate) return comms_fmdemod_set_prev(h->fm, prev);
     COMMS_TRY(use_device(h->device));
     COMMS_TRY(h->quiesce());
     COMMS_HIP_TRY(hipMemcpy(h->d_prev[h->cur], prev, sizeof(float2), hipMemcpyHostToDevice));

@@ -526,10 +526,11 @@ static int32_t decim_macs(const comms_fir_t* h, uint32_t rate) {
 }
 // Whether (taps, rate) runs on the decimating kernel: 0 = no, 1 = it can, 2 = and with few enough MACs per
 // input sample that it beats the alternative (measured at 2^24 samples, scripts under gpurun / DESIGN.md section 3):
-//   * the fused overlap-save launch, where that exists: 67 us without FM demod (crossover 44 MACs), 82-92 us with
-//     it (127 taps / 3: 42 MACs, 62 us; 255 / 4: 64 MACs, 93 us -> crossover ~56);
-//   * the four kernels in series, where it does not (FM demod and taps + rate > 257): 135-152 us, against
-//     101 us at 85 MACs (255 taps / 3) and 186 us at 128 (255 / 2) -> 96.
+//   * the fused overlap-save launch, where that exists (up to 257 taps): 67 us without FM demod (crossover 44 MACs),
+//     60-68 us + the demodulator's own small kernel with it (127 taps / 3: 42 MACs, 63 against 68 us; 255 / 5: 51
+//     MACs, 66 against ~65 -> 48);
+//   * the four kernels in series, where it does not: 135-170 us, against 101 us at 85 MACs (255 taps / 3) and
+//     186 us at 128 (255 / 2) -> 96.
 int32_t comms_fir_decim_supported_for(const comms_fir_t* h, uint32_t rate, int32_t fm_demod, int32_t can_fuse) {
     const int macs = decim_macs(h, rate);
     if (macs < 0) return 0;
@@ -537,7 +538,7 @@ int32_t comms_fir_decim_supported_for(const comms_fir_t* h, uint32_t rate, int32
         const char* v = getenv("COMMS_DECIM_MAX_MACS");
         return v && *v ? atoi(v) : 0;
     }();
-    const int limit = max_macs > 0 ? max_macs : !can_fuse ? 96 : fm_demod ? 56 : 44;
+    const int limit = max_macs > 0 ? max_macs : !can_fuse ? 96 : fm_demod ? 48 : 44;
     return macs <= limit ? 2 : 1;
 }
 int32_t comms_fir_decim_supported(const comms_fir_t* h, uint32_t rate) {

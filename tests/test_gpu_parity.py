@@ -833,14 +833,48 @@ def test_fused_fm_chain_rates_and_fallbacks(c, rate, kernel):
         mag = np.minimum(np.abs(y), np.abs(np.concatenate([[1.0], y[:-1]])))
         ok = mag > 0.05  # the angle is ill-conditioned where the filtered signal is ~0
         assert np.max(circ(got.astype(np.float64) - w)[ok]) <= 1e-4
-    # combinations the fused kernel does not cover fall back to the four-kernel path
+    # what runs where: the time-domain kernel for the rates it is built for, otherwise the overlap-save launch for
+    # mixer / FIR / decimate with the demodulator as its own kernel behind it; four kernels beyond 257 taps
     assert c.ChainNode(0.3, 0.1, lowpass_taps(255, 0.1), 8, True).kernel == "time"
-    assert not c.ChainNode(0.3, 0.1, lowpass_taps(255, 0.1), 8, True, kernel="freq").fused  # taps + rate > 257
-    assert not c.ChainNode(0.3, 0.1, lowpass_taps(255, 0.1), 7, True).fused      # ... and no time kernel for /7
-    assert not c.ChainNode(0.3, 0.1, lowpass_taps(63, 0.1), 128, True).fused     # rate > 64
+    assert c.ChainNode(0.3, 0.1, lowpass_taps(255, 0.1), 8, True, kernel="freq").kernel == "freq"
+    assert c.ChainNode(0.3, 0.1, lowpass_taps(255, 0.1), 7, True).kernel == "freq"      # no time kernel for /7
+    assert c.ChainNode(0.3, 0.1, lowpass_taps(63, 0.1), 128, True).kernel == "freq"
     assert not c.ChainNode(0.3, 0.1, lowpass_taps(300, 0.1), 8, False).fused     # > 257 taps
     with pytest.raises(c.CommsError):
         c.ChainNode(0.3, 0.1, taps, 8, True).run(x[:12])  # n not a multiple of rate
+
+
+@pytest.mark.parametrize("n_taps,rate,after", [(255, 7, False), (255, 20, True), (200, 100, False), (63, 128, True),
+                                               (257, 3, False), (255, 8, True)])
+def test_fm_chain_with_the_demodulator_as_its_own_kernel(c, n_taps, rate, after):
+    """FM chains on the overlap-save path: mixer / FIR / decimate as the one fused launch, FM::demod
+    (analog.rs:22-35) as a kernel of its own over the decimated samples -- any rate, up to 257 taps; FM.prev
+    carried across calls and through the checkpoint hooks."""
+    n = 768 * rate * 5
+    x = fm_stream(n)
+    taps = lowpass_taps(n_taps, 1 / (2.5 * rate))
+    node = c.ChainNode(0.3, 0.1, taps, rate, True, kernel="freq", mixer_after_fir=after)
+    assert node.fused and node.kernel == "freq"
+    ost, om, ofm = oracle.default_state(taps), oracle.Mixer(0.1, 0.3), oracle.FM()
+
+    def ref(seg):
+        if after:
+            return oracle.decimate(om.mix(oracle.batch_fir(seg, taps, ost, norotate=True)), rate)
+        return oracle.decimate(oracle.batch_fir(om.mix(seg), taps, ost, norotate=True), rate)
+
+    cuts = [0, 768 * rate, 768 * rate + 3 * rate, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        y = ref(x[a:b])
+        w = ofm.demod(y)
+        got = node.run(x[a:b])
+        mag = np.minimum(np.abs(y), np.abs(np.concatenate([[1.0], y[:-1]])))
+        ok = mag > 0.05
+        assert np.max(circ(got.astype(np.float64) - w)[ok], initial=0.0) <= 1e-4, (a, b)
+    # the checkpoint hook reaches the separate demodulator's state
+    p = node.fm_prev
+    node2 = c.ChainNode(0.3, 0.1, taps, rate, True, kernel="freq", mixer_after_fir=after)
+    node2.fm_prev = p
+    assert node2.fm_prev == p
 
 
 @pytest.mark.parametrize("rate", [2, 3, 4, 5, 6, 8, 10, 12, 16])
