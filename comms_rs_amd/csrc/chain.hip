@@ -218,13 +218,21 @@ comms_status_t comms_chain_run_dev(comms_chain_t* h, const comms_c32* d_in_any, 
         return COMMS_OK;
     }
     COMMS_TRY(h->t1.reserve(n * sizeof(comms_c32)));
-    COMMS_TRY(h->t2.reserve(n * sizeof(comms_c32)));
     comms_c32* a = static_cast<comms_c32*>(h->t1.p);
-    comms_c32* b = static_cast<comms_c32*>(h->t2.p);
-    if (h->mixer_after) {
+    if (h->mixer_after) {  // FIR, then mixer + decimate in one pass over the kept samples only
         COMMS_TRY(comms_fir_run_dev(h->fir, d_in, n, a, s));
-        COMMS_TRY(comms_mixer_run_dev(h->mixer, a, n, b, s));
-    } else {
+        comms_c32* dst = static_cast<comms_c32*>(d_out);
+        if (h->fm_demod) {
+            COMMS_TRY(h->t3.reserve(n_dec * sizeof(comms_c32)));
+            dst = static_cast<comms_c32*>(h->t3.p);
+        }
+        COMMS_TRY(comms_mixer_run_decim_dev(h->mixer, a, n, h->rate, dst, s));
+        if (!h->fm_demod) return COMMS_OK;
+        return comms_fmdemod_run_dev(h->fm, dst, n_dec, static_cast<float*>(d_out), s);
+    }
+    COMMS_TRY(h->t2.reserve(n * sizeof(comms_c32)));
+    comms_c32* b = static_cast<comms_c32*>(h->t2.p);
+    {
         COMMS_TRY(chain_flush_raw_state(h));
         COMMS_TRY(comms_mixer_run_dev(h->mixer, d_in, n, a, s));
         COMMS_TRY(comms_fir_run_dev(h->fir, a, n, b, s));

@@ -28,6 +28,8 @@ extern "C" COMMS_INTERNAL comms_status_t comms_fir_run_fused_dev(comms_fir_t* h,
                                                   const void* fm_prev, void* fm_prev_new, void* stream);
 
 // the same chain on the time-domain decimating kernel (fir_decim.hip), where it applies
+extern "C" COMMS_INTERNAL comms_status_t comms_mixer_run_decim_dev(comms_mixer_t* h, const comms_c32* d_in, size_t n, size_t rate,
+                                                                 comms_c32* d_out, void* stream);
 extern "C" COMMS_INTERNAL int32_t comms_fir_decim_supported(const comms_fir_t* h, uint32_t rate);
 extern "C" COMMS_INTERNAL int32_t comms_fir_decim_supported_for(const comms_fir_t* h, uint32_t rate, int32_t fm_demod, int32_t can_fuse);
 extern "C" COMMS_INTERNAL comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t n, void* d_out,

@@ -71,6 +71,23 @@ __global__ __launch_bounds__(256) void mixer_kernel(const float2* __restrict__ i
     }
 }
 
+// MixerNode -> DecimateNode in one pass: out[j] = mix(in[j * rate]) with the oscillator phase of sample j * rate --
+// only the kept samples are mixed and only their sectors are read (the four-kernel chain with the mixer behind the
+// FIR: 40 + 23 us for the two nodes at 2^24 samples and rate 8, 25 us for this).  Same arithmetic as mixer_kernel.
+__global__ __launch_bounds__(256) void mix_decimate_kernel(const float2* __restrict__ in, float2* __restrict__ out,
+                                                           size_t n_out, size_t rate, uint64_t turns0, uint64_t frac,
+                                                           double sweep_c, double sweep_s) {
+    const size_t nthreads = static_cast<size_t>(gridDim.x) * blockDim.x;
+    const size_t gid = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= n_out) return;
+    double c0, s0;
+    rotor_at(turns0 + static_cast<uint64_t>(gid * rate) * frac, c0, s0);
+    for (size_t j = gid; j < n_out; j += nthreads) {
+        out[j] = mix1(in[j * rate], c0, s0);
+        rot_step(c0, s0, sweep_c, sweep_s);
+    }
+}
+
 // =============================================================== decimate / upsample
 // Reference: resample_node.rs:53-65 / :120-131.  Byte-exact copies of a Copy type.
 template <typename V>
@@ -322,6 +339,28 @@ comms_status_t comms_mixer_run_dev(comms_mixer_t* h, const comms_c32* d_in, size
         mixer_kernel<1><<<dim3(blocks), dim3(256), 0, s>>>(in, o, n, h->turns, h->frac, sc, ss, dc, ds);
     h->toc(s);
     COMMS_TRY(launch_ok("mixer_kernel"));
+    h->turns += static_cast<uint64_t>(n) * h->frac;
+    return COMMS_OK;
+}
+
+// internal (chain.hip): MixerNode over n samples followed by DecimateNode(rate), n a multiple of rate
+comms_status_t comms_mixer_run_decim_dev(comms_mixer_t* h, const comms_c32* d_in, size_t n, size_t rate,
+                                         comms_c32* d_out, void* stream) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG((d_in && d_out) || !n, "NULL device pointer");
+    COMMS_ARG(rate >= 1 && n % rate == 0, "n must be a multiple of the rate");
+    COMMS_TRY(use_device(h->device));
+    if (!n) return COMMS_OK;
+    hipStream_t s = h->pick(stream);
+    const size_t n_out = n / rate;
+    unsigned blocks = grid_for(n_out, 256, 8 * kNumCU);
+    double sc, ss;
+    host_rotor(static_cast<uint64_t>(blocks) * 256u * rate * h->frac, sc, ss);
+    h->tic(s);
+    mix_decimate_kernel<<<dim3(blocks), dim3(256), 0, s>>>(reinterpret_cast<const float2*>(d_in), reinterpret_cast<float2*>(d_out),
+                                                         n_out, rate, h->turns, h->frac, sc, ss);
+    h->toc(s);
+    COMMS_TRY(launch_ok("mix_decimate_kernel"));
     h->turns += static_cast<uint64_t>(n) * h->frac;
     return COMMS_OK;
 }
