@@ -877,6 +877,49 @@ def test_fm_chain_with_the_demodulator_as_its_own_kernel(c, n_taps, rate, after)
     assert node2.fm_prev == p
 
 
+@pytest.mark.parametrize("fm", [False, True])
+@pytest.mark.parametrize("after", [False, True])
+@pytest.mark.parametrize("n_taps,rate", [(300, 8), (777, 16), (2500, 5)])
+def test_chain_beyond_257_taps(c, n_taps, rate, after, fm):
+    """Long filters: the chain is a series of launches (4096- / 16384-point overlap-save FIR, mixer + decimator,
+    demodulator) with the reference nodes' results; state and phase carried across calls."""
+    n = 4096 * rate * 3
+    x = fm_stream(n) if fm else rand_c(np.random.default_rng(n_taps), n)
+    taps = lowpass_taps(n_taps, 1 / (2.5 * rate))
+    node = c.ChainNode(0.3, 0.1, taps, rate, fm, mixer_after_fir=after)
+    assert not node.fused
+    ost, om, ofm = oracle.default_state(taps), oracle.Mixer(0.1, 0.3), oracle.FM()
+
+    def ref(seg):
+        if after:
+            return oracle.decimate(om.mix(oracle.batch_fir(seg, taps, ost, norotate=True)), rate)
+        return oracle.decimate(oracle.batch_fir(om.mix(seg), taps, ost, norotate=True), rate)
+
+    cuts = [0, 4096 * rate, 4096 * rate + 7 * rate, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        y = ref(x[a:b])
+        got = node.run(x[a:b])
+        if fm:
+            w = ofm.demod(y)
+            mag = np.minimum(np.abs(y), np.abs(np.concatenate([[1.0], y[:-1]])))
+            ok = mag > 0.05
+            assert np.max(circ(got.astype(np.float64) - w)[ok], initial=0.0) <= 1e-4, (a, b)
+        else:
+            fir_close(got, y, taps, x)
+    # checkpoint: a second node restored from the first one's state continues identically
+    node2 = c.ChainNode(0.3, 0.1, taps, rate, fm, mixer_after_fir=after)
+    node2.set_fir_state(node.fir_state(n_taps))
+    node2.phase = node.phase
+    if fm:
+        node2.fm_prev = node.fm_prev
+    tail = x[:512 * rate]
+    g1, g2 = node.run(tail), node2.run(tail)
+    if fm:
+        assert np.max(circ(g1.astype(np.float64) - g2.astype(np.float64))) <= 1e-4
+    else:
+        fir_close(g2, g1, taps, tail)
+
+
 @pytest.mark.parametrize("rate", [2, 3, 4, 5, 6, 8, 10, 12, 16])
 def test_time_domain_decimating_chain_kernel(c, rate):
     """fir_decim_kernel on every instantiated rate: real and complex taps, tap counts around the
