@@ -202,6 +202,89 @@ def test_config5_full_shard_2p27_second_rank(c):
         fir_close(y[a:a + 3000].cpu().numpy(), want, taps, xs)
 
 
+@pytest.mark.parametrize("n_taps,lg,spacing,algo", [(255, 24, 1000, "FIR_OS1024"), (1025, 24, 3000, "FIR_OS4096"),
+                                                   (4097, 27, 50000, "FIR_OS16K"), (63, 22, 257, "FIR_OS1024")])
+def test_fir_full_size_impulse_comb_every_output(c, n_taps, lg, spacing, algo):
+    """Size-independent property at the BASELINE sizes, checked on EVERY output sample (the oracle comparisons
+    above look through windows): a comb of complex impulses further apart than the filter is long must come out as
+    copies of the taps, a_i * h[k] at p_i + k and (numerically) zero everywhere else -- whatever segment, wave or
+    workgroup a sample fell to.  fir.rs:87-102 is linear and time-invariant."""
+    import torch
+
+    n = 1 << lg
+    rng = np.random.default_rng(lg + n_taps)
+    k = np.arange(n_taps) - n_taps // 2
+    taps = ((0.25 * np.sinc(0.25 * k) * np.hamming(n_taps)) * np.exp(0.3j * k)).astype(np.complex64)
+    assert spacing > n_taps
+    pos = np.arange(0, n - spacing, spacing, dtype=np.int64)      # base + offset + n_taps <= base + spacing <= n
+    pos += rng.integers(0, spacing - n_taps, pos.size)            # irregular: every phase of a segment gets hit
+    assert int(pos.max()) + n_taps <= n
+    amp = (rng.uniform(0.5, 1.0, pos.size) * np.exp(2j * np.pi * rng.uniform(0, 1, pos.size))).astype(np.complex64)
+    dev = "cuda:0"
+    x = torch.zeros(n, dtype=torch.complex64, device=dev)
+    x[torch.from_numpy(pos).to(dev)] = torch.from_numpy(amp).to(dev)
+    node = c.BatchFirNode(taps)
+    assert node.algo_for(n) == getattr(c, algo)
+    y = torch.empty_like(x)
+    node.run_dev(x.data_ptr(), n, y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = torch.zeros(n, dtype=torch.complex64, device=dev)
+    ht = torch.from_numpy(taps).to(dev)
+    pt, at = torch.from_numpy(pos).to(dev), torch.from_numpy(amp).to(dev)
+    for k0 in range(0, n_taps, 64):                              # place the taps 64 at a time (bounded index tensors)
+        kk = torch.arange(k0, min(k0 + 64, n_taps), device=dev)
+        idx = (pt[:, None] + kk[None, :]).reshape(-1)
+        want[idx] = (at[:, None] * ht[kk][None, :]).reshape(-1)
+    err = float((y - want).abs().max())
+    assert err <= TOL * float(np.sum(np.abs(taps))), err
+
+
+@pytest.mark.parametrize("n_taps,rate,lg,after,kernel", [(255, 8, 24, True, "time"), (127, 8, 26, False, "time"),
+                                                         (63, 5, 24, False, "time"), (255, 8, 24, True, "freq"),
+                                                         (127, 3, 24, False, "freq"), (600, 16, 24, False, "auto")])
+def test_chain_full_size_impulse_comb_every_output(c, n_taps, rate, lg, after, kernel):
+    """The same property through the fused mixer / FIR / decimate chains at the BASELINE sizes (without the
+    demodulator, which is not linear): impulse a_i at p_i comes out as a_i h[jR - p_i] times the oscillator's
+    phase -- of sample p_i with the mixer in front, of sample jR with the mixer behind -- on every kept output."""
+    import torch
+
+    n = (1 << lg) // rate * rate
+    rng = np.random.default_rng(lg + n_taps + rate)
+    k = np.arange(n_taps) - n_taps // 2
+    taps = (0.25 * np.sinc(0.25 * k / rate * 2) * np.hamming(n_taps)).astype(np.float32).astype(np.complex64)
+    spacing = 4 * n_taps + 37
+    pos = np.arange(0, n - spacing, spacing, dtype=np.int64)
+    pos += rng.integers(0, spacing - n_taps, pos.size)
+    amp = (rng.uniform(0.5, 1.0, pos.size) * np.exp(2j * np.pi * rng.uniform(0, 1, pos.size))).astype(np.complex64)
+    dev = "cuda:0"
+    x = torch.zeros(n, dtype=torch.complex64, device=dev)
+    pt, at = torch.from_numpy(pos).to(dev), torch.from_numpy(amp).to(dev)
+    x[pt] = at
+    dphase, phase = 2 * np.pi * 0.05, 0.3
+    node = c.ChainNode(dphase, phase, taps, rate, False, mixer_after_fir=after, kernel=kernel)
+    if kernel != "auto":
+        assert node.kernel == kernel
+    y = torch.empty(n // rate, dtype=torch.complex64, device=dev)
+    node.run_dev(x.data_ptr(), n, y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    # full-rate expectation (complex128 on the device), then every rate-th sample
+    want = torch.zeros(n, dtype=torch.complex128, device=dev)
+    ht = torch.from_numpy(taps.astype(np.complex128)).to(dev)
+    a128 = at.to(torch.complex128)
+    if not after:   # the impulse carries the phase of its own sample
+        a128 = a128 * torch.exp(1j * (phase + dphase * pt.to(torch.float64)))
+    for k0 in range(0, n_taps, 64):
+        kk = torch.arange(k0, min(k0 + 64, n_taps), device=dev)
+        idx = (pt[:, None] + kk[None, :]).reshape(-1)
+        want[idx] = (a128[:, None] * ht[kk][None, :]).reshape(-1)
+    want = want[::rate]
+    if after:       # the kept outputs are mixed with the phase of THEIR sample
+        j = torch.arange(n // rate, device=dev, dtype=torch.float64) * rate
+        want = want * torch.exp(1j * (phase + dphase * j))
+    err = float((y.to(torch.complex128) - want).abs().max())
+    assert err <= 2e-5 * float(np.sum(np.abs(taps))), err
+
+
 def test_fir_auto_selection_and_errors(c):
     taps = np.ones(255, np.complex64)
     node = c.BatchFirNode(taps)
