@@ -285,6 +285,34 @@ def test_chain_full_size_impulse_comb_every_output(c, n_taps, rate, lg, after, k
     assert err <= 2e-5 * float(np.sum(np.abs(taps))), err
 
 
+@pytest.mark.parametrize("n_taps,rate,lg,kernel", [(127, 8, 26, "time"), (63, 5, 24, "time"), (255, 8, 24, "time"),
+                                                   (127, 8, 24, "freq"), (255, 7, 24, "freq"), (600, 16, 24, "auto")])
+def test_fm_chain_full_size_tone_every_output(c, n_taps, rate, lg, kernel):
+    """Every output of a full-size FM chain (config 3's shape at 2^26 among them): a complex tone of frequency w
+    through mixer (dphi) -> low-pass -> /R -> FM::demod is the constant R (w + dphi) once the filter has filled --
+    whichever tile computed the sample and wherever the demodulator's previous sample came from."""
+    import torch
+
+    n = (1 << lg) // rate * rate
+    dev = "cuda:0"
+    w, dphi = 2 * np.pi * 0.011 / rate * 8, 2 * np.pi * 0.004 / rate * 8
+    t = torch.arange(n, device=dev, dtype=torch.float64)
+    x = torch.polar(torch.ones(n, device=dev, dtype=torch.float64), w * t + 0.2).to(torch.complex64)
+    del t
+    taps = lowpass_taps(n_taps, 1 / (2.5 * rate))
+    node = c.ChainNode(dphi, 0.7, taps, rate, True, kernel=kernel)
+    if kernel != "auto":
+        assert node.kernel == kernel
+    y = torch.empty(n // rate, dtype=torch.float32, device=dev)
+    node.run_dev(x.data_ptr(), n, y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = rate * (w + dphi)
+    assert abs(want) < np.pi
+    skip = n_taps // rate + 2                                    # the filter's start-up transient
+    err = float((y[skip:].to(torch.float64) - want).abs().max())
+    assert err <= 2e-4, err
+
+
 def test_fir_auto_selection_and_errors(c):
     taps = np.ones(255, np.complex64)
     node = c.BatchFirNode(taps)
