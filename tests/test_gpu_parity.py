@@ -313,6 +313,60 @@ def test_fm_chain_full_size_tone_every_output(c, n_taps, rate, lg, kernel):
     assert err <= 2e-4, err
 
 
+@pytest.mark.parametrize("sps,n_taps", [(4, 63), (8, 255), (5, 40), (7, 33)])
+def test_pulse_shaper_full_size_impulse_comb_every_output(c, sps, n_taps):
+    """PulseNode (pulse.rs:82-92: zero-stuff by sam_per_sym, then the FIR) at 2^24 output samples, every output:
+    isolated symbols come out as copies of the taps at sps * position, zero elsewhere (polyphase kernels for
+    sps 4 / 8 / 5, the generic kernel for 7)."""
+    import torch
+
+    n_sym = (1 << 24) // sps
+    rng = np.random.default_rng(sps)
+    taps = (np.hamming(n_taps) * np.exp(0.1j * np.arange(n_taps))).astype(np.complex64)
+    spacing = n_taps // sps + 5                                   # in symbols: the copies of the taps do not overlap
+    pos = np.arange(0, n_sym - spacing, spacing, dtype=np.int64)
+    amp = (rng.uniform(0.5, 1.0, pos.size) * np.exp(2j * np.pi * rng.uniform(0, 1, pos.size))).astype(np.complex64)
+    dev = "cuda:0"
+    sym = torch.zeros(n_sym, dtype=torch.complex64, device=dev)
+    pt, at = torch.from_numpy(pos).to(dev), torch.from_numpy(amp).to(dev)
+    sym[pt] = at
+    y = torch.empty(n_sym * sps, dtype=torch.complex64, device=dev)
+    c.PulseNode(taps, sps).run_dev(sym.data_ptr(), n_sym, y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = torch.zeros(n_sym * sps, dtype=torch.complex64, device=dev)
+    ht = torch.from_numpy(taps).to(dev)
+    kk = torch.arange(n_taps, device=dev)
+    idx = (pt[:, None] * sps + kk[None, :]).reshape(-1)
+    keep = idx < n_sym * sps
+    want[idx[keep]] = (at[:, None] * ht[None, :]).reshape(-1)[keep]
+    assert float((y - want).abs().max()) <= 1e-6 * float(np.sum(np.abs(taps)))
+
+
+@pytest.mark.parametrize("rate", [2, 8, 5])
+def test_resample_full_size_bit_exact(c, rate):
+    """DecimateNode / UpsampleNode at 2^24 Complex<f32> samples against plain indexing, bit for bit."""
+    import torch
+
+    n = 1 << 24
+    dev = "cuda:0"
+    s = torch.cuda.current_stream().cuda_stream
+    x = torch.empty(n, dtype=torch.complex64, device=dev)
+    c.synth_iq_dev(x.data_ptr(), n, 0, 77)
+    xi = torch.view_as_real(x).view(torch.int32)
+    m = (n + rate - 1) // rate
+    d = torch.empty(m, dtype=torch.complex64, device=dev)
+    assert c.DecimateNode(rate).run_dev(x.data_ptr(), n, 8, d.data_ptr(), s) == m
+    torch.cuda.synchronize()
+    assert torch.equal(torch.view_as_real(d).view(torch.int32), xi[::rate])
+    n_in = n // rate
+    u = torch.full((n_in * rate,), float("nan"), dtype=torch.complex64, device=dev)
+    assert c.UpsampleNode(rate).run_dev(x.data_ptr(), n_in, 8, u.data_ptr(), s) == n_in * rate
+    torch.cuda.synchronize()
+    ui = torch.view_as_real(u).view(torch.int32).reshape(n_in, rate, 2)
+    assert torch.equal(ui[:, 0, :], xi[:n_in])
+    assert int(torch.count_nonzero(ui[:, 1:, :])) == 0
+
+
 def test_fir_auto_selection_and_errors(c):
     taps = np.ones(255, np.complex64)
     node = c.BatchFirNode(taps)
