@@ -831,6 +831,35 @@ def test_fft_above_2p20_columns_rows_transpose(c, logn, batch, inverse):
     assert torch.equal(torch.view_as_real(x), torch.view_as_real(y))
 
 
+@pytest.mark.parametrize("logn,batch", [(6, 4096), (10, 512), (14, 64), (17, 16), (20, 8), (22, 2)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_fft_tones_every_bin(c, logn, batch, inverse):
+    """Every bin of every transform of a batch: transform b holds one complex tone of its own frequency k_b and
+    amplitude, so its spectrum is N a_b at bin k_b (N - k_b for the inverse direction's sign) and numerically
+    nothing anywhere else -- one case per FFT kernel family (in-register, one pass, column + row passes, 2^20
+    two-pass, columns + rows + transpose)."""
+    import torch
+
+    N = 1 << logn
+    dev = "cuda:0"
+    rng = np.random.default_rng(logn)
+    kb = rng.integers(0, N, batch)
+    amp = (rng.uniform(0.5, 1.0, batch) * np.exp(2j * np.pi * rng.uniform(0, 1, batch)))
+    t = torch.arange(N, device=dev, dtype=torch.float64)
+    kt = torch.from_numpy(kb).to(dev).to(torch.float64)
+    ang = 2 * np.pi * torch.remainder(kt[:, None] * t[None, :], N) / N          # exact reduction of k n mod N first
+    x = (torch.from_numpy(amp).to(dev)[:, None] * torch.polar(torch.ones_like(ang), ang)).to(torch.complex64).reshape(-1)
+    del ang
+    y = torch.empty_like(x)
+    c.FFTBatchNode(N, inverse).run_dev(x.data_ptr(), x.numel(), y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = torch.zeros(batch, N, dtype=torch.complex64, device=dev)
+    bins = torch.from_numpy((N - kb) % N if inverse else kb).to(dev)
+    want[torch.arange(batch, device=dev), bins] = torch.from_numpy((amp * N).astype(np.complex64)).to(dev)
+    err = float((y.reshape(batch, N) - want).abs().max())
+    assert err <= 2e-6 * N * np.sqrt(logn), (err, N)
+
+
 def test_fft_bluestein_on_a_padded_length_above_2p20(c):
     """A non-power-of-two length whose chirp-z padding (2^21) runs on the columns / rows / transpose path,
     forward and inverse, against numpy's f64 FFT."""
