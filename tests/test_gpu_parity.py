@@ -9,10 +9,14 @@ relative for f32 FIR/FFT/mixer), made precise:
   FM     |d| <= 1e-5 rad on the circle (no tolerance in the reference: no test)
   decimate / upsample / pulse-on-integers: bit-exact
 """
+import os
+
 import numpy as np
 import pytest
 
 import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -1112,6 +1116,36 @@ def test_chain_beyond_257_taps(c, n_taps, rate, after, fm):
         assert np.max(circ(g1.astype(np.float64) - g2.astype(np.float64))) <= 1e-4
     else:
         fir_close(g2, g1, taps, tail)
+
+
+def test_fm_chain_demodulating_inside_the_overlap_save_kernel_still_works():
+    """COMMS_CHAIN_FM_SEPARATE=0 brings back the form that demodulates inside the overlap-save kernel (kept for the
+    comparison recorded in profiles/r02_bench_chain_rates.txt).  The switch is read once per process: own process."""
+    import subprocess
+    import sys
+
+    code = r'''
+import sys; sys.path.insert(0, %r)
+import numpy as np, comms_rs_amd as c, oracle
+rate, n = 5, 768 * 5 * 4
+t = np.arange(n)
+x = np.exp(1j * (0.05 * t + 0.5 * np.sin(2 * np.pi * t / 4096))).astype(np.complex64)
+k = np.arange(63) - 31
+taps = (0.16 * np.sinc(0.16 * k) * np.hamming(63)).astype(np.float32).astype(np.complex64)
+node = c.ChainNode(0.3, 0.1, taps, rate, True, kernel="freq")
+assert node.kernel == "freq"
+ost, om, ofm = oracle.default_state(taps), oracle.Mixer(0.1, 0.3), oracle.FM()
+for a, b in ((0, 768 * rate), (768 * rate, n)):
+    y = oracle.decimate(oracle.batch_fir(om.mix(x[a:b]), taps, ost, norotate=True), rate)
+    w = ofm.demod(y)
+    d = np.abs(node.run(x[a:b]).astype(np.float64) - w); d = np.minimum(d, 2 * np.pi - d)
+    ok = np.minimum(np.abs(y), np.abs(np.concatenate([[1.0], y[:-1]]))) > 0.05
+    assert d[ok].max() <= 1e-4, d[ok].max()
+print("ok")
+''' % ROOT
+    env = dict(os.environ, COMMS_CHAIN_FM_SEPARATE="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
 
 @pytest.mark.parametrize("rate", [2, 3, 4, 5, 6, 8, 10, 12, 16])
