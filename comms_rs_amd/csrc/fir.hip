@@ -181,8 +181,8 @@ __device__ __forceinline__ void lds_read16_contig(const cf* __restrict__ p, cf (
     }
 }
 
-template <int WPS>
-__global__ __launch_bounds__(256, WPS) void fir_os4096_kernel(const float2* __restrict__ in,
+template <int WPS, class In = const float2*>
+__global__ __launch_bounds__(256, WPS) void fir_os4096_kernel(In in,
                                                             const float2* __restrict__ hist,
                                                             int hist_len, float2* __restrict__ out,
                                                             size_t n, int hblk, size_t nseg,
@@ -1554,7 +1554,9 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
     const float2* hist = h->d_hist[h->cur];
     float2* nh = h->d_hist[h->cur ^ 1];  // the kernel's workgroup 0 advances the history into it
     const int algo = fir_pick(h, n);
-    const bool fused_fmt = algo == COMMS_FIR_DIRECT || algo == COMMS_FIR_OS1024;  // their load stages read raw IQ
+    // kernels whose load stages read raw IQ (the 4096-point one in its default two-workgroups-per-CU build)
+    static const int os4096_wps = tune_int("COMMS_OS4096_WPS", 2);
+    const bool fused_fmt = algo == COMMS_FIR_DIRECT || algo == COMMS_FIR_OS1024 || (algo == COMMS_FIR_OS4096 && os4096_wps == 2);
     const float2* in = nullptr;  // Complex<f32> view of the input (the conversion pass, where the kernel needs one)
     if (!fused_fmt || h->in_fmt == COMMS_IQ_C32) COMMS_TRY(fir_converted_input(h, d_in, n, s, &in));
     if (algo == COMMS_FIR_DIRECT) {
@@ -1619,7 +1621,7 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
         // persistent grid: WPS workgroups per CU (one wave of each per SIMD), segments dealt round-robin
         // two workgroups per CU: at three the kernel no longer fits its 170-register budget (24 spilled registers
         // since the input views were templated) and runs 4-21 % slower (300-511 taps at 2^24: 86.8 -> 68.4 us)
-        static const int wps = tune_int("COMMS_OS4096_WPS", 2);
+        const int wps = os4096_wps;
         // segments b, b + G, ... per workgroup (the chip sweeps the stream as one window: 2-4 % faster at 2^24 ...
         // 2^26 than a contiguous run per workgroup, 1 % at 2^28); 0 restores the runs
         static const int il = tune_int("COMMS_OS4096_INTERLEAVE", 1);
@@ -1633,6 +1635,12 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
                 fir_os4096_kernel<4><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, pt * OS_PART, pt ? 1 : 0, il);
             else if (wps == 3)
                 fir_os4096_kernel<3><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, pt * OS_PART, pt ? 1 : 0, il);
+            else if (h->in_fmt == COMMS_IQ_I16)
+                fir_os4096_kernel<2, InI16><<<dim3(blocks), dim3(256), 0, s>>>(InI16{static_cast<const short2*>(d_in), h->in_scale}, hist, h->n_eff, o, n,
+                                                                              h->hblk, nseg, tb, nh, pt * OS_PART, pt ? 1 : 0, il);
+            else if (h->in_fmt == COMMS_IQ_U8)
+                fir_os4096_kernel<2, InU8><<<dim3(blocks), dim3(256), 0, s>>>(InU8{static_cast<const uchar2*>(d_in)}, hist, h->n_eff, o, n, h->hblk, nseg,
+                                                                             tb, nh, pt * OS_PART, pt ? 1 : 0, il);
             else
                 fir_os4096_kernel<2><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, pt * OS_PART, pt ? 1 : 0, il);
         }
