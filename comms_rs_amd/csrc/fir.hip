@@ -1554,9 +1554,9 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
     const float2* hist = h->d_hist[h->cur];
     float2* nh = h->d_hist[h->cur ^ 1];  // the kernel's workgroup 0 advances the history into it
     const int algo = fir_pick(h, n);
-    // kernels whose load stages read raw IQ (the 4096-point one in its default two-workgroups-per-CU build)
-    static const int os4096_wps = tune_int("COMMS_OS4096_WPS", 2);
-    const bool fused_fmt = algo == COMMS_FIR_DIRECT || algo == COMMS_FIR_OS1024 || (algo == COMMS_FIR_OS4096 && os4096_wps == 2);
+    // kernels whose load stages read raw IQ (the 4096-point one in its default three-workgroups-per-CU build)
+    static const int os4096_wps = tune_int("COMMS_OS4096_WPS", 3);
+    const bool fused_fmt = algo == COMMS_FIR_DIRECT || algo == COMMS_FIR_OS1024 || (algo == COMMS_FIR_OS4096 && os4096_wps == 3);
     const float2* in = nullptr;  // Complex<f32> view of the input (the conversion pass, where the kernel needs one)
     if (!fused_fmt || h->in_fmt == COMMS_IQ_C32) COMMS_TRY(fir_converted_input(h, d_in, n, s, &in));
     if (algo == COMMS_FIR_DIRECT) {
@@ -1618,9 +1618,12 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
         COMMS_TRY(fir_prepare_os(h));
         const size_t V = OSF - 256 * static_cast<size_t>(h->hblk);
         const size_t nseg = (n + V - 1) / V;
-        // persistent grid: WPS workgroups per CU (one wave of each per SIMD), segments dealt round-robin
-        // two workgroups per CU: at three the kernel no longer fits its 170-register budget (24 spilled registers
-        // since the input views were templated) and runs 4-21 % slower (300-511 taps at 2^24: 86.8 -> 68.4 us)
+        // persistent grid: WPS workgroups per CU (one wave of each per SIMD), segments dealt round-robin.
+        // Three workgroups per CU with the samples read as 4-byte loads (InC32Split, or the raw i16 / u8 views): with
+        // 8-byte loads the kernel's load stage needs ~200 VGPRs, which at three workgroups (budget 170) spilled 24
+        // registers and cost 4-21 %, while two workgroups leave the CU short of waves; with 4-byte loads it fits in 130
+        // (511 taps at 2^24: 86.8 us spilling, 69.7 at two workgroups, 66.6 now; 2049 taps: 107.5 / 105.7 / 97.5).
+        // COMMS_OS4096_WPS=2 / 4 select the 8-byte-load builds (raw input then takes a conversion pass).
         const int wps = os4096_wps;
         // segments b, b + G, ... per workgroup (the chip sweeps the stream as one window: 2-4 % faster at 2^24 ...
         // 2^26 than a contiguous run per workgroup, 1 % at 2^28); 0 restores the runs
@@ -1631,18 +1634,20 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
         for (int pt = 0; pt < h->n_part; ++pt) {
             OsTables tb{reinterpret_cast<const cf*>(h->d_tw1), reinterpret_cast<const cf*>(h->d_tw2),
                         reinterpret_cast<const cf*>(h->d_hparts[pt])};
+            const int dl = pt * OS_PART, acc = pt ? 1 : 0;
             if (wps == 4)
-                fir_os4096_kernel<4><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, pt * OS_PART, pt ? 1 : 0, il);
-            else if (wps == 3)
-                fir_os4096_kernel<3><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, pt * OS_PART, pt ? 1 : 0, il);
+                fir_os4096_kernel<4><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, dl, acc, il);
+            else if (wps == 2)
+                fir_os4096_kernel<2><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, dl, acc, il);
             else if (h->in_fmt == COMMS_IQ_I16)
-                fir_os4096_kernel<2, InI16><<<dim3(blocks), dim3(256), 0, s>>>(InI16{static_cast<const short2*>(d_in), h->in_scale}, hist, h->n_eff, o, n,
-                                                                              h->hblk, nseg, tb, nh, pt * OS_PART, pt ? 1 : 0, il);
+                fir_os4096_kernel<3, InI16><<<dim3(blocks), dim3(256), 0, s>>>(InI16{static_cast<const short2*>(d_in), h->in_scale}, hist, h->n_eff, o, n,
+                                                                              h->hblk, nseg, tb, nh, dl, acc, il);
             else if (h->in_fmt == COMMS_IQ_U8)
-                fir_os4096_kernel<2, InU8><<<dim3(blocks), dim3(256), 0, s>>>(InU8{static_cast<const uchar2*>(d_in)}, hist, h->n_eff, o, n, h->hblk, nseg,
-                                                                             tb, nh, pt * OS_PART, pt ? 1 : 0, il);
+                fir_os4096_kernel<3, InU8><<<dim3(blocks), dim3(256), 0, s>>>(InU8{static_cast<const uchar2*>(d_in)}, hist, h->n_eff, o, n, h->hblk, nseg,
+                                                                             tb, nh, dl, acc, il);
             else
-                fir_os4096_kernel<2><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, pt * OS_PART, pt ? 1 : 0, il);
+                fir_os4096_kernel<3, InC32Split><<<dim3(blocks), dim3(256), 0, s>>>(InC32Split{reinterpret_cast<const float*>(in)}, hist, h->n_eff, o, n,
+                                                                                   h->hblk, nseg, tb, nh, dl, acc, il);
         }
         h->toc(s);
         COMMS_TRY(launch_ok("fir_os4096_kernel"));
