@@ -29,7 +29,10 @@ Other BASELINE configs (same contract, one JSON line each):
   --backend gloo --n-log2 K   rehearsal aid: CPU-side messages, ranks may share a GPU, smaller shards.
 
     python bench.py --gpus N --steps K --warmup W
+        N > 1 without RANK in the environment: this process only spawns N rank processes
+        (child processes, never exec; it has not touched the GPU) and relays rank 0's line.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+        (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, one rank per GPU)
 """
 import argparse
 import json
@@ -206,6 +209,19 @@ class Ctx:
             return float(t.item())
         return v
 
+    def over_ranks(self, v):
+        """The value of `v` on every rank, as a list indexed by rank (all ranks get it)."""
+        if self.world == 1:
+            return [float(v)]
+        t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=self.comm_dev)
+        parts = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t)
+        return [float(p.item()) for p in parts]
+
+    def world_size_seen(self):
+        """What the process group itself reports (1 when no group was needed)."""
+        return self.dist.get_world_size() if self.world > 1 else 1
+
     def all_ok(self, ok, what):
         """Fail loudly on every rank when any rank's self-check failed."""
         if self.world > 1:
@@ -293,6 +309,14 @@ class Ctx:
         del full
 
 
+def rank_report(ctx, kernel_ms):
+    """Collective: what the process group saw -- its own world size and every rank's mean kernel time."""
+    per = ctx.over_ranks(kernel_ms)
+    return {"world_size_seen": ctx.world_size_seen(), "backend": ctx.args.backend if ctx.world > 1 else None,
+            "kernel_ms_per_rank": [round(v, 5) for v in per], "kernel_ms_min": round(min(per), 5),
+            "kernel_ms_max": round(max(per), 5)}
+
+
 def fir_chain_pass(ctx, n, first_index, steps, warmup, algo="auto"):
     """The metric's chain, node by node, over this rank's shard [first_index, first_index + n) of the
     stream: 255-tap BatchFirNode -> MixerNode -> DecimateNode.  Returns timings + the nodes' facts."""
@@ -375,8 +399,9 @@ def fir_chain_pass(ctx, n, first_index, steps, warmup, algo="auto"):
     chain = c.ChainNode(MIX_DPHASE, mix_phase, taps, DEC_RATE, False, device=ctx.local_rank, mixer_after_fir=True)
     zf = torch.empty_like(z)
     fused_elapsed = ctx.timed(lambda: chain.run_dev(x.data_ptr(), n, zf.data_ptr(), s), steps, max(warmup, 1))
-    res = {"elapsed": elapsed, "fused_elapsed": fused_elapsed,
-           "kernel_ms": float(np.mean(kms)) if kms.size else float("nan"), "launches_timed": int(kms.size),
+    kernel_ms = float(np.mean(kms)) if kms.size else float("nan")
+    res = {"elapsed": elapsed, "fused_elapsed": fused_elapsed, "ranks": rank_report(ctx, kernel_ms),
+           "kernel_ms": kernel_ms, "launches_timed": int(kms.size),
            "algo": fir.kernel_for(n), "fused": chain.fused, "fused_kernel": chain.kernel, "transfer": transfer}
     del x, y, z, zf, fir, mixer, chain
     torch.cuda.empty_cache()
@@ -414,6 +439,7 @@ def run_config2(ctx):
         "value": round(total / head["elapsed"] / 1e6, 1),
         "unit": "Msamples/s",
         "n_gpus": world,
+        "world_size_seen": head["ranks"]["world_size_seen"],
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(head["elapsed"] / args.steps * 1e3, 4),
@@ -433,6 +459,7 @@ def run_config2(ctx):
                      "traffic": pmc_traffic(algo, n),
                      "kernel_ms": round(kernel_ms, 5), "launches_timed": head["launches_timed"],
                      "algorithmic_bytes_per_launch": FIR_BYTES_PER_SAMPLE * n},
+        "ranks": head["ranks"],
     }
     out["fused_chain"] = {"value": round(total / head["fused_elapsed"] / 1e6, 1), "unit": "Msamples/s",
                           "ms_per_step": round(head["fused_elapsed"] / args.steps * 1e3, 4), "fused": head["fused"],
@@ -451,6 +478,7 @@ def run_config2(ctx):
             "fused_chain_value": round(st["total"] * st["steps"] / st["fused_elapsed"] / 1e6, 1),
             "fir_kernel": st["algo"], "fir_kernel_ms": round(st["kernel_ms"], 5),
             "fir_hbm_GBps": round(ach, 1), "fir_frac_of_peak": round(ach / HBM_PEAK_GBS, 4),
+            "fir_kernel_ms_per_rank": st["ranks"]["kernel_ms_per_rank"],
             "note": "%.2f GiB of FIR input + output per GPU (HBM-resident once this is far past the 256 MiB "
                     "Infinity Cache)" % (16.0 * st["per"] / 2 ** 30)}
         if st["transfer"]:
@@ -524,9 +552,10 @@ def run_config3(ctx):
     kms = timer.read_ms()
     timer.close()
     ctx.collect(out, transfer)
+    kernel_ms = float(np.mean(kms))
+    ranks = rank_report(ctx, kernel_ms)
     if rank != 0:
         return None
-    kernel_ms = float(np.mean(kms))
     ach = C3_BYTES_PER_SAMPLE * n / (kernel_ms * 1e-3) / 1e9
     res = {"metric": "Msamples/s Complex<f32> through mixer->127-tap FIR->decimate-by-8->FM demod (BASELINE config 3)",
            "value": round(float(world) * n * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s", "n_gpus": world,
@@ -541,6 +570,7 @@ def run_config3(ctx):
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                         "traffic": None, "kernel_ms": round(kernel_ms, 5), "launches_timed": int(kms.size),
                         "algorithmic_bytes_per_launch": C3_BYTES_PER_SAMPLE * n}}
+    res["world_size_seen"], res["ranks"] = ranks["world_size_seen"], ranks
     if transfer:
         res["transfer"] = transfer
     return res
@@ -599,9 +629,10 @@ def run_config5(ctx):
     kms = timer.read_ms()
     timer.close()
     ctx.collect(y, transfer)
+    kernel_ms = float(np.mean(kms))
+    ranks = rank_report(ctx, kernel_ms)
     if rank != 0:
         return None
-    kernel_ms = float(np.mean(kms))
     ach = FIR_BYTES_PER_SAMPLE * n / (kernel_ms * 1e-3) / 1e9
     res = {"metric": "Msamples/s Complex<f32> through the 4097-tap overlap-save FIR (BASELINE config 5)",
            "value": round(float(world) * n * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s", "n_gpus": world,
@@ -616,6 +647,7 @@ def run_config5(ctx):
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                         "kernel_ms": round(kernel_ms, 5), "launches_timed": int(kms.size),
                         "algorithmic_bytes_per_launch": FIR_BYTES_PER_SAMPLE * n}}
+    res["world_size_seen"], res["ranks"] = ranks["world_size_seen"], ranks
     if transfer:
         res["transfer"] = transfer
     return res
@@ -658,9 +690,10 @@ def run_config4(ctx):
     kms = timer.read_ms()
     timer.close()
     ctx.collect(y, transfer)
+    kernel_ms = float(np.mean(kms))
+    ranks = rank_report(ctx, kernel_ms)
     if rank != 0:
         return None
-    kernel_ms = float(np.mean(kms))
     ach = FFT_BYTES_PER_POINT * n / (kernel_ms * 1e-3) / 1e9
     res = {"metric": "Mpoints/s Complex<f32> through the 2^20-point FFT node, batch 4096 (BASELINE config 4)",
            "value": round(float(batch_total) * FFT_N * args.steps / elapsed / 1e6, 1), "unit": "Mpoints/s", "n_gpus": world,
@@ -673,9 +706,81 @@ def run_config4(ctx):
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                         "traffic": None, "kernel_ms": round(kernel_ms, 5), "launches_timed": int(kms.size),
                         "algorithmic_bytes_per_launch": FFT_BYTES_PER_POINT * n}}
+    res["world_size_seen"], res["ranks"] = ranks["world_size_seen"], ranks
     if transfer:
         res["transfer"] = transfer
     return res
+
+
+def free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no RANK in the environment: spawn the N rank processes
+    (this file again, one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torchrun would), relay
+    rank 0's JSON line and return the worst exit code.  Child processes only -- nothing is exec'ed -- and this
+    parent imports no torch and makes no HIP call, before or after."""
+    import signal
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["MASTER_PORT"] = str(free_port())
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        # rank 0's stdout is the JSON line; the other ranks print nothing there
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, left, stopped = 0, set(range(n)), set()
+    try:
+        while left:
+            for r in sorted(left):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                left.discard(r)
+                if code != 0 and r not in stopped:
+                    rc = rc or (code if code > 0 else 1)
+                    sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n" % (r, code))
+                    for q in left - stopped:  # the exact PIDs started above
+                        procs[q].send_signal(signal.SIGTERM)
+                        stopped.add(q)
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+            pr.wait()
+    return rc
+
+
+def launch_check(ctx_args):
+    """--launch-check: rendezvous only (gloo, CPU): every rank joins the group, the ranks sum their rank
+    numbers, rank 0 prints what the group saw.  Runs without a GPU: the test of the launcher itself."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    import torch
+    import torch.distributed as dist
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    assert world == ctx_args.gpus, "--gpus %d but WORLD_SIZE=%d" % (ctx_args.gpus, world)
+    seen, total = 1, 0
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        dist.all_reduce(t)
+        seen, total = dist.get_world_size(), int(t.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "world_size_seen": seen, "rank_sum": total,
+                          "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}), flush=True)
 
 
 def main():
@@ -694,7 +799,13 @@ def main():
     ap.add_argument("--algo", choices=["auto", "direct", "os1024", "os4096"], default="auto")
     # rehearsal aid: "gloo" runs the N>1 logic with CPU-side messages, ranks sharing the visible GPUs
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous of the N ranks only (gloo on the CPU), no GPU work: checks the launcher")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.launch_check:
+        return launch_check(args)
     if args.config != 2 and args.steps == 1000 and args.warmup == 50:
         args.steps, args.warmup = 20, 3   # the other configs' steps are 10-100x longer
 

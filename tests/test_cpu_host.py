@@ -273,3 +273,39 @@ def test_header_is_plain_c():
     hdr = os.path.join(ROOT, "include", "comms_hip.h")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
+
+
+def _bench(*argv, timeout=300):
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_launches_its_own_ranks(world):
+    """`python bench.py --gpus N` with no RANK in the environment spawns the N rank processes itself (children,
+    no exec) and relays rank 0's line: here the rendezvous-only mode, which needs no GPU.  The group must have
+    seen N ranks (the round-2 command died with `--gpus 2 but WORLD_SIZE=1`)."""
+    import json
+
+    r = _bench("--gpus", str(world), "--launch-check")
+    assert r.returncode == 0, r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout
+    d = json.loads(line[0])
+    assert d["n_gpus"] == world and d["world_size_seen"] == world and d["rank_sum"] == world * (world - 1) // 2
+
+
+def test_bench_rank_failure_is_the_exit_code():
+    """Without a GPU every rank of the real benchmark fails loudly (no CPU fallback); the launching parent
+    must report that -- not the old WORLD_SIZE assertion -- and exit non-zero without leaving ranks behind."""
+    r = _bench("--gpus", "2", "--backend", "gloo", "--n-log2", "20", "--stream-log2", "0")
+    import comms_rs_amd as c
+
+    if c.device_count() >= 1:
+        pytest.skip("a GPU is present: this is the CPU-box behaviour")
+    assert r.returncode != 0
+    assert "WORLD_SIZE=1" not in r.stderr
+    assert "no MI355X visible" in r.stderr or "COMMS_ERR_DEVICE" in r.stderr, r.stderr[-2000:]
