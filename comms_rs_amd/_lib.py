@@ -59,6 +59,7 @@ _PROTOS = {
     "comms_stream_create": [_i32, _pp],
     "comms_stream_synchronize": [_i32, _vp],
     "comms_stream_destroy": [_i32, _vp],
+    "comms_stream_pool_trim": [_i32],
     "comms_timer_create": [_sz, _i32, _pp],
     "comms_timer_reset": [_vp],
     "comms_timer_read": [_vp, _vp, _sz, _psz],
@@ -98,6 +99,8 @@ _PROTOS = {
     "comms_mixer_create": [_f64, _f64, _i32, _pp],
     "comms_mixer_run": [_vp, _vp, _sz, _vp],
     "comms_mixer_run_dev": [_vp, _vp, _sz, _vp, _vp],
+    "comms_mixer_run_f64": [_vp, _vp, _sz, _vp],
+    "comms_mixer_run_f64_dev": [_vp, _vp, _sz, _vp, _vp],
     "comms_mixer_get_phase": [_vp, C.POINTER(_f64)],
     "comms_mixer_set_phase": [_vp, _f64],
     "comms_mixer_destroy": [_vp],

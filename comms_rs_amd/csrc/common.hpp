@@ -229,14 +229,26 @@ struct Handle {
     bool launched = false;
     comms_status_t enter(void* s_arg, hipStream_t* out) {
         hipStream_t s = pick(s_arg);
-        if (launched && s != last_stream) COMMS_HIP_TRY(hipStreamSynchronize(last_stream));
+        if (launched && s != last_stream) COMMS_TRY(drain());
         last_stream = s;
         launched = true;
         *out = s;
         return COMMS_OK;
     }
     comms_status_t quiesce() {
-        if (launched) COMMS_HIP_TRY(hipStreamSynchronize(last_stream));
+        if (launched) COMMS_TRY(drain());
+        return COMMS_OK;
+    }
+    // Host wait for the launches pending on the stream the handle followed last.  Whatever the outcome the handle
+    // forgets that stream: a caller-owned stream that was destroyed meanwhile (against the header's lifetime rule)
+    // fails this ONE call and the handle goes on with the next stream it is given.
+    comms_status_t drain() {
+        hipStream_t s = last_stream;
+        launched = false;
+        last_stream = nullptr;
+        hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess)
+            return fail(COMMS_ERR_DEVICE, "draining the handle's previous stream: %s", hipGetErrorString(e));
         return COMMS_OK;
     }
     // The host-pointer form of a node: `launch(d_in, d_out)` runs the device form on this handle's

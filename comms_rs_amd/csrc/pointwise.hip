@@ -71,6 +71,23 @@ __global__ __launch_bounds__(256) void mixer_kernel(const float2* __restrict__ i
     }
 }
 
+// Mixer::mix::<f64> -- the instantiation the reference's own mixer tests use (src/mixer.rs:160-246, :250-336):
+// the casts to and from f64 are identities, so the output is the f64 product itself.  One double2 (16 B) per lane.
+__global__ __launch_bounds__(256) void mixer_f64_kernel(const double2* __restrict__ in, double2* __restrict__ out,
+                                                        size_t n, uint64_t turns0, uint64_t frac, double sweep_c,
+                                                        double sweep_s) {
+    const size_t nthreads = static_cast<size_t>(gridDim.x) * blockDim.x;
+    const size_t gid = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= n) return;
+    double c, s;
+    rotor_at(turns0 + static_cast<uint64_t>(gid) * frac, c, s);
+    for (size_t g = gid; g < n; g += nthreads) {
+        const double2 x = in[g];
+        out[g] = make_double2(x.x * c - x.y * s, x.x * s + x.y * c);
+        rot_step(c, s, sweep_c, sweep_s);
+    }
+}
+
 // MixerNode -> DecimateNode in one pass: out[j] = mix(in[j * rate]) with the oscillator phase of sample j * rate --
 // only the kept samples are mixed and only their sectors are read (the four-kernel chain with the mixer behind the
 // FIR: 40 + 23 us for the two nodes at 2^24 samples and rate 8, 25 us for this).  Same arithmetic as mixer_kernel.
@@ -372,6 +389,37 @@ comms_status_t comms_mixer_run(comms_mixer_t* h, const comms_c32* in, size_t n, 
     if (!n) return COMMS_OK;
     return h->run_host(in, n * sizeof(comms_c32), out, n * sizeof(comms_c32), [&](void* d_in, void* d_out) {
         return comms_mixer_run_dev(h, static_cast<const comms_c32*>(d_in), n, static_cast<comms_c32*>(d_out), COMMS_STREAM_HANDLE);
+    });
+}
+
+// MixerNode<f64> (src/mixer.rs:93-148 with T = f64): same handle, same oscillator, Complex<f64> samples
+comms_status_t comms_mixer_run_f64_dev(comms_mixer_t* h, const comms_c64* d_in, size_t n, comms_c64* d_out,
+                                       void* stream) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG((d_in && d_out) || !n, "NULL device pointer");
+    COMMS_ARG(((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0,
+              "Complex<f64> streams must be 16-byte aligned");
+    COMMS_TRY(use_device(h->device));
+    if (!n) return COMMS_OK;
+    hipStream_t s = h->pick(stream);
+    unsigned blocks = grid_for(n, 256, 8 * kNumCU);
+    double sc, ss;
+    host_rotor(static_cast<uint64_t>(blocks) * 256u * h->frac, sc, ss);
+    h->tic(s);
+    mixer_f64_kernel<<<dim3(blocks), dim3(256), 0, s>>>(reinterpret_cast<const double2*>(d_in),
+                                                       reinterpret_cast<double2*>(d_out), n, h->turns, h->frac, sc, ss);
+    h->toc(s);
+    COMMS_TRY(launch_ok("mixer_f64_kernel"));
+    h->turns += static_cast<uint64_t>(n) * h->frac;
+    return COMMS_OK;
+}
+comms_status_t comms_mixer_run_f64(comms_mixer_t* h, const comms_c64* in, size_t n, comms_c64* out) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG((in && out) || !n, "NULL host pointer");
+    COMMS_TRY(use_device(h->device));
+    if (!n) return COMMS_OK;
+    return h->run_host(in, n * sizeof(comms_c64), out, n * sizeof(comms_c64), [&](void* d_in, void* d_out) {
+        return comms_mixer_run_f64_dev(h, static_cast<const comms_c64*>(d_in), n, static_cast<comms_c64*>(d_out), COMMS_STREAM_HANDLE);
     });
 }
 

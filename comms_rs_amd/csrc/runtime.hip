@@ -52,10 +52,8 @@ __global__ void synth_iq_kernel(float2* out, size_t n, uint64_t first, uint64_t 
 }
 
 // ---- stream pool (common.hpp: why streams are recycled rather than destroyed)
-namespace {
-std::mutex g_stream_m;
-std::vector<hipStream_t> g_free_streams[64];
-}  // namespace
+static std::mutex g_stream_m;
+static std::vector<hipStream_t> g_free_streams[64];
 
 comms_status_t stream_acquire(int32_t device, hipStream_t* out) {
     COMMS_ARG(device >= 0 && device < 64, "device index out of range");
@@ -104,19 +102,23 @@ struct comms_buf {
 
 namespace {
 
-// Per-device cache of released allocations by size class (powers of two from 256 B) and of
-// events, so that a steady-state graph does no hipMalloc / hipFree / hipEventCreate per message
-// (hipFree synchronises the whole device).  COMMS_BUF_POOL_MB caps the cached bytes per device
-// (default 8192; 0 disables caching).
+// Per-device cache of released allocations by size class and of events, so that a steady-state
+// graph does no hipMalloc / hipFree / hipEventCreate per message (hipFree synchronises the whole
+// device).  Size classes: powers of two from 256 B up to 1 MiB, four per octave above (a block is
+// at most 25 % larger than the request; a plain power of two could double a multi-GiB message).
+// COMMS_BUF_POOL_MB caps the cached bytes per device (default 8192; 0 disables caching).
 struct PoolBlock {
     void* ptr;
     std::vector<hipEvent_t> uses;  // readers that may still be running
 };
+constexpr int kMaxBufLog2 = 40;    // 1 TiB: beyond any device; larger requests are argument errors
+constexpr int kNumClasses = 13 + 4 * (kMaxBufLog2 - 20) + 1;
 struct DevicePool {
     std::mutex m;
-    std::vector<PoolBlock> free_blocks[48];
+    std::vector<PoolBlock> free_blocks[kNumClasses];
     std::vector<hipEvent_t> free_events;
     size_t cached_bytes = 0;
+    std::atomic<long> live_bufs{0};  // comms_buf objects alive on this device (stream-pool trim refuses while > 0)
 };
 DevicePool g_pools[64];
 size_t pool_cap_bytes() {
@@ -126,11 +128,20 @@ size_t pool_cap_bytes() {
     }();
     return cap;
 }
+// bytes in [1, 2^kMaxBufLog2] (checked by the caller) -> class index and the class's size
 int size_class(size_t bytes, size_t* cap) {
-    int c = 8;
-    while ((static_cast<size_t>(1) << c) < bytes) ++c;
-    *cap = static_cast<size_t>(1) << c;
-    return c;
+    if (bytes <= (static_cast<size_t>(1) << 20)) {
+        int c = 8;
+        while (c < 20 && (static_cast<size_t>(1) << c) < bytes) ++c;
+        *cap = static_cast<size_t>(1) << c;
+        return c - 8;  // 0 .. 12
+    }
+    int o = 20;  // octave: 2^o < bytes <= 2^(o+1)
+    while (o + 1 < kMaxBufLog2 && (static_cast<size_t>(1) << (o + 1)) < bytes) ++o;
+    const size_t step = static_cast<size_t>(1) << (o - 2);
+    const size_t q = (bytes - (static_cast<size_t>(1) << o) + step - 1) / step;  // 1 .. 4
+    *cap = (static_cast<size_t>(1) << o) + q * step;
+    return 13 + 4 * (o - 20) + static_cast<int>(q) - 1;
 }
 hipEvent_t pool_event(DevicePool& p) {  // caller holds no lock; current device is the pool's
     {
@@ -185,6 +196,8 @@ comms_status_t comms_buf_alloc(size_t bytes, int32_t device, comms_buf_t** out) 
     COMMS_ARG(out != nullptr, "out is NULL");
     *out = nullptr;
     COMMS_ARG(device >= 0 && device < 64, "device index out of range");
+    COMMS_ARG(bytes <= (static_cast<size_t>(1) << kMaxBufLog2), "%zu bytes is not a device allocation (limit 2^%d)",
+              bytes, kMaxBufLog2);
     COMMS_TRY(use_device(device));
     comms_buf* b = new (std::nothrow) comms_buf;
     COMMS_ARG(b != nullptr, "out of host memory");
@@ -232,6 +245,7 @@ comms_status_t comms_buf_alloc(size_t bytes, int32_t device, comms_buf_t** out) 
             }
         }
     }
+    g_pools[device].live_bufs.fetch_add(1);
     *out = b;
     return COMMS_OK;
 }
@@ -272,6 +286,7 @@ comms_status_t comms_buf_release(comms_buf_t* b) {
                 pool_return_events(p, b->uses);
             }
         }
+        p.live_bufs.fetch_sub(1);
         delete b;
     }
     return COMMS_OK;
@@ -354,6 +369,33 @@ comms_status_t comms_stream_destroy(int32_t device, void* stream) {
     if (!stream) return COMMS_OK;
     COMMS_ARG(device >= 0 && device < 64, "device index out of range");
     comms::stream_release(device, reinterpret_cast<hipStream_t>(stream));
+    return COMMS_OK;
+}
+// Destroys the idle streams of `device`'s pool.  Streams are recycled rather than destroyed because events
+// that travel with comms_buf allocations keep referring to the stream that recorded them; so this first
+// requires that no comms_buf is alive on the device, then frees the buffer cache, drains the device and
+// destroys the pooled events (all of them are free at that point) before the streams go.
+comms_status_t comms_stream_pool_trim(int32_t device) {
+    COMMS_ARG(device >= 0 && device < 64, "device index out of range");
+    DevicePool& p = g_pools[device];
+    COMMS_ARG(p.live_bufs.load() == 0, "%ld comms_buf objects are alive on device %d: release them first",
+              p.live_bufs.load(), device);
+    COMMS_TRY(comms_buf_pool_trim(device));
+    std::vector<hipStream_t> streams;
+    {
+        std::lock_guard<std::mutex> lk(comms::g_stream_m);
+        streams.swap(comms::g_free_streams[device]);
+    }
+    std::vector<hipEvent_t> events;
+    {
+        std::lock_guard<std::mutex> lk(p.m);
+        events.swap(p.free_events);
+    }
+    if (streams.empty() && events.empty()) return COMMS_OK;
+    COMMS_TRY(use_device(device));
+    COMMS_HIP_TRY(hipDeviceSynchronize());
+    for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    for (hipStream_t s : streams) (void)hipStreamDestroy(s);
     return COMMS_OK;
 }
 comms_status_t comms_buf_upload(comms_buf_t* b, size_t offset, const void* host, size_t bytes) {

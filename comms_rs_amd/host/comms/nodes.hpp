@@ -38,6 +38,10 @@ static_assert(sizeof(Complex32) == sizeof(comms_c32), "Complex<f32> must be inte
 
 inline const comms_c32* c32(const Complex32* p) { return reinterpret_cast<const comms_c32*>(p); }
 inline comms_c32* c32(Complex32* p) { return reinterpret_cast<comms_c32*>(p); }
+using Complex64 = std::complex<double>;  // num::Complex<f64>
+static_assert(sizeof(Complex64) == sizeof(comms_c64), "Complex<f64> must be interleaved {re, im}");
+inline const comms_c64* c64(const Complex64* p) { return reinterpret_cast<const comms_c64*>(p); }
+inline comms_c64* c64(Complex64* p) { return reinterpret_cast<comms_c64*>(p); }
 
 inline void throw_on(comms_status_t st, const char* what) {
     if (st != COMMS_OK) throw std::runtime_error(std::string(what) + ": " + comms_last_error());
@@ -308,6 +312,37 @@ public:
     Result<std::vector<Complex32>> run_block(const std::vector<Complex32>& ins) {  // see FirNode::run_block
         std::vector<Complex32> out(ins.size());
         comms_status_t st = comms_mixer_run(h_, c32(ins.data()), ins.size(), c32(out.data()));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_mixer_t* h_ = nullptr;
+};
+
+// MixerNode<f64> (src/mixer.rs:93-148 with T = f64, the type of the reference's own mixer tests :160-336)
+class MixerNode64 : public DeriveNode<MixerNode64> {
+public:
+    NodeReceiver<Complex64> input;
+    NodeSender<Complex64> output;
+
+    explicit MixerNode64(double dphase, std::optional<double> phase = std::nullopt, int device = 0) {
+        throw_on(comms_mixer_create(dphase, phase.value_or(0.0), device, &h_), "MixerNode<f64>::new");
+    }
+    MixerNode64(MixerNode64&& o) noexcept : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_) { o.h_ = nullptr; }
+    ~MixerNode64() { comms_mixer_destroy(h_); }
+
+    Result<Complex64> run(const Complex64& in) {
+        Complex64 out;
+        comms_status_t st = comms_mixer_run_f64(h_, c64(&in), 1, c64(&out));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    Result<std::vector<Complex64>> run_block(const std::vector<Complex64>& ins) {  // see FirNode::run_block
+        std::vector<Complex64> out(ins.size());
+        comms_status_t st = comms_mixer_run_f64(h_, c64(ins.data()), ins.size(), c64(out.data()));
         if (st != COMMS_OK) return to_node_error(st);
         return out;
     }

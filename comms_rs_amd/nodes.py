@@ -285,7 +285,13 @@ class MixerNode(_Handle):
         check(lib().comms_mixer_create(float(dphase), 0.0 if phase is None else float(phase), device, C.byref(self._h)))
 
     def run(self, x):
+        """Complex<f32> samples -> MixerNode<f32>; complex128 input -> MixerNode<f64> (Complex<f64> out)."""
         scalar = np.ndim(x) == 0
+        if np.asarray(x).dtype == np.complex128:
+            a = np.ascontiguousarray(np.atleast_1d(x), dtype=np.complex128)
+            out = np.empty_like(a)
+            check(lib().comms_mixer_run_f64(self._h, _ptr(a), a.size, _ptr(out)))
+            return out[0] if scalar else out
         a = _as_c64(np.atleast_1d(x))
         out = np.empty_like(a)
         check(lib().comms_mixer_run(self._h, _ptr(a), a.size, _ptr(out)))
@@ -293,6 +299,9 @@ class MixerNode(_Handle):
 
     def run_dev(self, in_ptr, n, out_ptr, stream=0):
         check(lib().comms_mixer_run_dev(self._h, in_ptr, n, out_ptr, stream))
+
+    def run_f64_dev(self, in_ptr, n, out_ptr, stream=0):
+        check(lib().comms_mixer_run_f64_dev(self._h, in_ptr, n, out_ptr, stream))
 
     @property
     def phase(self):

@@ -181,6 +181,33 @@ impl MixerNode {
 }
 drained_node!(MixerNode, Complex<f32>, Complex<f32>);
 
+/// `MixerNode<f64>` (mixer.rs:93-148 with T = f64 -- the instantiation the reference's own mixer tests use)
+pub struct MixerNode64 {
+    pub input: NodeReceiver<Complex<f64>>,
+    h: *mut comms_mixer_t,
+    pub output: NodeSender<Complex<f64>>,
+}
+handle_node!(MixerNode64, comms_mixer_t, comms_mixer_destroy);
+impl MixerNode64 {
+    pub fn new(dphase: f64, phase: Option<f64>) -> Self {
+        let mut h = ptr::null_mut();
+        let st = unsafe { comms_mixer_create(dphase, phase.unwrap_or(0.0), 0, &mut h) };
+        assert_eq!(st, COMMS_OK, "comms_mixer_create failed");
+        MixerNode64 { input: Default::default(), h, output: Default::default() }
+    }
+    pub fn run(&mut self, input: &Complex<f64>) -> Result<Complex<f64>, NodeError> {
+        let mut out = Complex::new(0.0f64, 0.0);
+        let st = unsafe { comms_mixer_run_f64(self.h, input, 1, &mut out) };
+        if st == COMMS_OK { Ok(out) } else { Err(to_err(st)) }
+    }
+    pub fn run_block(&mut self, input: &[Complex<f64>]) -> Result<Vec<Complex<f64>>, NodeError> {
+        let mut out = vec![Complex::new(0.0f64, 0.0); input.len()];
+        let st = unsafe { comms_mixer_run_f64(self.h, input.as_ptr(), input.len(), out.as_mut_ptr()) };
+        if st == COMMS_OK { Ok(out) } else { Err(to_err(st)) }
+    }
+}
+drained_node!(MixerNode64, Complex<f64>, Complex<f64>);
+
 /// pulse.rs:38-93
 #[derive(Node)]
 #[pass_by_ref]

@@ -155,6 +155,20 @@ static void test_mixer_nodes() {
         CHECK(close(a.got[i], want0[i], 2e-6f));  // f64 goldens at 1e-6; f32 rounding at |y|~10 is 5e-7
         CHECK(close(b.got[i], want1[i], 2e-6f));
     }
+    // MixerNode<f64>: the reference's tests themselves (mixer.rs:160-246, :250-336) at their own 1e-6
+    const std::vector<Complex64> in64 = {{1, 2}, {3, 4}, {5, 6}, {7, 8}, {9, 0}};
+    const std::vector<Complex64> w0 = {{1.0, 2.0}, {2.486574736, 4.337850399}, {3.388313374, 7.036997405},
+                                       {3.643356072, 9.986288426}, {7.932508585, 4.251506503}};
+    const std::vector<Complex64> w1 = {{0.795337332, 2.089841747}, {2.041089794, 4.564422467}, {2.668858427, 7.340108630},
+                                       {2.628189174, 10.300127265}, {7.468436663, 5.022196114}};
+    Collect<Complex64> a64, b64;
+    pump(Replay<Complex64>(in64), MixerNode64(0.123), a64);
+    pump(Replay<Complex64>(in64), MixerNode64(0.123, 0.1), b64);
+    CHECK(a64.got.size() == 5 && b64.got.size() == 5);
+    for (size_t i = 0; i < 5 && a64.got.size() == 5 && b64.got.size() == 5; ++i) {
+        CHECK(std::abs(a64.got[i].real() - w0[i].real()) < 1e-6 && std::abs(a64.got[i].imag() - w0[i].imag()) < 1e-6);
+        CHECK(std::abs(b64.got[i].real() - w1[i].real()) < 1e-6 && std::abs(b64.got[i].imag() - w1[i].imag()) < 1e-6);
+    }
 }
 
 static void test_pulse_node() {

@@ -309,3 +309,14 @@ def test_bench_rank_failure_is_the_exit_code():
     assert r.returncode != 0
     assert "WORLD_SIZE=1" not in r.stderr
     assert "no MI355X visible" in r.stderr or "COMMS_ERR_DEVICE" in r.stderr, r.stderr[-2000:]
+
+
+def test_buf_alloc_rejects_absurd_sizes_before_touching_the_pool():
+    """sizes beyond 2^40 bytes (e.g. an underflowed size_t) are COMMS_ERR_ARG -- checked before any
+    device call, so this holds on the CPU box too (it used to walk past the size-class table / never return)."""
+    import comms_rs_amd as c
+
+    for bad in ((1 << 40) + 1, (1 << 48), (1 << 64) - 1):
+        with pytest.raises(c.CommsError) as e:
+            c.DeviceBuf(bad)
+        assert e.value.code == c.COMMS_ERR_ARG

@@ -544,6 +544,55 @@ def test_mixer_reference_golden(c, kats, key):
     assert np.max(np.abs(got.imag - want.imag)) < 2e-6
 
 
+@pytest.mark.parametrize("key", ["mixer_phase0", "mixer_phase0p1"])
+def test_mixer_f64_reference_golden_at_the_reference_tolerance(c, kats, key):
+    """MixerNode<f64> -- the instantiation src/mixer.rs:160-246, :250-336 test -- at the reference's own
+    assert_approx_eq tolerance (1e-6, mixer.rs:220-223, :310-313), one sample per call like the node."""
+    k = kats[key]
+    node = c.MixerNode(k["dphase"], k["phase"] if k["phase"] else None)
+    got = np.array([node.run(np.complex128(v)) for v in cx(k["input"], np.complex128)])
+    assert got.dtype == np.complex128
+    want = cx(k["expected"], np.complex128)
+    assert np.max(np.abs(got.real - want.real)) < 1e-6
+    assert np.max(np.abs(got.imag - want.imag)) < 1e-6
+    # and far inside it: the goldens are printed to 9 decimals, the f64 path agrees to that print precision
+    assert np.max(np.abs(got - want)) < 2e-9
+
+
+@pytest.mark.parametrize("dphase,phase", [(0.123, 0.0), (2 * np.pi * 0.1, 0.0), (5.9, 1.0), (-0.4, 7.5)])
+def test_mixer_f64_vs_oracle(c, dphase, phase):
+    """Complex<f64> streams against the oracle's f64 instantiation, cut into ragged calls; tolerance: the
+    north-star's 1e-5 relative is met with ten orders to spare -- |d| <= 1e-9 |x| (the oracle accumulates the phase
+    in f64 as the reference does, the device evaluates it in closed form: they drift apart by ~1e-16 per sample)."""
+    rng = np.random.default_rng(int(abs(dphase) * 1000) + 11)
+    x = (rng.standard_normal(100003) + 1j * rng.standard_normal(100003)).astype(np.complex128)
+    node, orc = c.MixerNode(dphase, phase), oracle.Mixer(phase, dphase)
+    cuts = [0, 1, 2, 3, 1000, 1001, 65536, 100003]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        got, want = node.run(x[a:b]), orc.mix(x[a:b])
+        assert got.dtype == np.complex128
+        assert np.all(np.abs(got - want) <= 1e-9 * np.abs(x[a:b]) + 1e-30)
+    dd = abs((node.phase - orc.phase.value + np.pi) % (2 * np.pi) - np.pi)
+    assert dd < 1e-9
+
+
+def test_mixer_f64_device_resident_in_place_and_alignment(c):
+    import torch
+
+    n = (1 << 20) + 5
+    rng = np.random.default_rng(5)
+    xs = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex128)
+    x = torch.from_numpy(xs).cuda()
+    node = c.MixerNode(2 * np.pi * 0.05, 0.3)
+    s = torch.cuda.current_stream().cuda_stream
+    node.run_f64_dev(x.data_ptr(), n, x.data_ptr(), s)   # in place
+    torch.cuda.synchronize()
+    want = oracle.Mixer(0.3, 2 * np.pi * 0.05).mix(xs)
+    assert np.all(np.abs(x.cpu().numpy() - want) <= 1e-9 * np.abs(xs) + 1e-30)
+    with pytest.raises(c.CommsError):                    # Complex<f64> streams are 16-byte aligned
+        node.run_f64_dev(x.data_ptr() + 8, 4, x.data_ptr() + 8, s)
+
+
 @pytest.mark.parametrize("dphase,phase", [(0.123, 0.0), (2 * np.pi * 0.1, 0.0), (5.9, 1.0), (-0.4, 7.5), (0.0, -3.0), (40.0, 0.5)])
 def test_mixer_vs_oracle(c, dphase, phase):
     rng = np.random.default_rng(int(abs(dphase) * 1000) + 3)
@@ -1339,6 +1388,43 @@ def test_device_buf_refcount_and_roundtrip(c):
     assert np.array_equal(y.download(np.complex64, 1000), x)
     with pytest.raises(c.CommsError):
         b2.download(np.complex64, 1001)
+
+
+def test_device_buf_size_classes_and_limits(c):
+    """comms_buf_alloc: absurd sizes are argument errors (an underflowed size_t used to spin in the size-class loop),
+    blocks above 1 MiB are at most 25 % larger than the request and come back from the cache, and the stream pool
+    can be trimmed once no buffer is alive."""
+    from comms_rs_amd._lib import lib
+
+    for bad in ((1 << 40) + 1, (1 << 47) + 5, (1 << 64) - 1):
+        with pytest.raises(c.CommsError) as e:
+            c.DeviceBuf(bad)
+        assert e.value.code == c.COMMS_ERR_ARG
+    lib().comms_buf_pool_trim(0)
+    import torch
+
+    def free_bytes():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info(0)[0]
+
+    before = free_bytes()
+    want = (1 << 30) + (1 << 20)                 # 1 GiB + 1 MiB: a power-of-two class would take 2 GiB
+    b = c.DeviceBuf(want)
+    used = before - free_bytes()
+    assert want <= used <= int(1.26 * want) + (8 << 20), used
+    p0 = b.ptr
+    b.release()
+    b = c.DeviceBuf(want - 4096)                 # same class: the cached block comes back
+    assert b.ptr == p0
+    b.release()
+    small = [c.DeviceBuf(n) for n in (1, 255, 256, 257, 4096, (1 << 20) - 1, 1 << 20, (1 << 20) + 1)]
+    assert len({x.ptr for x in small}) == len(small)
+    with pytest.raises(c.CommsError) as e:       # buffers alive: the stream pool refuses
+        from comms_rs_amd._lib import check
+        check(lib().comms_stream_pool_trim(0))
+    assert e.value.code == c.COMMS_ERR_ARG
+    for x in small:
+        x.release()
 
 
 def test_handles_create_destroy_many_times(c):
