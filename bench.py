@@ -17,7 +17,9 @@ Default (what the driver runs):  --config 2
   (strong scaling; every shard is far past the 256 MiB Infinity Cache, so its FIR
   fraction is the HBM-resident figure).
 
-Other BASELINE configs (same contract, one JSON line each):
+Other BASELINE configs (same contract, one JSON line each, each with roofline + cpu_baseline at N = 1):
+  --config 1   the reference's own CPU case on the GPU: PRBS7 -> BPSK -> 63-tap RRC x4 -> mixer, 2^20 samples per step,
+               one launch; cpu_baseline = the whole config through the oracle
   --config 3   mixer -> 127-tap LPF -> decimate-by-8 -> FM demod, 2^26 samples per rank,
                one fused launch; shards are primed by a 136-sample prefix (FIR halo + FM.prev)
   --config 4   2^20-point FFT, batch 4096 sharded over the ranks (4096/N transforms each), no
@@ -163,6 +165,107 @@ def cpu_baseline(n):
     except Exception as e:  # the single-thread figure above is the contract; these are extras
         out["all_cores"] = {"error": str(e)}
     return out
+
+
+def _best_of(fn, reps=2):
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best
+
+
+def cpu_baseline_c1():
+    """BASELINE config 1 IS the reference's CPU path (examples/single_thread_bpsk.rs:15-52 made deterministic,
+    SURVEY 8d): PRBS7 -> BPSK -> PulseNode(rrc_taps(63, 4, 0.25), 4) -> Mixer, 2^18 symbols = 2^20 samples, run in
+    full on one thread; beside it the literal example (32 taps, zero-stuff, batch_fir, x8192 -> i16, no mixer)."""
+    import oracle
+
+    nsym = 1 << 18
+    bits, _ = oracle.prns_u8(0xC0, 0x01, nsym)
+    sym = (bits.astype(np.float32) * 2.0 - 1.0).astype(np.complex64)
+    taps = oracle.rrc_taps(63, 4.0, 0.25)
+
+    def chain():
+        oracle.Mixer(0.0, MIX_DPHASE).mix(oracle.pulse(sym, taps, 4, oracle.default_state(taps)))
+
+    dt = _best_of(chain)
+    taps32 = oracle.rrc_taps(32, 4.0, 0.25)
+
+    def literal():  # single_thread_bpsk.rs:24-47, 4096-symbol blocks, one state across blocks
+        st = oracle.default_state(taps32)
+        for i in range(0, nsym, 4096):
+            oracle.iq_c32_to_i16(oracle.batch_fir(oracle.upsample(sym[i:i + 4096], 4), taps32, st), 8192.0)
+
+    dl = _best_of(literal)
+    return {"value": round(4 * nsym / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "the whole config: 2^18 PRBS7 symbols -> BPSK -> oracle PulseNode (63-tap RRC, 4 samples per "
+                      "symbol: fir() per output sample, rotate_right each) -> Mixer::mix (f64), 2^20 output samples, "
+                      "best of 2, 1 thread of %d host cores" % (os.cpu_count() or 0),
+            "literal_example": {"value": round(4 * nsym / dl / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+                                "what": "single_thread_bpsk.rs as written: 4096-symbol blocks, zero-stuff x4, "
+                                        "batch_fir(32-tap RRC), x8192 -> i16; no mixer"}}
+
+
+def cpu_baseline_c3():
+    """examples/fm_radio.rs:144-164 shaped as BASELINE config 3: Mixer::mix -> batch_fir(127) -> decimate(8) ->
+    FM::demod on a 2^25-sample piece of the same stream (the rate does not depend on the length)."""
+    import oracle
+    from comms_rs_amd import synth_iq
+
+    n = 1 << 25
+    x = synth_iq(n, 0, SEED)
+    taps = lowpass_taps(C3_TAPS, 1.0 / 16)
+
+    def chain():
+        y = oracle.batch_fir(oracle.Mixer(0.0, C3_DPHASE).mix(x), taps, oracle.default_state(taps))
+        oracle.FM().demod(oracle.decimate(y, C3_RATE))
+
+    dt = _best_of(chain)
+    return {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "2^25 of the config's 2^26 samples (extrapolates linearly: per-sample work is constant) through "
+                      "oracle Mixer::mix (f64) -> batch_fir(127 taps, rotate_right per sample) -> decimate(8) -> "
+                      "FM::demod, best of 2, 1 thread of %d host cores" % (os.cpu_count() or 0)}
+
+
+def cpu_baseline_c4():
+    """src/fft/mod.rs:73-96: cast to f64, unnormalised 2^20-point DFT in f64, cast back -- 64 of the 4096 transforms."""
+    import oracle
+    from comms_rs_amd import synth_iq
+
+    k = 64
+    xs = [synth_iq(FFT_N, i * FFT_N, SEED) for i in range(k)]
+
+    def run():
+        for x in xs:
+            oracle.fft(x, False)
+
+    dt = _best_of(run)
+    return {"value": round(k * FFT_N / dt / 1e6, 3), "unit": "Mpoints/s", "cores": 1, "kind": "port",
+            "sample": "64 of the config's 4096 transforms of 2^20 points (extrapolates linearly: transforms are "
+                      "independent) through the oracle's BatchFFT::run_fft (f32 -> f64, radix-2 f64 FFT standing in "
+                      "for rustfft 2.1.0, whose plan is built once -- the oracle rebuilds its twiddles per call, a "
+                      "few %% of the time --, f64 -> f32), best of 2, 1 thread of %d host cores" % (os.cpu_count() or 0)}
+
+
+def cpu_baseline_c5():
+    """src/filter/fir.rs:87-102 with 4097 taps: 2^21 samples, literal (rotate_right of 32 KiB per sample)."""
+    import oracle
+    from comms_rs_amd import synth_iq
+
+    n, m = 1 << 21, 1 << 19
+    x = synth_iq(n, 0, SEED)
+    taps = lowpass_taps(C5_TAPS, 1.0 / 64)
+    dt = _best_of(lambda: oracle.batch_fir(x, taps, oracle.default_state(taps)), 1)
+    dn = _best_of(lambda: oracle.batch_fir(x[:m], taps, oracle.default_state(taps), norotate=True), 1) * (n / m)
+    return {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "2^21 of the config's 2^27 samples per GPU (extrapolates linearly: 4097 MACs + a 32 KiB "
+                      "rotate_right per sample whatever the length) through the oracle's literal batch_fir, "
+                      "1 thread of %d host cores" % (os.cpu_count() or 0),
+            "one_core_norotate": {"value": round(n / dn / 1e6, 4), "unit": "Msamples/s", "cores": 1,
+                                  "what": "circular index instead of rotate_right: not the reference's algorithm"}}
 
 
 class Ctx:
@@ -573,6 +676,8 @@ def run_config3(ctx):
     res["world_size_seen"], res["ranks"] = ranks["world_size_seen"], ranks
     if transfer:
         res["transfer"] = transfer
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_c3()
     return res
 
 
@@ -650,6 +755,8 @@ def run_config5(ctx):
     res["world_size_seen"], res["ranks"] = ranks["world_size_seen"], ranks
     if transfer:
         res["transfer"] = transfer
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_c5()
     return res
 
 
@@ -709,6 +816,88 @@ def run_config4(ctx):
     res["world_size_seen"], res["ranks"] = ranks["world_size_seen"], ranks
     if transfer:
         res["transfer"] = transfer
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_c4()
+    return res
+
+
+def run_config1(ctx):
+    """BASELINE config 1 on the GPU: the transmit chain PRBS7 -> BPSK -> PulseNode(rrc_taps(63, 4, 0.25), 4) -> MixerNode
+    on 2^18 symbols = 2^20 samples per step, as ONE launch (pulse_poly_kernel<4,real,MIX>); the two-node form and the
+    literal example (32 taps, no mixer, i16 wire format out) beside it.  Every rank runs its own symbol block."""
+    import comms_rs_amd as c
+
+    args, torch, rank, world = ctx.args, ctx.torch, ctx.rank, ctx.world
+    nsym = 1 << ((args.n_log2 or 20) - 2)
+    n = 4 * nsym
+    # the symbol source is not on the hot path (SURVEY 8d: restated on the host): PRBS7 bits, LFSR poly 0xC0 state 0x01
+    bits = np.empty(nsym, np.uint8)
+    st = 0x01
+    for i in range(nsym):                                 # prns.rs:64-71: out = MSB, shift left, OR in parity(state & mask)
+        fb = bin(st & 0xC0).count("1") & 1
+        bits[i] = st >> 7
+        st = ((st << 1) | fb) & 0xFF
+    sym_h = (bits.astype(np.float32) * 2.0 - 1.0).astype(np.complex64)
+    sym = torch.from_numpy(sym_h).to(ctx.dev)
+    out = torch.empty(n, dtype=torch.complex64, device=ctx.dev)
+    taps = c.rrc_taps(63, 4.0, 0.25)
+    s = ctx.stream
+    fused = c.PulseNode(taps, 4, device=ctx.local_rank).set_mixer(MIX_DPHASE)
+    # self-check with product code only: one launch against the two reference nodes in series
+    pn, mx = c.PulseNode(taps, 4, device=ctx.local_rank), c.MixerNode(MIX_DPHASE, device=ctx.local_rank)
+    two = torch.empty_like(out)
+    fused.run_dev(sym.data_ptr(), nsym, out.data_ptr(), s)
+    pn.run_dev(sym.data_ptr(), nsym, two.data_ptr(), s)
+    mx.run_dev(two.data_ptr(), n, two.data_ptr(), s)
+    torch.cuda.synchronize()
+    err, bound = float((out - two).abs().max()), 2e-5 * float(np.sum(np.abs(taps)))
+    ctx.all_ok(err <= bound, "config 1: fused transmit chain vs PulseNode -> MixerNode differ by %g (bound %g)" % (err, bound))
+
+    timer = c.KernelTimer(max(args.steps, 1), device=ctx.local_rank).attach(fused)
+    for _ in range(args.warmup):
+        fused.run_dev(sym.data_ptr(), nsym, out.data_ptr(), s)
+    timer.reset()
+    elapsed = ctx.timed(lambda: fused.run_dev(sym.data_ptr(), nsym, out.data_ptr(), s), args.steps, 0)
+    kms = timer.read_ms()
+    timer.close()
+
+    def two_nodes():
+        pn.run_dev(sym.data_ptr(), nsym, two.data_ptr(), s)
+        mx.run_dev(two.data_ptr(), n, two.data_ptr(), s)
+
+    two_elapsed = ctx.timed(two_nodes, args.steps, max(args.warmup, 1))
+    lit = c.PulseNode(c.rrc_taps(32, 4.0, 0.25), 4, device=ctx.local_rank).set_output_format("i16", 8192.0)
+    out16 = torch.empty((n, 2), dtype=torch.int16, device=ctx.dev)
+    lit_elapsed = ctx.timed(lambda: lit.run_dev(sym.data_ptr(), nsym, out16.data_ptr(), s), args.steps, max(args.warmup, 1))
+    kernel_ms = float(np.mean(kms))
+    ranks = rank_report(ctx, kernel_ms)
+    if rank != 0:
+        return None
+    bytes_per_out = 8.0 / 4 + 8.0   # SURVEY 8d, pulse (sps = 4): 2 B read + 8 B written per output sample
+    ach = bytes_per_out * n / (kernel_ms * 1e-3) / 1e9
+    res = {"metric": "Msamples/s Complex<f32> out of PRBS->BPSK->63-tap RRC pulse shaping->mixer (BASELINE config 1)",
+           "value": round(float(world) * n * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE config 1 (examples/single_thread_bpsk.rs made deterministic): 2^%d PRBS7/BPSK "
+                                  "symbols -> PulseNode(rrc_taps(63,4,0.25), 4) -> MixerNode(2pi*0.1) = 2^%d output samples "
+                                  "per GPU and step, one launch" % (int(np.log2(nsym)), int(np.log2(n))),
+                      "output_samples_per_gpu_per_step": n, "n_taps": 63, "sam_per_sym": 4, "kernel": "pulse_poly_kernel<4,real,MIX>"},
+           "roofline": {"bound": "hbm", "kernel": "pulse_poly_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "kernel_ms": round(kernel_ms, 5), "launches_timed": int(kms.size),
+                        "algorithmic_bytes_per_launch": bytes_per_out * n,
+                        "note": "2^20 outputs are 10.5 MB: at this size the launch is latency-bound (the same kernel at "
+                                "2^24 outputs: DESIGN.md section 4); events around the launch"},
+           "two_nodes": {"value": round(float(world) * n * args.steps / two_elapsed / 1e6, 1), "unit": "Msamples/s",
+                         "ms_per_step": round(two_elapsed / args.steps * 1e3, 5), "what": "PulseNode -> MixerNode, two launches"},
+           "literal_example": {"value": round(float(world) * n * args.steps / lit_elapsed / 1e6, 1), "unit": "Msamples/s",
+                               "ms_per_step": round(lit_elapsed / args.steps * 1e3, 5),
+                               "what": "single_thread_bpsk.rs as written: 32-tap RRC x4, no mixer, x8192 -> i16 file "
+                                       "samples written by the kernel's store stage, one launch"}}
+    res["world_size_seen"], res["ranks"] = ranks["world_size_seen"], ranks
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_c1()
     return res
 
 
@@ -788,7 +977,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)   # 0.12 s of timed region at config 2: long enough for an outside
     ap.add_argument("--warmup", type=int, default=50)    # utilisation sampler to see; the whole default run stays ~10 s
-    ap.add_argument("--config", type=int, choices=[2, 3, 4, 5], default=2)
+    ap.add_argument("--config", type=int, choices=[1, 2, 3, 4, 5], default=2)
     ap.add_argument("--variant", choices=["inplace", "scatter"], default="inplace")
     ap.add_argument("--stream-log2", type=int, default=30,
                     help="config 2: log2 of the whole stream of the strong-scaling extra (0 = skip it)")
@@ -806,11 +995,13 @@ def main():
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     if args.launch_check:
         return launch_check(args)
-    if args.config != 2 and args.steps == 1000 and args.warmup == 50:
+    if args.config == 1 and args.steps == 1000 and args.warmup == 50:
+        args.steps, args.warmup = 200, 20
+    elif args.config != 2 and args.steps == 1000 and args.warmup == 50:
         args.steps, args.warmup = 20, 3   # the other configs' steps are 10-100x longer
 
     ctx = Ctx(args)
-    out = {2: run_config2, 3: run_config3, 4: run_config4, 5: run_config5}[args.config](ctx)
+    out = {1: run_config1, 2: run_config2, 3: run_config3, 4: run_config4, 5: run_config5}[args.config](ctx)
     if ctx.rank == 0:
         print(json.dumps(out), flush=True)
     if ctx.world > 1:

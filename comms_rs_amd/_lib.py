@@ -68,6 +68,7 @@ _PROTOS = {
     "comms_fir_set_input_format": [_vp, _i32, C.c_float],
     "comms_chain_set_input_format": [_vp, _i32, C.c_float],
     "comms_mixer_set_timer": [_vp, _vp],
+    "comms_pulse_set_timer": [_vp, _vp],
     "comms_fmdemod_set_timer": [_vp, _vp],
     "comms_fft_set_timer": [_vp, _vp],
     "comms_chain_set_timer": [_vp, _vp],

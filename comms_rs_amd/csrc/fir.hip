@@ -1996,6 +1996,12 @@ comms_status_t comms_pulse_run(comms_pulse_t* h, const comms_c32* sym, size_t n_
     });
 }
 
+comms_status_t comms_pulse_set_timer(comms_pulse_t* h, comms_timer_t* t) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    h->timer = t;
+    return COMMS_OK;
+}
+
 comms_status_t comms_pulse_destroy(comms_pulse_t* h) {
     if (!h) return COMMS_OK;
     free_pulse(h);

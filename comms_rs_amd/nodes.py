@@ -287,7 +287,7 @@ class MixerNode(_Handle):
     def run(self, x):
         """Complex<f32> samples -> MixerNode<f32>; complex128 input -> MixerNode<f64> (Complex<f64> out)."""
         scalar = np.ndim(x) == 0
-        if np.asarray(x).dtype == np.complex128:
+        if isinstance(x, (np.ndarray, np.generic)) and x.dtype == np.complex128:
             a = np.ascontiguousarray(np.atleast_1d(x), dtype=np.complex128)
             out = np.empty_like(a)
             check(lib().comms_mixer_run_f64(self._h, _ptr(a), a.size, _ptr(out)))
@@ -675,7 +675,7 @@ class KernelTimer:
     def attach(self, node):
         name = {"comms_fir_destroy": "comms_fir_set_timer", "comms_mixer_destroy": "comms_mixer_set_timer",
                 "comms_fmdemod_destroy": "comms_fmdemod_set_timer", "comms_fft_destroy": "comms_fft_set_timer",
-                "comms_chain_destroy": "comms_chain_set_timer"}[node._destroy]
+                "comms_chain_destroy": "comms_chain_set_timer", "comms_pulse_destroy": "comms_pulse_set_timer"}[node._destroy]
         check(getattr(lib(), name)(node._h, self._h))
         self._node, self._setter = node, name
         return self
