@@ -61,6 +61,19 @@ __device__ __forceinline__ cf cmulcf(cf a, cf b) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(p));
     return d;
 }
+// the same with the second factor in an SGPR pair (a wave-uniform twiddle: no VGPRs, no LDS read)
+__device__ __forceinline__ cf cmulf_s(cf a, cf b) {
+    cf p, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(p) : "v"(a), "s"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(a), "s"(b), "v"(p));
+    return d;
+}
+__device__ __forceinline__ cf cmulcf_s(cf a, cf b) {
+    cf p, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(p) : "v"(a), "s"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "s"(b), "v"(p));
+    return d;
+}
 // a * w for DIR = -1, a * conj(w) for DIR = +1 (w = forward twiddle)
 template <int DIR>
 __device__ __forceinline__ cf tw_mul(cf a, cf w) {

@@ -409,6 +409,10 @@ __device__ __forceinline__ void os1024_core(cf (&v)[16], cf* lds, const cf* tw1,
     for (int b = 0; b < 16; ++b) v[b] = lds[q0 * W_S1 + 4 * b + q1];
     wave_lds_sync();
     stamp(2);  // exchange-1 reads
+    // the 16384-point kernel's spectrum lives in global memory (L2): all sixteen loads go out here, a
+    // radix-16 and the cross-lane radix-4 ahead of their use (one at a time at the multiply they cost
+    // sixteen L2 round trips per segment)
+    cf hh[HS == 64 ? 1 : 16];
     // ---- stage 3 without LDS: lane (k0, c) keeps its 16 k1 values and the radix-4 over c = lane >> 4 runs
     // ACROSS lanes: v_permlane32_swap pairs registers so that the c1 halves meet in one lane, v_permlane16_swap
     // does the same for c0; the W4^{c0} twiddle of the odd outputs is folded into the second butterfly.
@@ -421,6 +425,13 @@ __device__ __forceinline__ void os1024_core(cf (&v)[16], cf* lds, const cf* tw1,
         if (k) r[k] = cmulf(r[k], tw2[k * 4 + q1]);
     }
     stamp(3);  // R16 + twiddle (stage 2)
+    // The 16384-point kernel's spectrum lives in global memory (L2).  Its sixteen loads go out in two batches
+    // ahead of their use -- here and between the two swap layers (the lane-swap fences keep them in place) --
+    // instead of one L2 round trip at a time at the multiply.
+    if (HS != 64) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hh[i] = hsp[i * HS + l];
+    }
     cf sd[16];  // [0..7] sums (even k2), [8..15] differences (odd k2) of the c1 halves
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -428,6 +439,10 @@ __device__ __forceinline__ void os1024_core(cf (&v)[16], cf* lds, const cf* tw1,
         lane_swap32(p, q);
         sd[m] = p + q;
         sd[8 + m] = p - q;
+    }
+    if (HS != 64) {
+#pragma unroll
+        for (int i = 8; i < 16; ++i) hh[i] = hsp[i * HS + l];
     }
     cf z[16];
 #pragma unroll
@@ -443,7 +458,7 @@ __device__ __forceinline__ void os1024_core(cf (&v)[16], cf* lds, const cf* tw1,
     }
     stamp(4);  // radix-4 across lanes
 #pragma unroll
-    for (int i = 0; i < 16; ++i) z[i] = cmulf(z[i], hsp[i * HS + l]);
+    for (int i = 0; i < 16; ++i) z[i] = cmulf(z[i], HS == 64 ? hsp[i * HS + l] : hh[i]);
     // ---- the mirror image
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -804,6 +819,10 @@ __global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(In in,
 // tables = 158 KiB, one workgroup per CU.
 constexpr int XV = 12288;      // new samples per segment (halo 4096)
 constexpr int X_BUF = 1090;    // per-wave slice buffer (>= 1088; 2180 dwords = 4 mod 64 banks)
+constexpr size_t X_LDS_BYTES = (1024 + 64 + 16 * X_BUF) * sizeof(float2) + 32 * sizeof(unsigned);  // tables, slices, counters
+#ifndef COMMS_OS16K_CARRY
+#define COMMS_OS16K_CARRY 0  // 1: the four halo rows of a segment stay in registers from the previous one (8 VGPRs)
+#endif
 
 struct XTables {
     const cf* tw1;   // [16][64]   W1024^{lane*k}          (per-wave 1024-point transform)
@@ -813,7 +832,39 @@ struct XTables {
     const cf* hdev;  // [16][1024] H[k0 + 16 k']/16384 at [4t + m][tid], k0 = tid>>6, k' = the bin os1024_core leaves in register 4t + m of lane tid&63
 };
 
-__global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(const float2* __restrict__ in,
+// Workgroup synchronisation of the 16384-point kernel without s_barrier: two sets of sixteen
+// monotonic counters in LDS.  slice_in[k] counts the waves that have written their part of slice k
+// (stage 1 of the current segment), slice_out[k] the segments wave k has finished; a consumer polls
+// (ds_read + s_sleep) until the count it needs is there.  What the three barriers per segment cost
+// (profiles/r02_pmc_config5.txt: 59 % of wave cycles waiting) was not the waiting itself but its
+// shape: every phase ended with the CU idling until its slowest wave arrived, and one of the three
+// (before stage 1's writes) ordered nothing -- thread tid writes exactly the words it has read itself
+// in the previous segment's inverse stage.  All sixteen waves of the workgroup are resident (one
+// workgroup per CU) and run the same number of segments, so every count is reached; the poll is
+// bounded anyway (a miscount would give wrong samples, which the tests see, not a hung GPU).
+__device__ __forceinline__ void x_signal(unsigned* cnt, bool lane_on) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the whole wave's LDS writes first
+    if (lane_on) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void x_wait_one(const unsigned* cnt, unsigned target) {
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        const unsigned c = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<int>(c)) - target) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void x_wait_all16(const unsigned* cnt, unsigned target, int l) {
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        const unsigned c = __hip_atomic_load(cnt + (l & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__all(static_cast<int>(c - target) >= 0)) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <class In = const float2*>
+__global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
                                                             const float2* __restrict__ hist, int hist_len,
                                                             float2* __restrict__ out, size_t n, size_t nseg,
                                                             XTables tb, float2* __restrict__ new_hist, int delay,
@@ -821,25 +872,41 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(const float2* __rest
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* tw1 = reinterpret_cast<cf*>(smem);  // [16][64]
     cf* tw2 = tw1 + 1024;                   // [16][4]
-    cf* ta = tw2 + 64;                      // [16][16]
-    cf* tbl = ta + 256;                     // [16][64]
-    cf* bufs = tbl + 1024;                  // [16][X_BUF]
+    cf* bufs = tw2 + 64;                    // [16][X_BUF]
+    unsigned* slice_in = reinterpret_cast<unsigned*>(bufs + 16 * X_BUF);  // [16]
+    unsigned* slice_out = slice_in + 16;                                   // [16]
     const int tid = threadIdx.x;
     const int l = tid & 63, wave = tid >> 6;
     cf* buf = bufs + wave * X_BUF;
     if (!accumulate) hist_advance(hist, in, n, new_hist, hist_len);
     tw1[tid] = tb.tw1[tid];
-    tbl[tid] = tb.tb[tid];
     if (tid < 64) tw2[tid] = tb.tw2[tid];
-    if (tid < 256) ta[tid] = tb.ta[tid];
+    if (tid < 32) slice_in[tid] = 0;
+    // The stage-1 twiddle W16384^{t*k0} of point t = 64 a + l of slice k0 is applied by the wave that OWNS
+    // slice k0 (k0 = wave), where it factors into W256^{a*k0} -- wave-uniform, indexed by the register: sixteen
+    // SGPR pairs read through the scalar cache -- and W16384^{l*k0}, one per-lane constant.  (Applied by the
+    // producers it is fifteen per-lane values per thread: two LDS table reads and a product per point.)
+    typedef const __attribute__((address_space(4))) cf* const_cf_ptr;  // constant address space: scalar loads
+    const_cf_ptr sta_p = (const_cf_ptr)(tb.ta + 16 * __builtin_amdgcn_readfirstlane(wave));
+    cf sta[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) sta[a] = sta_p[a];
+    const cf lane_tw = tb.tb[wave * 64 + l];
+    __syncthreads();  // tables and counters: the only barrier of the launch
 
     // workgroup g of the persistent grid owns segments [g*nseg/G, (g+1)*nseg/G)
     const size_t seg_lo = static_cast<size_t>(blockIdx.x) * nseg / gridDim.x;
     const size_t seg_hi = static_cast<size_t>(blockIdx.x + 1) * nseg / gridDim.x;
-    cf v[16], carry[4];
-    for (size_t seg = seg_lo; seg < seg_hi; ++seg) {
+    cf v[16];
+#if COMMS_OS16K_CARRY
+    cf carry[4];
+#endif
+    unsigned done = 0;  // segments this workgroup has finished
+    for (size_t seg = seg_lo; seg < seg_hi; ++seg, ++done) {
         const size_t nb = seg * XV;
         const long long base = static_cast<long long>(nb) - 4096 - delay;
+        const bool inside = base >= 0 && static_cast<size_t>(base) + XF <= n;  // all 16 rows are input samples
+#if COMMS_OS16K_CARRY
         if (seg == seg_lo) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) v[a] = to_cf(stream_at(in, hist, hist_len, base + 1024 * a + tid, n));
@@ -847,35 +914,56 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(const float2* __rest
 #pragma unroll
             for (int a = 0; a < 4; ++a) v[a] = carry[a];
         }
+        if (inside) {
 #pragma unroll
-        for (int a = 4; a < 16; ++a) v[a] = to_cf(stream_at(in, hist, hist_len, base + 1024 * a + tid, n));
+            for (int a = 4; a < 16; ++a) v[a] = to_cf(in[static_cast<size_t>(base) + 1024 * a + tid]);
+        } else {
+#pragma unroll
+            for (int a = 4; a < 16; ++a) v[a] = to_cf(stream_at(in, hist, hist_len, base + 1024 * a + tid, n));
+        }
 #pragma unroll
         for (int a = 0; a < 4; ++a) carry[a] = v[12 + a];
-
-        // ---- stage 1: radix-16 over the rows, x W16384^{tid*k0}, slice k0 -> wave k0
-        radix16<-1>(v);
-        __syncthreads();  // the previous segment's last LDS reads are done
+#else
+        // all sixteen rows from memory: the four halo rows were this CU's last loads of the previous segment (L2)
+        if (inside) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            cf x = v[R16_POS(k)];
-            if (k) x = cmulf(x, cmulf(ta[wave * 16 + k], tbl[k * 64 + l]));
-            bufs[k * X_BUF + tid] = x;
+            for (int a = 0; a < 16; ++a) v[a] = to_cf(in[static_cast<size_t>(base) + 1024 * a + tid]);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 16; ++a) v[a] = to_cf(stream_at(in, hist, hist_len, base + 1024 * a + tid, n));
         }
-        __syncthreads();
-        // ---- this wave's slice: 1024-point transform, spectrum multiply, inverse
+#endif
+
+        // ---- stage 1: radix-16 over the rows; value k of thread tid is point tid of slice k.  No wait in front
+        // of the writes: word (k, tid) was last read by this very thread (inverse stage 1 of the previous
+        // segment), and wave k is past its slice work for that segment or nobody could have read it.
+        radix16<-1>(v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) bufs[k * X_BUF + tid] = v[R16_POS(k)];
+        x_signal(slice_in + (l & 15), l < 16);  // one ds_add, sixteen lanes, sixteen counters
+        // ---- this wave's slice, once all sixteen waves have delivered their 64 points of it: stage-1 twiddle,
+        // 1024-point transform, spectrum multiply, inverse, conjugate twiddle
+        x_wait_one(slice_in + wave, 16u * (done + 1));
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = buf[64 * a + l];
         wave_lds_sync();
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            if (a) v[a] = cmulf_s(v[a], sta[a]);
+            v[a] = cmulf(v[a], lane_tw);
+        }
         os1024_core<1024>(v, buf, tw1, tb.hdev + 64 * wave, tw2, l, [](int) {});
 #pragma unroll
-        for (int a = 0; a < 16; ++a) buf[64 * a + l] = v[R16_POS(a)];
-        __syncthreads();
-        // ---- inverse stage 1: lane tid gathers slice values k0 = 0..15, conj twiddle, radix-16
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            cf x = bufs[k * X_BUF + tid];
-            v[k] = k ? cmulcf(x, cmulf(ta[wave * 16 + k], tbl[k * 64 + l])) : x;
+        for (int a = 0; a < 16; ++a) {
+            cf y = cmulcf(v[R16_POS(a)], lane_tw);
+            if (a) y = cmulcf_s(y, sta[a]);
+            buf[64 * a + l] = y;
         }
+        x_signal(slice_out + wave, l == 0);
+        // ---- inverse stage 1: thread tid gathers point tid of every slice, radix-16 back to the rows
+        x_wait_all16(slice_out, done + 1, l);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = bufs[k * X_BUF + tid];
         radix16<1>(v);
 #pragma unroll
         for (int a = 4; a < 16; ++a) {
@@ -1322,8 +1410,12 @@ static comms_status_t fir_prepare_os16k(comms_fir* h) {
         COMMS_TRY(upload_f2(hdev, &d));
         h->d_xh.push_back(d);
     }
-    const int lds = (1024 + 64 + 256 + 1024 + 16 * X_BUF) * static_cast<int>(sizeof(float2));
-    COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os16k_kernel),
+    const int lds = static_cast<int>(X_LDS_BYTES);
+    COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os16k_kernel<const float2*>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os16k_kernel<InI16>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os16k_kernel<InU8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     h->x_ready = true;
     return COMMS_OK;
@@ -1556,7 +1648,8 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
     const int algo = fir_pick(h, n);
     // kernels whose load stages read raw IQ (the 4096-point one in its default three-workgroups-per-CU build)
     static const int os4096_wps = tune_int("COMMS_OS4096_WPS", 3);
-    const bool fused_fmt = algo == COMMS_FIR_DIRECT || algo == COMMS_FIR_OS1024 || (algo == COMMS_FIR_OS4096 && os4096_wps == 3);
+    const bool fused_fmt = algo == COMMS_FIR_DIRECT || algo == COMMS_FIR_OS1024 || algo == COMMS_FIR_OS16K ||
+                           (algo == COMMS_FIR_OS4096 && os4096_wps == 3);
     const float2* in = nullptr;  // Complex<f32> view of the input (the conversion pass, where the kernel needs one)
     if (!fused_fmt || h->in_fmt == COMMS_IQ_C32) COMMS_TRY(fir_converted_input(h, d_in, n, s, &in));
     if (algo == COMMS_FIR_DIRECT) {
@@ -1603,14 +1696,21 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
         COMMS_TRY(fir_prepare_os16k(h));
         const size_t nseg = (n + XV - 1) / XV;
         const unsigned blocks = static_cast<unsigned>(nseg < static_cast<size_t>(kNumCU) ? nseg : kNumCU);
-        const size_t lds = (1024 + 64 + 256 + 1024 + 16 * X_BUF) * sizeof(float2);
+        const size_t lds = X_LDS_BYTES;
         h->tic(s);
         for (int pt = 0; pt < h->x_part; ++pt) {
             XTables tb{reinterpret_cast<const cf*>(h->d_xt[0]), reinterpret_cast<const cf*>(h->d_xt[1]),
                        reinterpret_cast<const cf*>(h->d_xt[2]), reinterpret_cast<const cf*>(h->d_xt[3]),
                        reinterpret_cast<const cf*>(h->d_xh[pt])};
-            fir_os16k_kernel<<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, h->n_eff, o, n, nseg, tb, nh,
-                                                                   pt * X_PART, pt ? 1 : 0);
+            const int dl = pt * X_PART, acc = pt ? 1 : 0;
+            if (h->in_fmt == COMMS_IQ_I16)
+                fir_os16k_kernel<InI16><<<dim3(blocks), dim3(1024), lds, s>>>(InI16{static_cast<const short2*>(d_in), h->in_scale}, hist, h->n_eff,
+                                                                              o, n, nseg, tb, nh, dl, acc);
+            else if (h->in_fmt == COMMS_IQ_U8)
+                fir_os16k_kernel<InU8><<<dim3(blocks), dim3(1024), lds, s>>>(InU8{static_cast<const uchar2*>(d_in)}, hist, h->n_eff, o, n, nseg, tb,
+                                                                             nh, dl, acc);
+            else
+                fir_os16k_kernel<const float2*><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, h->n_eff, o, n, nseg, tb, nh, dl, acc);
         }
         h->toc(s);
         COMMS_TRY(launch_ok("fir_os16k_kernel"));
