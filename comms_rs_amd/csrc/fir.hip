@@ -897,46 +897,30 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
     // workgroup g of the persistent grid owns segments [g*nseg/G, (g+1)*nseg/G)
     const size_t seg_lo = static_cast<size_t>(blockIdx.x) * nseg / gridDim.x;
     const size_t seg_hi = static_cast<size_t>(blockIdx.x + 1) * nseg / gridDim.x;
-    cf v[16];
-#if COMMS_OS16K_CARRY
-    cf carry[4];
-#endif
+    // The sixteen rows of a segment (the four halo rows too: this CU read them as the last rows of the previous
+    // segment, an L2 hit) are requested one phase ahead -- between the slice work and the inverse stage 1 of the
+    // segment before, where the registers are free -- so their HBM latency runs behind the workgroup's second
+    // wait instead of in front of an idle CU.
+    cf v[16], rows[16];
+    auto fetch_rows = [&](size_t sg) {
+        const long long base = static_cast<long long>(sg * XV) - 4096 - delay;
+        if (base >= 0 && static_cast<size_t>(base) + XF <= n) {  // all 16 rows are input samples
+#pragma unroll
+            for (int a = 0; a < 16; ++a) rows[a] = to_cf(in[static_cast<size_t>(base) + 1024 * a + tid]);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 16; ++a) rows[a] = to_cf(stream_at(in, hist, hist_len, base + 1024 * a + tid, n));
+        }
+    };
+    if (seg_lo < seg_hi) fetch_rows(seg_lo);
     unsigned done = 0;  // segments this workgroup has finished
     for (size_t seg = seg_lo; seg < seg_hi; ++seg, ++done) {
         const size_t nb = seg * XV;
-        const long long base = static_cast<long long>(nb) - 4096 - delay;
-        const bool inside = base >= 0 && static_cast<size_t>(base) + XF <= n;  // all 16 rows are input samples
-#if COMMS_OS16K_CARRY
-        if (seg == seg_lo) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) v[a] = to_cf(stream_at(in, hist, hist_len, base + 1024 * a + tid, n));
-        } else {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) v[a] = carry[a];
-        }
-        if (inside) {
-#pragma unroll
-            for (int a = 4; a < 16; ++a) v[a] = to_cf(in[static_cast<size_t>(base) + 1024 * a + tid]);
-        } else {
-#pragma unroll
-            for (int a = 4; a < 16; ++a) v[a] = to_cf(stream_at(in, hist, hist_len, base + 1024 * a + tid, n));
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a) carry[a] = v[12 + a];
-#else
-        // all sixteen rows from memory: the four halo rows were this CU's last loads of the previous segment (L2)
-        if (inside) {
-#pragma unroll
-            for (int a = 0; a < 16; ++a) v[a] = to_cf(in[static_cast<size_t>(base) + 1024 * a + tid]);
-        } else {
-#pragma unroll
-            for (int a = 0; a < 16; ++a) v[a] = to_cf(stream_at(in, hist, hist_len, base + 1024 * a + tid, n));
-        }
-#endif
-
         // ---- stage 1: radix-16 over the rows; value k of thread tid is point tid of slice k.  No wait in front
         // of the writes: word (k, tid) was last read by this very thread (inverse stage 1 of the previous
         // segment), and wave k is past its slice work for that segment or nobody could have read it.
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = rows[a];
         radix16<-1>(v);
 #pragma unroll
         for (int k = 0; k < 16; ++k) bufs[k * X_BUF + tid] = v[R16_POS(k)];
@@ -960,6 +944,9 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
             buf[64 * a + l] = y;
         }
         x_signal(slice_out + wave, l == 0);
+        // (unconditional -- the last segment fetches itself again -- so that `rows` is redefined on every path
+        // and its registers are free during the slice work)
+        fetch_rows(seg + 1 < seg_hi ? seg + 1 : seg);
         // ---- inverse stage 1: thread tid gathers point tid of every slice, radix-16 back to the rows
         x_wait_all16(slice_out, done + 1, l);
 #pragma unroll
