@@ -821,7 +821,7 @@ constexpr int XV = 12288;      // new samples per segment (halo 4096)
 constexpr int X_BUF = 1090;    // per-wave slice buffer (>= 1088; 2180 dwords = 4 mod 64 banks)
 constexpr size_t X_LDS_BYTES = (1024 + 64 + 16 * X_BUF) * sizeof(float2) + 32 * sizeof(unsigned);  // tables, slices, counters
 #ifndef COMMS_OS16K_CARRY
-#define COMMS_OS16K_CARRY 0  // 1: the four halo rows of a segment stay in registers from the previous one (8 VGPRs)
+#define COMMS_OS16K_CARRY 1  // the four halo rows of a segment stay in registers from the previous one
 #endif
 
 struct XTables {
@@ -897,22 +897,24 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
     // workgroup g of the persistent grid owns segments [g*nseg/G, (g+1)*nseg/G)
     const size_t seg_lo = static_cast<size_t>(blockIdx.x) * nseg / gridDim.x;
     const size_t seg_hi = static_cast<size_t>(blockIdx.x + 1) * nseg / gridDim.x;
-    // The sixteen rows of a segment (the four halo rows too: this CU read them as the last rows of the previous
-    // segment, an L2 hit) are requested one phase ahead -- between the slice work and the inverse stage 1 of the
+    // The new rows of a segment are requested one phase ahead -- between the slice work and the inverse stage 1 of the
     // segment before, where the registers are free -- so their HBM latency runs behind the workgroup's second
     // wait instead of in front of an idle CU.
+    constexpr int R0 = COMMS_OS16K_CARRY ? 4 : 0;  // first row that is fetched per segment
     cf v[16], rows[16];
-    auto fetch_rows = [&](size_t sg) {
+    auto fetch_rows = [&](size_t sg, int first) {
         const long long base = static_cast<long long>(sg * XV) - 4096 - delay;
         if (base >= 0 && static_cast<size_t>(base) + XF <= n) {  // all 16 rows are input samples
 #pragma unroll
-            for (int a = 0; a < 16; ++a) rows[a] = to_cf(in[static_cast<size_t>(base) + 1024 * a + tid]);
+            for (int a = 0; a < 16; ++a)
+                if (a >= first) rows[a] = to_cf(in[static_cast<size_t>(base) + 1024 * a + tid]);
         } else {
 #pragma unroll
-            for (int a = 0; a < 16; ++a) rows[a] = to_cf(stream_at(in, hist, hist_len, base + 1024 * a + tid, n));
+            for (int a = 0; a < 16; ++a)
+                if (a >= first) rows[a] = to_cf(stream_at(in, hist, hist_len, base + 1024 * a + tid, n));
         }
     };
-    if (seg_lo < seg_hi) fetch_rows(seg_lo);
+    if (seg_lo < seg_hi) fetch_rows(seg_lo, 0);
     unsigned done = 0;  // segments this workgroup has finished
     for (size_t seg = seg_lo; seg < seg_hi; ++seg, ++done) {
         const size_t nb = seg * XV;
@@ -921,6 +923,11 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
         // segment), and wave k is past its slice work for that segment or nobody could have read it.
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = rows[a];
+#if COMMS_OS16K_CARRY
+#pragma unroll
+        for (int a = 0; a < 4; ++a) rows[a] = rows[12 + a];  // the next segment's halo (HBM would see it again otherwise:
+                                                             // the XCD streams 7 MiB per segment time through a 4 MiB L2)
+#endif
         radix16<-1>(v);
 #pragma unroll
         for (int k = 0; k < 16; ++k) bufs[k * X_BUF + tid] = v[R16_POS(k)];
@@ -946,7 +953,7 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
         x_signal(slice_out + wave, l == 0);
         // (unconditional -- the last segment fetches itself again -- so that `rows` is redefined on every path
         // and its registers are free during the slice work)
-        fetch_rows(seg + 1 < seg_hi ? seg + 1 : seg);
+        fetch_rows(seg + 1 < seg_hi ? seg + 1 : seg, R0);
         // ---- inverse stage 1: thread tid gathers point tid of every slice, radix-16 back to the rows
         x_wait_all16(slice_out, done + 1, l);
 #pragma unroll
