@@ -393,7 +393,10 @@ __device__ __forceinline__ void lane_swap16(cf& a, cf& b) {
 // 16384-point kernel, whose 16 waves each filter one 1024-point slice with their own part of the spectrum).
 template <int HS = 64, class Stamp>
 __device__ __forceinline__ void os1024_core(cf (&v)[16], cf* lds, const cf* tw1, const cf* hsp, const cf* tw2, int l,
-                                            Stamp&& stamp) {
+                                            Stamp&& stamp, int hl = -1) {
+    if (HS == 64) hl = l;  // hl: this lane's column of the spectrum table (the 16384-point kernel: its thread index,
+                           // on a workgroup-uniform base pointer -- the loads then take the SGPR-base form and share
+                           // one offset register instead of sixteen 64-bit addresses)
     const int q0 = l & 15, q1 = l >> 4;  // stage 2 and 3: lane (k0, c) = (q0, q1)
     // ---- forward
     radix16<-1>(v);
@@ -428,9 +431,10 @@ __device__ __forceinline__ void os1024_core(cf (&v)[16], cf* lds, const cf* tw1,
     // The 16384-point kernel's spectrum lives in global memory (L2).  Its sixteen loads go out in two batches
     // ahead of their use -- here and between the two swap layers (the lane-swap fences keep them in place) --
     // instead of one L2 round trip at a time at the multiply.
+    __amdgpu_buffer_rsrc_t hrs = make_rsrc(hsp, HS == 64 ? 0 : 16 * HS * sizeof(cf));  // (workgroup-uniform base)
     if (HS != 64) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) hh[i] = hsp[i * HS + l];
+        for (int i = 0; i < 8; ++i) hh[i] = to_cf(BufRows<const float2*>::get_from(hrs, hl * 8, i * HS * 8));
     }
     cf sd[16];  // [0..7] sums (even k2), [8..15] differences (odd k2) of the c1 halves
 #pragma unroll
@@ -442,7 +446,7 @@ __device__ __forceinline__ void os1024_core(cf (&v)[16], cf* lds, const cf* tw1,
     }
     if (HS != 64) {
 #pragma unroll
-        for (int i = 8; i < 16; ++i) hh[i] = hsp[i * HS + l];
+        for (int i = 8; i < 16; ++i) hh[i] = to_cf(BufRows<const float2*>::get_from(hrs, hl * 8, i * HS * 8));
     }
     cf z[16];
 #pragma unroll
@@ -458,7 +462,7 @@ __device__ __forceinline__ void os1024_core(cf (&v)[16], cf* lds, const cf* tw1,
     }
     stamp(4);  // radix-4 across lanes
 #pragma unroll
-    for (int i = 0; i < 16; ++i) z[i] = cmulf(z[i], HS == 64 ? hsp[i * HS + l] : hh[i]);
+    for (int i = 0; i < 16; ++i) z[i] = cmulf(z[i], HS == 64 ? hsp[i * HS + hl] : hh[i]);
     // ---- the mirror image
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -904,10 +908,11 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
     cf v[16], rows[16];
     auto fetch_rows = [&](size_t sg, int first) {
         const long long base = static_cast<long long>(sg * XV) - 4096 - delay;
-        if (base >= 0 && static_cast<size_t>(base) + XF <= n) {  // all 16 rows are input samples
+        if (base >= 0) {  // no history involved: buffer loads, zeros past the end of the stream
+            const BufRows<In> br(in, static_cast<size_t>(base), static_cast<size_t>(base) < n ? n - static_cast<size_t>(base) : 0);
 #pragma unroll
             for (int a = 0; a < 16; ++a)
-                if (a >= first) rows[a] = to_cf(in[static_cast<size_t>(base) + 1024 * a + tid]);
+                if (a >= first) rows[a] = to_cf(br.get(tid * BufRows<In>::E, a * 1024 * BufRows<In>::E));
         } else {
 #pragma unroll
             for (int a = 0; a < 16; ++a)
@@ -943,7 +948,7 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
             if (a) v[a] = cmulf_s(v[a], sta[a]);
             v[a] = cmulf(v[a], lane_tw);
         }
-        os1024_core<1024>(v, buf, tw1, tb.hdev + 64 * wave, tw2, l, [](int) {});
+        os1024_core<1024>(v, buf, tw1, tb.hdev, tw2, l, [](int) {}, tid);
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
             cf y = cmulcf(v[R16_POS(a)], lane_tw);
@@ -959,14 +964,13 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = bufs[k * X_BUF + tid];
         radix16<1>(v);
+        // stores (and the accumulating pass's loads) through a buffer resource that ends at sample n: nothing past it
+        const __amdgpu_buffer_rsrc_t ors = make_rsrc(out + nb, nb < n ? (n - nb) * sizeof(float2) : 0);
 #pragma unroll
         for (int a = 4; a < 16; ++a) {
-            const size_t o = nb + 1024 * (a - 4) + tid;
-            if (o < n) {
-                cf y = v[R16_POS(a)];
-                if (accumulate) y = y + to_cf(out[o]);
-                out[o] = to_f2(y);
-            }
+            cf y = v[R16_POS(a)];
+            if (accumulate) y = y + to_cf(BufRows<const float2*>::get_from(ors, tid * 8, (a - 4) * 8192));
+            __builtin_amdgcn_raw_buffer_store_b64(bv2u{__float_as_uint(y.x), __float_as_uint(y.y)}, ors, tid * 8, (a - 4) * 8192, 0);
         }
     }
 }

@@ -49,6 +49,59 @@ struct InU8 {
     }
 };
 
+// The same view / pointer moved forward by `off` samples (a workgroup-uniform offset: the loads that follow keep
+// an SGPR base and a small per-lane offset)
+__device__ __forceinline__ const float2* view_at(const float2* p, size_t off) { return p + off; }
+__device__ __forceinline__ InC32 view_at(InC32 v, size_t off) { return InC32{v.p + off}; }
+__device__ __forceinline__ InC32Split view_at(InC32Split v, size_t off) { return InC32Split{v.p + 2 * off}; }
+__device__ __forceinline__ InI16 view_at(InI16 v, size_t off) { return InI16{v.p + off, v.scale}; }
+__device__ __forceinline__ InU8 view_at(InU8 v, size_t off) { return InU8{v.p + off}; }
+
+// ---- buffer-addressed rows: an SGPR resource (base + byte count), ONE per-lane byte offset and a scalar offset
+// per row.  Global loads with 8-KiB row strides cannot use immediate offsets (13 bits), and the compiler then keeps a
+// 64-bit address pair per row in VGPRs -- sixteen of them in the 16384-point FIR kernel, which spilled.  Reads past
+// the byte count return zero and stores past it are dropped: the stream's end needs no guard.
+typedef unsigned bv2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes) {
+    const unsigned nrec = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : static_cast<unsigned>(bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, static_cast<int>(nrec), 0x00020000);
+}
+template <class In>
+struct BufRows;
+template <>
+struct BufRows<const float2*> {
+    static constexpr unsigned E = 8;
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ BufRows(const float2* in, size_t first, size_t count) : r(make_rsrc(in + first, count * E)) {}
+    static __device__ __forceinline__ float2 get_from(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned row_bytes) {
+        const bv2u x = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_bytes, row_bytes, 0);
+        return make_float2(__uint_as_float(x.x), __uint_as_float(x.y));
+    }
+    __device__ __forceinline__ float2 get(unsigned lane_bytes, unsigned row_bytes) const { return get_from(r, lane_bytes, row_bytes); }
+};
+template <>
+struct BufRows<InI16> {
+    static constexpr unsigned E = 4;
+    __amdgpu_buffer_rsrc_t r;
+    float scale;
+    __device__ __forceinline__ BufRows(InI16 in, size_t first, size_t count) : r(make_rsrc(in.p + first, count * E)), scale(in.scale) {}
+    __device__ __forceinline__ float2 get(unsigned lane_bytes, unsigned row_bytes) const {
+        const unsigned x = __builtin_amdgcn_raw_buffer_load_b32(r, lane_bytes, row_bytes, 0);
+        return make_float2(static_cast<float>(static_cast<short>(x & 0xffffu)) * scale,
+                           static_cast<float>(static_cast<short>(x >> 16)) * scale);
+    }
+};
+template <>
+struct BufRows<InU8> {
+    static constexpr unsigned E = 2;
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ BufRows(InU8 in, size_t first, size_t count) : r(make_rsrc(in.p + first, count * E)) {}
+    __device__ __forceinline__ float2 get(unsigned lane_bytes, unsigned row_bytes) const {
+        const unsigned x = __builtin_amdgcn_raw_buffer_load_b16(r, lane_bytes, row_bytes, 0);
+        return make_float2(InU8::cvt(static_cast<float>(x & 0xffu)), InU8::cvt(static_cast<float>((x >> 8) & 0xffu)));
+    }
+};
+
 // `(scale * x) as i16` (examples/single_thread_bpsk.rs:40-44): Rust's float -> int `as` truncates toward zero,
 // saturates, and maps NaN to 0 -- what IQOutput then writes (src/io/raw_iq.rs:173-178).  Shared by the
 // stand-alone conversion kernel (iqformat.hip) and the pulse shaper's i16 store stage.
