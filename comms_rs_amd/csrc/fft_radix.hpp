@@ -79,6 +79,13 @@ template <int DIR>
 __device__ __forceinline__ cf tw_mul(cf a, cf w) {
     return DIR < 0 ? cmulf(a, w) : cmulcf(a, w);
 }
+// the same with a wave-uniform (compile-time) twiddle read from an SGPR pair: the W16 constants of radix16 below.
+// With a "v" operand the compiler copies the constant into a VGPR pair in front of every use (v_mov_b64: five
+// vector instructions per 16-point DFT, and the registers).
+template <int DIR>
+__device__ __forceinline__ cf tw_mul_s(cf a, cf w) {
+    return DIR < 0 ? cmulf_s(a, w) : cmulcf_s(a, w);
+}
 // a + (DIR*i)*b  and  a - (DIR*i)*b
 template <int DIR>
 __device__ __forceinline__ cf cadd_di(cf a, cf b) {
@@ -134,14 +141,14 @@ __device__ __forceinline__ void radix16(cf (&v)[16]) {
     radix4<DIR>(v[2], v[6], v[10], v[14]);
     radix4<DIR>(v[3], v[7], v[11], v[15]);
     // twiddle W16^{n0*k1}; v[10] (W16^4 = -+i) is folded into its layer-B butterfly
-    v[5] = tw_mul<DIR>(v[5], w16<1>());
-    v[6] = tw_mul<DIR>(v[6], w16<2>());
-    v[7] = tw_mul<DIR>(v[7], w16<3>());
-    v[9] = tw_mul<DIR>(v[9], w16<2>());
-    v[11] = tw_mul<DIR>(v[11], w16<6>());
-    v[13] = tw_mul<DIR>(v[13], w16<3>());
-    v[14] = tw_mul<DIR>(v[14], w16<6>());
-    v[15] = tw_mul<DIR>(v[15], w16<9>());
+    v[5] = tw_mul_s<DIR>(v[5], w16<1>());
+    v[6] = tw_mul_s<DIR>(v[6], w16<2>());
+    v[7] = tw_mul_s<DIR>(v[7], w16<3>());
+    v[9] = tw_mul_s<DIR>(v[9], w16<2>());
+    v[11] = tw_mul_s<DIR>(v[11], w16<6>());
+    v[13] = tw_mul_s<DIR>(v[13], w16<3>());
+    v[14] = tw_mul_s<DIR>(v[14], w16<6>());
+    v[15] = tw_mul_s<DIR>(v[15], w16<9>());
     // layer B: for each k1, DFT4 over n0 on {4*k1 .. 4*k1+3} -> X[k1 + 4*k0] at v[4*k1 + k0]
     radix4<DIR>(v[0], v[1], v[2], v[3]);
     radix4<DIR>(v[4], v[5], v[6], v[7]);
