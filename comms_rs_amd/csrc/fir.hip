@@ -1454,8 +1454,14 @@ static int fir_pick(const comms_fir* h, size_t n) {
             algo = direct_ps < os_ps ? COMMS_FIR_DIRECT : COMMS_FIR_OVERLAP_SAVE;
         }
     }
-    if (algo == COMMS_FIR_OVERLAP_SAVE)
-        algo = h->n_eff <= 257 ? COMMS_FIR_OS1024 : h->n_eff <= 2049 ? COMMS_FIR_OS4096 : COMMS_FIR_OS16K;
+    if (algo == COMMS_FIR_OVERLAP_SAVE) {
+        // The 16384-point kernel costs the same whatever the tap count (halo 4096): 74-78 us per 2^24 samples.  The
+        // 4096-point kernel's halo is 256 * ceil((taps - 1) / 256): 61-67 us up to 1025 taps, 75 at 1537, 81 at 1793,
+        // 88 at 2049 (2^24; the same order at 2^26; below 2^23 samples the 16384-point segments are too few to fill
+        // the chip and the 4096-point kernel wins at every tap count) -- scripts/sweep_os.py, profiles/r03_sweep_os.txt.
+        const bool big = h->n_eff > 2049 || (h->n_eff > 1537 && n >= (static_cast<size_t>(1) << 23));
+        algo = h->n_eff <= 257 ? COMMS_FIR_OS1024 : big ? COMMS_FIR_OS16K : COMMS_FIR_OS4096;
+    }
     return algo;
 }
 

@@ -95,10 +95,13 @@ template <>
 struct BufRows<InU8> {
     static constexpr unsigned E = 2;
     __amdgpu_buffer_rsrc_t r;
-    __device__ __forceinline__ BufRows(InU8 in, size_t first, size_t count) : r(make_rsrc(in.p + first, count * E)) {}
+    unsigned limit;  // bytes; past the end the SAMPLE is zero (the byte 0 would convert to -1)
+    __device__ __forceinline__ BufRows(InU8 in, size_t first, size_t count)
+        : r(make_rsrc(in.p + first, count * E)), limit(count * E > 0xFFFFFFFFull ? 0xFFFFFFFFu : static_cast<unsigned>(count * E)) {}
     __device__ __forceinline__ float2 get(unsigned lane_bytes, unsigned row_bytes) const {
         const unsigned x = __builtin_amdgcn_raw_buffer_load_b16(r, lane_bytes, row_bytes, 0);
-        return make_float2(InU8::cvt(static_cast<float>(x & 0xffu)), InU8::cvt(static_cast<float>((x >> 8) & 0xffu)));
+        const float2 v = make_float2(InU8::cvt(static_cast<float>(x & 0xffu)), InU8::cvt(static_cast<float>((x >> 8) & 0xffu)));
+        return lane_bytes + row_bytes < limit ? v : make_float2(0.f, 0.f);
     }
 };
 

@@ -48,15 +48,16 @@ def test_u8_conversion_formula_is_exact_for_every_byte(c):
 
 
 @pytest.mark.parametrize("fmt", ["i16", "u8"])
-@pytest.mark.parametrize("algo,n", [("direct", 5000), ("os1024", 30000), ("dyn", 4200 * 768 + 100), ("os4096", 20000)])
+@pytest.mark.parametrize("algo,n", [("direct", 5000), ("os1024", 30000), ("dyn", 4200 * 768 + 100), ("os4096", 20000),
+                                    ("os16k", 100000)])
 def test_fir_node_reads_raw_iq(c, fmt, algo, n):
     """BatchFirNode on raw samples == BatchFirNode on the converted samples, bit for bit (same kernel, same
     arithmetic after the load stage), across two calls (the history is kept converted)."""
     rng = np.random.default_rng(5)
-    n_taps = 255 if algo != "os4096" else 600
+    n_taps = {"os4096": 600, "os16k": 3000}.get(algo, 255)
     taps = lowpass_taps(n_taps, 1 / 16)
     raw, x = raw_stream(rng, n, fmt)
-    al = {"direct": c.FIR_DIRECT, "os1024": c.FIR_OS1024_FIXED, "dyn": c.FIR_OS1024, "os4096": c.FIR_OS4096}[algo]
+    al = {"direct": c.FIR_DIRECT, "os1024": c.FIR_OS1024_FIXED, "dyn": c.FIR_OS1024, "os4096": c.FIR_OS4096, "os16k": c.FIR_OS16K}[algo]
     scale = 1.0 / 8192
     a = c.BatchFirNode(taps).set_algo(al).set_input_format(fmt, scale)
     b = c.BatchFirNode(taps).set_algo(al)
