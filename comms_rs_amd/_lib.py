@@ -160,6 +160,10 @@ _PROTOS = {
     "comms_nco_get_phase": [_vp, C.POINTER(_f64)],
     "comms_nco_destroy": [_vp],
     "comms_synth_iq_dev": [_vp, _sz, _u64, _u64, _i32, _vp],
+    "comms_shard_range": [_sz, _u32, _u32, _psz, _psz],
+    "comms_state_from_halo": [_vp, _sz, _vp],
+    "comms_shard_mixer_phase": [_f64, _f64, C.c_int64, C.POINTER(_f64)],
+    "comms_chain_prefix_len": [_sz, _sz, _i32, _psz],
 }
 _OTHER = {
     "comms_version": (C.c_char_p, []),

@@ -838,6 +838,34 @@ private:
     DevStream st_;
 };
 
+// ---------------------------------------------------------------- stream shards
+// One long stream over several GPUs, one node set per GPU: contiguous shards and one hand-over of the raw samples
+// in front of each shard.  Thin wrappers of the C entries (csrc/shard.cpp), so that a C++ host cuts a stream exactly
+// as bench.py / sharding.py do.
+inline std::pair<size_t, size_t> shard_range(size_t total, unsigned world, unsigned rank) {
+    size_t a = 0, b = 0;
+    throw_on(comms_shard_range(total, world, rank, &a, &b), "shard_range");
+    return {a, b};
+}
+// the n samples before a shard, time order -> BatchFirNode::new(taps, Some(state)) (fir_node.rs:193-211)
+inline std::vector<Complex32> state_from_halo(const std::vector<Complex32>& halo) {
+    std::vector<Complex32> st(halo.size());
+    throw_on(comms_state_from_halo(c32(halo.data()), halo.size(), c32(st.data())), "state_from_halo");
+    return st;
+}
+// oscillator phase of stream sample first_index: MixerNode::new(dphase, Some(phase)) of the shard's node
+inline double shard_mixer_phase(double phase0, double dphase, long long first_index) {
+    double ph = 0.0;
+    throw_on(comms_shard_mixer_phase(phase0, dphase, first_index, &ph), "shard_mixer_phase");
+    return ph;
+}
+// raw samples a chain shard runs through first (outputs dropped): FIR history + the sample FM.prev comes from
+inline size_t chain_prefix_len(size_t n_taps, size_t rate, bool fm_demod) {
+    size_t n = 0;
+    throw_on(comms_chain_prefix_len(n_taps, rate, fm_demod ? 1 : 0, &n), "chain_prefix_len");
+    return n;
+}
+
 // mixer / FIR / decimate [/ FM demod] as ONE node (comms_chain_*; an additional node, the results of
 // the reference nodes in series).  Out = Complex32 without FM demod, float with it.
 template <class Out>

@@ -24,13 +24,20 @@ with device tensors, "gloo" with CPU tensors in the tests and rehearsals.
 """
 
 
+# The arithmetic lives in the C ABI (csrc/shard.cpp: comms_shard_range, comms_state_from_halo,
+# comms_shard_mixer_phase, comms_chain_prefix_len) so that C++ / Rust hosts cut streams the same way; the functions
+# here are thin bindings, plus the torch.distributed messages.
 def shard_range(total, world, rank):
     """[start, stop) of `rank`'s contiguous shard of a `total`-sample stream."""
+    import ctypes as C
+
+    from ._lib import CommsError, check, lib
+
     if not (0 <= rank < world):
         raise ValueError("rank %d outside world %d" % (rank, world))
-    base, rem = divmod(total, world)
-    start = rank * base + min(rank, rem)
-    return start, start + base + (1 if rank < rem else 0)
+    a, b = C.c_size_t(), C.c_size_t()
+    check(lib().comms_shard_range(total, world, rank, C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 def halo_exchange(dist, tail, rank, world):
@@ -53,7 +60,14 @@ def halo_exchange(dist, tail, rank, world):
 
 def state_from_halo(halo_samples):
     """Reference `state` layout (newest first) from time-ordered halo samples."""
-    return halo_samples[::-1].copy()
+    import numpy as np
+
+    from ._lib import check, lib
+
+    h = np.ascontiguousarray(halo_samples, dtype=np.complex64)
+    out = np.empty_like(h)
+    check(lib().comms_state_from_halo(h.ctypes.data, h.size, out.ctypes.data))
+    return out
 
 
 def shard_mixer_phase(phase0, dphase, first_index):
@@ -62,11 +76,13 @@ def shard_mixer_phase(phase0, dphase, first_index):
     reference's per-sample `phase += dphase` with wrap (src/mixer.rs:79-82), so every rank's
     MixerNode continues the un-sharded oscillator without any communication.  `first_index`
     may be negative (the prefix of prime_chain starts before the shard)."""
-    import numpy as np
+    import ctypes as C
 
-    two_pi = np.longdouble(2.0) * np.longdouble(np.pi)
-    ph = np.fmod(np.longdouble(phase0) + np.longdouble(first_index) * np.longdouble(dphase), two_pi)
-    return float(ph + two_pi if ph < 0 else ph)
+    from ._lib import check, lib
+
+    out = C.c_double()
+    check(lib().comms_shard_mixer_phase(float(phase0), float(dphase), int(first_index), C.byref(out)))
+    return out.value
 
 
 def chain_prefix_len(n_taps, rate, fm_demod):
@@ -74,8 +90,13 @@ def chain_prefix_len(n_taps, rate, fm_demod):
     Without FM demod the FIR history is enough (n_taps - 1, rounded up).  With FM demod the
     shard must also reproduce the last decimated filter output before the boundary -- the
     output at input index (boundary - rate), which looks back another n_taps - 1 samples."""
-    need = (n_taps - 1) + (rate if fm_demod else 0)
-    return -(-need // rate) * rate
+    import ctypes as C
+
+    from ._lib import check, lib
+
+    out = C.c_size_t()
+    check(lib().comms_chain_prefix_len(n_taps, rate, 1 if fm_demod else 0, C.byref(out)))
+    return out.value
 
 
 def prime_chain(chain, prefix_ptr, prefix_len, discard_ptr, stream=0):

@@ -400,6 +400,62 @@ static void test_device_resident_fan_out() {
     CHECK(got_d == want_d);
 }
 
+// One stream cut over two chain nodes (as two GPUs would hold them): the second shard's node is created with the
+// oscillator phase of the first PREFIX sample, runs the prefix (outputs dropped) and then its shard -- and the two
+// shards' outputs are the single node's over the whole stream.  Also the node-by-node form: FIR state from the halo,
+// mixer phase in closed form.  (The prefix / halo is what one rank receives from its left neighbour.)
+static void test_stream_cut_over_two_chain_nodes() {
+    const size_t n = 2 * 40960, half = n / 2;
+    std::vector<C> x(n);
+    for (size_t i = 0; i < n; ++i) {
+        const double ph = -2.0 * M_PI * 0.05 * static_cast<double>(i) + 8.0 * std::cos(2.0 * M_PI * static_cast<double>(i) / 4096.0);
+        x[i] = C(static_cast<float>(std::cos(ph)), static_cast<float>(std::sin(ph)));
+    }
+    std::vector<C> taps(127);
+    for (int k = 0; k < 127; ++k) {
+        const double t = k - 63.0, sc = t == 0.0 ? 1.0 : std::sin(M_PI * t / 8.0) / (M_PI * t / 8.0);
+        taps[k] = C(static_cast<float>(0.125 * sc * (0.54 - 0.46 * std::cos(2.0 * M_PI * k / 126.0))), 0.f);
+    }
+    const double dphase = 2.0 * M_PI * 0.05, phase0 = 0.4;
+    const size_t rate = 8;
+    CHECK(shard_range(n, 2, 0) == std::make_pair(size_t(0), half) && shard_range(n, 2, 1) == std::make_pair(half, n));
+    CHECK(shard_range(10, 4, 1) == std::make_pair(size_t(3), size_t(6)) && shard_range(10, 4, 3) == std::make_pair(size_t(8), size_t(10)));
+    const size_t W = chain_prefix_len(taps.size(), rate, true);
+    CHECK(W == 136 && chain_prefix_len(255, 8, false) == 256 && chain_prefix_len(1, 8, false) == 0);
+
+    ChainNodeDev<float> whole(dphase, phase0, taps, rate);
+    const std::vector<float> want = whole.run(DeviceBuf<C>::from_host(x)).value().to_host();
+
+    ChainNodeDev<float> left(dphase, phase0, taps, rate);
+    ChainNodeDev<float> right(dphase, shard_mixer_phase(phase0, dphase, static_cast<long long>(half - W)), taps, rate);
+    std::vector<float> got = left.run(DeviceBuf<C>::from_host(std::vector<C>(x.begin(), x.begin() + half))).value().to_host();
+    (void)right.run(DeviceBuf<C>::from_host(std::vector<C>(x.begin() + (half - W), x.begin() + half))).value();  // primed
+    const std::vector<float> g1 = right.run(DeviceBuf<C>::from_host(std::vector<C>(x.begin() + half, x.end()))).value().to_host();
+    got.insert(got.end(), g1.begin(), g1.end());
+    CHECK(got.size() == want.size());
+    double worst = 0.0;
+    for (size_t i = 0; i < got.size() && i < want.size(); ++i) {
+        double e = std::fabs(static_cast<double>(got[i]) - want[i]);
+        if (e > M_PI) e = 2.0 * M_PI - e;
+        worst = std::fmax(worst, e);
+    }
+    CHECK(worst < 1e-5);  // the oscillator restarts from a closed-form phase: not the same f32 everywhere, 1e-5 rad
+
+    // node by node: FIR -> mixer -> decimate, the second shard's FIR state from the halo: as many samples as taps
+    // (the reference's state holds taps.len() samples, fir_node.rs:97-105; fewer would truncate the filter, fir.rs:53)
+    BatchFirNode f_all(taps);
+    BatchMixerNode m_all(dphase, phase0);
+    const std::vector<C> ref = DecimateNode<C>(rate).run(m_all.run(f_all.run(x).value()).value()).value();
+    BatchFirNode f_r(taps, state_from_halo(std::vector<C>(x.begin() + (half - 127), x.begin() + half)));
+    BatchMixerNode m_r(dphase, shard_mixer_phase(phase0, dphase, static_cast<long long>(half)));
+    const std::vector<C> r2 =
+        DecimateNode<C>(rate).run(m_r.run(f_r.run(std::vector<C>(x.begin() + half, x.end())).value()).value()).value();
+    CHECK(r2.size() * 2 == ref.size());
+    double w2 = 0.0;
+    for (size_t i = 0; i < r2.size() && r2.size() * 2 == ref.size(); ++i) w2 = std::fmax(w2, std::abs(r2[i] - ref[r2.size() + i]));
+    CHECK(w2 < 2e-6);
+}
+
 static void test_device_resident_chain_and_fft() {
     // config 3 as a graph of device-resident messages: source -> fused chain (mixer, 127-tap LPF, /8,
     // FM demod) -> sink, against the four host-vector nodes in series; then FFT -> IFFT round trip
@@ -555,6 +611,7 @@ int main() {
     test_device_resident_stream_many_messages();
     test_device_resident_fan_out();
     test_device_resident_chain_and_fft();
+    test_stream_cut_over_two_chain_nodes();
     test_per_sample_nodes_keep_up();
     if (g_fail) {
         std::fprintf(stderr, "%d check(s) failed\n", g_fail);

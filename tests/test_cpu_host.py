@@ -320,3 +320,30 @@ def test_buf_alloc_rejects_absurd_sizes_before_touching_the_pool():
         with pytest.raises(c.CommsError) as e:
             c.DeviceBuf(bad)
         assert e.value.code == c.COMMS_ERR_ARG
+
+
+def test_shard_helpers_of_the_c_abi_match_their_definition():
+    """comms_shard_range / comms_state_from_halo / comms_shard_mixer_phase / comms_chain_prefix_len (host arithmetic in
+    the C ABI, bound by sharding.py and host/comms/nodes.hpp) against their definitions restated here."""
+    from comms_rs_amd import sharding as sh
+
+    for total, world in ((10, 4), (1 << 30, 8), (7, 8), (0, 3), (4096, 1)):
+        cuts = [sh.shard_range(total, world, r) for r in range(world)]
+        base, rem = divmod(total, world)
+        assert cuts[0][0] == 0 and cuts[-1][1] == total
+        for r, (a, b) in enumerate(cuts):
+            assert b - a == base + (1 if r < rem else 0) and (r == 0 or a == cuts[r - 1][1])
+    with pytest.raises(ValueError):
+        sh.shard_range(10, 2, 2)
+    h = (np.arange(7) + 1j * np.arange(7)[::-1]).astype(np.complex64)
+    assert np.array_equal(sh.state_from_halo(h), h[::-1])
+    two_pi = np.longdouble(2.0) * np.longdouble(np.pi)
+    for p0, dp, i in ((0.0, 2 * np.pi * 0.1, 1 << 27), (0.3, 0.123, -136), (1.0, 5.9, 7 * (1 << 27)), (0.0, 0.0, 5)):
+        want = np.fmod(np.longdouble(p0) + np.longdouble(i) * np.longdouble(dp), two_pi)
+        want = float(want + two_pi if want < 0 else want)
+        got = sh.shard_mixer_phase(p0, dp, i)
+        assert 0.0 <= got < 2 * np.pi + 1e-12 and abs(got - want) < 1e-12
+    for taps, rate, fm in ((127, 8, True), (255, 8, False), (63, 5, True), (1, 8, False), (4097, 1, False), (2, 0, True)):
+        r = max(rate, 1)
+        need = (taps - 1) + (r if fm else 0)
+        assert sh.chain_prefix_len(taps, rate, fm) == -(-need // r) * r
