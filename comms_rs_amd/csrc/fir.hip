@@ -821,7 +821,6 @@ __global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(In in,
 // filter spectrum, and the mirror image brings the samples back.  Three workgroup
 // barriers per segment.  LDS: 16 x 1090 slice buffers + W1024 / W64 / W256 / W16384
 // tables = 158 KiB, one workgroup per CU.
-constexpr int XV = 12288;      // new samples per segment (halo 4096)
 constexpr int X_BUF = 1090;    // per-wave slice buffer (>= 1088; 2180 dwords = 4 mod 64 banks)
 constexpr size_t X_LDS_BYTES = (1024 + 64 + 16 * X_BUF) * sizeof(float2) + 32 * sizeof(unsigned);  // tables, slices, counters
 #ifndef COMMS_OS16K_CARRY
@@ -867,16 +866,21 @@ __device__ __forceinline__ void x_wait_all16(const unsigned* cnt, unsigned targe
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <class In = const float2*>
+template <int HR, class In = const float2*>
 __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
                                                             const float2* __restrict__ hist, int hist_len,
                                                             float2* __restrict__ out, size_t n, size_t nseg,
                                                             XTables tb, float2* __restrict__ new_hist, int delay,
                                                             int accumulate) {
+    // HR = halo rows of 1024 samples (1 ... 4: up to 1025 / 2049 / 3073 / 4097 taps): a segment keeps 16 - HR rows.
+    // (A compile-time value: as a kernel argument the row loops turned into chains of uniform branches and the
+    // kernel lost 11 % -- 591 -> 658 us at 2^27 samples, 4097 taps.)
+    constexpr int hr = HR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* tw1 = reinterpret_cast<cf*>(smem);  // [16][64]
     cf* tw2 = tw1 + 1024;                   // [16][4]
     cf* bufs = tw2 + 64;                    // [16][X_BUF]
+    const size_t xv = static_cast<size_t>(16 - hr) * 1024;  // new samples per segment
     unsigned* slice_in = reinterpret_cast<unsigned*>(bufs + 16 * X_BUF);  // [16]
     unsigned* slice_out = slice_in + 16;                                   // [16]
     const int tid = threadIdx.x;
@@ -904,10 +908,10 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
     // The new rows of a segment are requested one phase ahead -- between the slice work and the inverse stage 1 of the
     // segment before, where the registers are free -- so their HBM latency runs behind the workgroup's second
     // wait instead of in front of an idle CU.
-    constexpr int R0 = COMMS_OS16K_CARRY ? 4 : 0;  // first row that is fetched per segment
+    const int R0 = COMMS_OS16K_CARRY ? hr : 0;  // first row that is fetched per segment
     cf v[16], rows[16];
     auto fetch_rows = [&](size_t sg, int first) {
-        const long long base = static_cast<long long>(sg * XV) - 4096 - delay;
+        const long long base = static_cast<long long>(sg * xv) - 1024 * hr - delay;
         if (base >= 0) {  // no history involved: buffer loads, zeros past the end of the stream
             const BufRows<In> br(in, static_cast<size_t>(base), static_cast<size_t>(base) < n ? n - static_cast<size_t>(base) : 0);
 #pragma unroll
@@ -922,16 +926,17 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
     if (seg_lo < seg_hi) fetch_rows(seg_lo, 0);
     unsigned done = 0;  // segments this workgroup has finished
     for (size_t seg = seg_lo; seg < seg_hi; ++seg, ++done) {
-        const size_t nb = seg * XV;
+        const size_t nb = seg * xv;
         // ---- stage 1: radix-16 over the rows; value k of thread tid is point tid of slice k.  No wait in front
         // of the writes: word (k, tid) was last read by this very thread (inverse stage 1 of the previous
         // segment), and wave k is past its slice work for that segment or nobody could have read it.
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = rows[a];
 #if COMMS_OS16K_CARRY
+        // the next segment's halo = this segment's last hr rows (HBM would see them again otherwise: the XCD streams
+        // 7 MiB per segment time through a 4 MiB L2)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) rows[a] = rows[12 + a];  // the next segment's halo (HBM would see it again otherwise:
-                                                             // the XCD streams 7 MiB per segment time through a 4 MiB L2)
+        for (int a = 0; a < HR; ++a) rows[a] = rows[16 - HR + a];
 #endif
         radix16<-1>(v);
 #pragma unroll
@@ -967,10 +972,12 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
         // stores (and the accumulating pass's loads) through a buffer resource that ends at sample n: nothing past it
         const __amdgpu_buffer_rsrc_t ors = make_rsrc(out + nb, nb < n ? (n - nb) * sizeof(float2) : 0);
 #pragma unroll
-        for (int a = 4; a < 16; ++a) {
+        for (int a = 1; a < 16; ++a) {
+            if (a < hr) continue;  // (workgroup-uniform)
+            const unsigned row = static_cast<unsigned>(a - hr) * 8192u;
             cf y = v[R16_POS(a)];
-            if (accumulate) y = y + to_cf(BufRows<const float2*>::get_from(ors, tid * 8, (a - 4) * 8192));
-            __builtin_amdgcn_raw_buffer_store_b64(bv2u{__float_as_uint(y.x), __float_as_uint(y.y)}, ors, tid * 8, (a - 4) * 8192, 0);
+            if (accumulate) y = y + to_cf(BufRows<const float2*>::get_from(ors, tid * 8, row));
+            __builtin_amdgcn_raw_buffer_store_b64(bv2u{__float_as_uint(y.x), __float_as_uint(y.y)}, ors, tid * 8, row, 0);
         }
     }
 }
@@ -1409,12 +1416,14 @@ static comms_status_t fir_prepare_os16k(comms_fir* h) {
         h->d_xh.push_back(d);
     }
     const int lds = static_cast<int>(X_LDS_BYTES);
-    COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os16k_kernel<const float2*>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os16k_kernel<InI16>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os16k_kernel<InU8>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#define COMMS_X_ATTR(HRV, INV) \
+    COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os16k_kernel<HRV, INV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds))
+#define COMMS_X_ATTR4(INV) COMMS_X_ATTR(1, INV); COMMS_X_ATTR(2, INV); COMMS_X_ATTR(3, INV); COMMS_X_ATTR(4, INV)
+    COMMS_X_ATTR4(const float2*);
+    COMMS_X_ATTR4(InI16);
+    COMMS_X_ATTR4(InU8);
+#undef COMMS_X_ATTR4
+#undef COMMS_X_ATTR
     h->x_ready = true;
     return COMMS_OK;
 }
@@ -1455,11 +1464,12 @@ static int fir_pick(const comms_fir* h, size_t n) {
         }
     }
     if (algo == COMMS_FIR_OVERLAP_SAVE) {
-        // The 16384-point kernel costs the same whatever the tap count (halo 4096): 74-78 us per 2^24 samples.  The
-        // 4096-point kernel's halo is 256 * ceil((taps - 1) / 256): 61-67 us up to 1025 taps, 75 at 1537, 81 at 1793,
-        // 88 at 2049 (2^24; the same order at 2^26; below 2^23 samples the 16384-point segments are too few to fill
-        // the chip and the 4096-point kernel wins at every tap count) -- scripts/sweep_os.py, profiles/r03_sweep_os.txt.
-        const bool big = h->n_eff > 2049 || (h->n_eff > 1537 && n >= (static_cast<size_t>(1) << 23));
+        // 16384-point kernel (halo 1024 * ceil((taps - 1) / 1024)): 71-73 us per 2^24 samples up to 2049 taps, 74-78 at
+        // 4097.  4096-point kernel (halo 256 * ceil((taps - 1) / 256)): 61-67 us up to 1025 taps, 74 at 1281, 75 at
+        // 1537, 81 at 1793, 88 at 2049 (2^24; the same order at 2^26).  Below 2^23 samples the 16384-point segments are
+        // too few to fill the chip and the 4096-point kernel wins at every tap count -- scripts/sweep_os.py,
+        // profiles/r03_sweep_os.txt.
+        const bool big = h->n_eff > 2049 || (h->n_eff > 1281 && n >= (static_cast<size_t>(1) << 23));
         algo = h->n_eff <= 257 ? COMMS_FIR_OS1024 : big ? COMMS_FIR_OS16K : COMMS_FIR_OS4096;
     }
     return algo;
@@ -1623,6 +1633,16 @@ static comms_status_t launch_fixed_hr(int hr, int wpb, size_t runs, hipStream_t 
     }
 }
 template <class In>
+static void launch_os16k_hr(int hr, unsigned blocks, size_t lds, hipStream_t s, In in, const float2* hist, int n_eff, float2* o, size_t n,
+                            size_t nseg, const XTables& tb, float2* nh, int dl, int acc) {
+    switch (hr) {
+        case 1: fir_os16k_kernel<1, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc); break;
+        case 2: fir_os16k_kernel<2, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc); break;
+        case 3: fir_os16k_kernel<3, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc); break;
+        default: fir_os16k_kernel<4, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc); break;
+    }
+}
+template <class In>
 static void launch_direct_in(comms_fir* h, In in, const float2* hist, float2* o, size_t n, float2* nh, unsigned blocks,
                              size_t lds, int vec4, hipStream_t s) {
     if (h->real_taps)
@@ -1698,7 +1718,10 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
         COMMS_TRY(launch_ok("fir_os1024_kernel"));
     } else if (algo == COMMS_FIR_OS16K) {
         COMMS_TRY(fir_prepare_os16k(h));
-        const size_t nseg = (n + XV - 1) / XV;
+        // halo rows: what the taps need (one pass), the full four for the 4097-tap partitions of longer filters
+        const int hr = h->x_part > 1 ? 4 : h->n_eff <= 1025 ? 1 : h->n_eff <= 2049 ? 2 : h->n_eff <= 3073 ? 3 : 4;
+        const size_t xv = static_cast<size_t>(16 - hr) * 1024;
+        const size_t nseg = (n + xv - 1) / xv;
         const unsigned blocks = static_cast<unsigned>(nseg < static_cast<size_t>(kNumCU) ? nseg : kNumCU);
         const size_t lds = X_LDS_BYTES;
         h->tic(s);
@@ -1708,13 +1731,11 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
                        reinterpret_cast<const cf*>(h->d_xh[pt])};
             const int dl = pt * X_PART, acc = pt ? 1 : 0;
             if (h->in_fmt == COMMS_IQ_I16)
-                fir_os16k_kernel<InI16><<<dim3(blocks), dim3(1024), lds, s>>>(InI16{static_cast<const short2*>(d_in), h->in_scale}, hist, h->n_eff,
-                                                                              o, n, nseg, tb, nh, dl, acc);
+                launch_os16k_hr(hr, blocks, lds, s, InI16{static_cast<const short2*>(d_in), h->in_scale}, hist, h->n_eff, o, n, nseg, tb, nh, dl, acc);
             else if (h->in_fmt == COMMS_IQ_U8)
-                fir_os16k_kernel<InU8><<<dim3(blocks), dim3(1024), lds, s>>>(InU8{static_cast<const uchar2*>(d_in)}, hist, h->n_eff, o, n, nseg, tb,
-                                                                             nh, dl, acc);
+                launch_os16k_hr(hr, blocks, lds, s, InU8{static_cast<const uchar2*>(d_in)}, hist, h->n_eff, o, n, nseg, tb, nh, dl, acc);
             else
-                fir_os16k_kernel<const float2*><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, h->n_eff, o, n, nseg, tb, nh, dl, acc);
+                launch_os16k_hr(hr, blocks, lds, s, in, hist, h->n_eff, o, n, nseg, tb, nh, dl, acc);
         }
         h->toc(s);
         COMMS_TRY(launch_ok("fir_os16k_kernel"));

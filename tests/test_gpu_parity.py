@@ -149,8 +149,8 @@ def test_fir_long_filters_partitioned(c, n_taps):
         assert np.array_equal(node.state(n_taps), st)
 
 
-@pytest.mark.parametrize("n_taps", [1600, 2050, 3000, 4097])
-@pytest.mark.parametrize("n", [1, 12287, 12288, 12289, 40000])
+@pytest.mark.parametrize("n_taps", [300, 1025, 1026, 1600, 2049, 2050, 3000, 3073, 3074, 4097])  # halo rows 1, 1, 2, 2, 2, 3, 3, 3, 4, 4
+@pytest.mark.parametrize("n", [1, 12287, 12288, 12289, 13312, 15360, 15361, 40000])
 def test_fir_os16k_vs_oracle(c, n_taps, n):
     rng = np.random.default_rng(n_taps + n)
     taps = (rand_c(rng, n_taps) / np.sqrt(n_taps)).astype(np.complex64)
@@ -377,11 +377,12 @@ def test_fir_auto_selection_and_errors(c):
     assert node.algo_for(1 << 24) == c.FIR_OS1024
     assert c.BatchFirNode(np.ones(258, np.complex64)).algo_for(1 << 24) == c.FIR_OS4096
     assert c.BatchFirNode(np.ones(2050, np.complex64)).algo_for(1 << 24) == c.FIR_OS16K
-    # 1538 ... 2049 taps: the 16384-point kernel on long streams (its cost does not depend on the tap count, the
-    # 4096-point kernel's halo is half a segment there), the 4096-point one below 2^23 samples
+    # 1282 ... 2049 taps: the 16384-point kernel on long streams (a halo of 2048 of 16384 points; the 4096-point
+    # kernel's halo is 1536 ... 2048 of 4096 there), the 4096-point one below 2^23 samples
     assert c.BatchFirNode(np.ones(1793, np.complex64)).algo_for(1 << 24) == c.FIR_OS16K
     assert c.BatchFirNode(np.ones(1793, np.complex64)).algo_for(1 << 22) == c.FIR_OS4096
-    assert c.BatchFirNode(np.ones(1537, np.complex64)).algo_for(1 << 24) == c.FIR_OS4096
+    assert c.BatchFirNode(np.ones(1282, np.complex64)).algo_for(1 << 24) == c.FIR_OS16K
+    assert c.BatchFirNode(np.ones(1281, np.complex64)).algo_for(1 << 24) == c.FIR_OS4096
     assert node.algo_for(4) == c.FIR_DIRECT
     assert c.BatchFirNode(np.ones(8, np.complex64)).algo_for(1 << 24) == c.FIR_DIRECT
     assert c.BatchFirNode(np.ones(63, np.complex64)).algo_for(1 << 24) == c.FIR_OS1024
