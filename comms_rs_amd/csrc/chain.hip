@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void chain_raw_hist_kernel(const float2* __res
 struct comms_chain : Handle {
     bool fused = false;
     bool decim = false;  // fused on the time-domain decimating kernel
+    bool decim_any = false;  // ... on its any-rate form (fir_decim_any.hip; a mixer in front is folded into the taps)
     bool fm_separate = false;  // fused mixer / FIR / decimate launch, FM demod as its own (small) kernel behind it
     bool pre_as_post = false;  // series of launches, mixer in front folded into the taps: runs as the mixer-behind form
     int mode = 0;
@@ -128,7 +129,44 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
                              : 0;
     const bool can_decim = !(flags & (COMMS_CHAIN_UNFUSED | COMMS_CHAIN_FREQ_DOMAIN)) &&
                            (decim_ok == 2 || (decim_ok == 1 && (flags & COMMS_CHAIN_TIME_DOMAIN)));
-    if (st == COMMS_OK && (can_fuse || can_decim || can_hybrid)) {
+    // Rates the per-rate kernel is not built for (17 and up; 11 / 13 / 15 with complex taps): the any-rate kernel (half
+    // a wave per output).  Against the overlap-save launch it replaces (58-60 us at 2^24 samples whatever the rate): 255
+    // taps 67 us at rate 17, 58 at 20, 42 at 32, 30 at 100, 11 at 1000; 127 taps 56 at 17; 63 taps 51 at 17
+    // (profiles/r03_bench_chain_rates.txt) -- so from rate 17 up to 160 taps, from rate 20 beyond; taps up to 512, where
+    // the alternative is four kernels in series.  COMMS_CHAIN_TIME_DOMAIN forces it wherever it can run.
+    static const int any_min_rate = [] { const char* v = getenv("COMMS_ANY_MIN_RATE"); return v && *v ? atoi(v) : 0; }();
+    const size_t any_from = any_min_rate > 0 ? static_cast<size_t>(any_min_rate) : n_taps <= 160 || n_taps > 257 ? 17 : 20;
+    const bool can_any = st == COMMS_OK && !can_decim && !(flags & (COMMS_CHAIN_UNFUSED | COMMS_CHAIN_FREQ_DOMAIN)) &&
+                         comms_fir_decim_any_supported(h->fir, static_cast<uint32_t>(rate)) &&
+                         ((flags & COMMS_CHAIN_TIME_DOMAIN) || rate >= any_from);
+    if (can_any && !h->mixer_after) {
+        // mixer in front: sum_k h[k] x[n-k] e^{i phi(n-k)} = e^{i phi(n)} sum_k (h[k] e^{-i k dphi}) x[n-k] -- the kernel
+        // filters the RAW samples with modulated (complex) taps and mixes the kept outputs (the roundings fall
+        // elsewhere than in the reference's order, inside the parity tolerance: test_chain_any_rate)
+        std::vector<comms_c32> mod(n_taps);
+        for (size_t k = 0; k < n_taps; ++k) {
+            const double ang = -h->dphase * static_cast<double>(k);
+            const double cr = std::cos(ang), ci = std::sin(ang);
+            const double tr = taps[k].re, ti = taps[k].im;
+            mod[k].re = static_cast<float>(tr * cr - ti * ci);
+            mod[k].im = static_cast<float>(tr * ci + ti * cr);
+        }
+        comms_fir_destroy(h->fir);
+        h->fir = nullptr;
+        st = comms_fir_create(mod.data(), n_taps, nullptr, 0, device, &h->fir);
+    }
+    if (st == COMMS_OK && can_any) {
+        h->fused = true;
+        h->decim_any = true;
+        h->mode = COMMS_CHAIN_POST | COMMS_CHAIN_DEC | (h->fm_demod ? COMMS_CHAIN_FM : 0);
+        h->frac = mix_to_turns(mix_wrap_dphase(dphase));
+        h->turns = mix_to_turns(phase);
+        for (int i = 0; i < 2 && st == COMMS_OK; ++i) {
+            hipError_t e = hipMalloc(&h->d_prev[i], sizeof(float2));
+            if (e == hipSuccess) e = zero_device(h->d_prev[i], sizeof(float2));
+            if (e != hipSuccess) st = fail(COMMS_ERR_DEVICE, "chain state alloc: %s", hipGetErrorString(e));
+        }
+    } else if (st == COMMS_OK && (can_fuse || can_decim || can_hybrid)) {
         h->fused = true;
         h->decim = can_decim;
         h->fm_separate = !can_decim && !can_fuse;
@@ -187,7 +225,7 @@ comms_status_t comms_chain_create(double dphase, double phase, const comms_c32* 
 
 comms_status_t comms_chain_is_fused(const comms_chain_t* h, int32_t* out_fused) {
     COMMS_ARG(h && out_fused, "NULL argument");
-    *out_fused = h->fused ? (h->decim ? 2 : 1) : 0;
+    *out_fused = h->fused ? (h->decim_any ? 3 : h->decim ? 2 : 1) : 0;
     return COMMS_OK;
 }
 
@@ -207,7 +245,7 @@ comms_status_t comms_chain_run_dev(comms_chain_t* h, const comms_c32* d_in_any, 
     hipStream_t hs = nullptr;
     COMMS_TRY(h->enter(stream, &hs));  // the stages' state (history, prev) advances in stream order
     void* s = static_cast<void*>(hs);
-    if (h->in_fmt != COMMS_IQ_C32 && !(h->fused && h->decim)) {
+    if (h->in_fmt != COMMS_IQ_C32 && !(h->fused && (h->decim || h->decim_any))) {
         // only the time-domain kernel reads wire formats in its load stage; everything else gets one
         // conversion pass first (same arithmetic, iqformat.hip)
         COMMS_TRY(h->t0.reserve(n * sizeof(comms_c32)));
@@ -225,7 +263,10 @@ comms_status_t comms_chain_run_dev(comms_chain_t* h, const comms_c32* d_in_any, 
             COMMS_TRY(h->t3.reserve(n_dec * sizeof(comms_c32)));
             stage_out = h->t3.p;
         }
-        if (h->decim)
+        if (h->decim_any)
+            COMMS_TRY(comms_fir_run_decim_any_dev(h->fir, d_in, n, stage_out, h->mode, h->turns, h->frac, static_cast<uint32_t>(h->rate),
+                                                  h->d_prev[h->cur], h->d_prev[h->cur ^ 1], s));
+        else if (h->decim)
             COMMS_TRY(comms_fir_run_decim_dev(h->fir, d_in, n, stage_out, h->mode, h->turns, h->frac, static_cast<uint32_t>(h->rate),
                                               h->d_prev[h->cur], h->d_prev[h->cur ^ 1], s));
         else
@@ -291,7 +332,7 @@ comms_status_t comms_chain_set_input_format(comms_chain_t* h, int32_t format, fl
     COMMS_ARG(format != COMMS_IQ_I16 || std::isfinite(scale), "scale must be finite");
     h->in_fmt = format;
     h->in_scale = format == COMMS_IQ_I16 ? scale : 1.0f;
-    if (h->fused && h->decim) COMMS_TRY(comms_fir_set_input_format(h->fir, format, scale));
+    if (h->fused && (h->decim || h->decim_any)) COMMS_TRY(comms_fir_set_input_format(h->fir, format, scale));
     return COMMS_OK;
 }
 

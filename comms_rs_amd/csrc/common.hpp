@@ -36,6 +36,12 @@ extern "C" COMMS_INTERNAL comms_status_t comms_fir_run_decim_dev(comms_fir_t* h,
                                                   int32_t mode, uint64_t turns0, uint64_t frac, uint32_t rate,
                                                   const void* fm_prev, void* fm_prev_new, void* stream);
 
+// ... and on the any-rate time-domain kernel (fir_decim_any.hip): mixer behind the FIR only
+extern "C" COMMS_INTERNAL int32_t comms_fir_decim_any_supported(const comms_fir_t* h, uint32_t rate);
+extern "C" COMMS_INTERNAL comms_status_t comms_fir_run_decim_any_dev(comms_fir_t* h, const void* d_in, size_t n, void* d_out,
+                                                  int32_t mode, uint64_t turns0, uint64_t frac, uint32_t rate,
+                                                  const void* fm_prev, void* fm_prev_new, void* stream);
+
 namespace comms {
 
 // ---- thread-local last error -------------------------------------------------

@@ -308,7 +308,7 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
                 }
             }
         } else {
-        constexpr int CH = CHX ? CHX : OPL == 2 ? (R <= 10 ? R : R / 2) : (R <= 4 ? R : R % 4 == 0 ? R / 2 : R <= 6 ? R : R / 2);  // taps per chunk
+        constexpr int CH = CHX ? CHX : OPL == 2 ? ((R <= 10 || R % 2) ? R : R / 2) : (R <= 4 ? R : R % 4 == 0 ? R / 2 : R <= 6 ? R : R / 2);  // taps per chunk (odd rates: whole blocks of R)
         constexpr int NCH = PR / CH;
         static_assert(PR % CH == 0 && (NCH == 1 || NCH % 2 == 0), "chunks must pair up inside a block (or be whole blocks)");
         constexpr int NP = ((CH & 1) + CH + (OPL - 1) * R + 1) / 2;  // SGPR pairs (A[2i], A[2i+1]) covering the chunk's taps of all OPL outputs (an odd chunk may start in a pair's hi half)
@@ -501,6 +501,12 @@ static comms_status_t launch_decim(const DecimArgs& a, bool real, int opl, int t
     return pre ? launch_decim_v<R, 2, true, true>(a, s) : launch_decim_v<R, 2, true, false>(a, s);
 }
 
+// odd rates above 10 (chunks of R taps): real taps only
+template <int R>
+static comms_status_t launch_decim_real(const DecimArgs& a, hipStream_t s) {
+    return (a.mode & COMMS_CHAIN_PRE) ? launch_decim_v<R, 2, true, true>(a, s) : launch_decim_v<R, 2, true, false>(a, s);
+}
+
 }  // namespace comms
 
 using namespace comms;
@@ -519,7 +525,10 @@ void comms_debug_decim_stamps(void* d_buf) { g_decim_stamps = static_cast<unsign
 static int32_t decim_macs(const comms_fir_t* h, uint32_t rate) {
     if (!h || h->n_eff < 1 || h->n_eff > DC_NMAX) return -1;
     switch (rate) {
-        case 2: case 3: case 4: case 5: case 6: case 8: case 10: case 12: case 16: break;
+        case 2: case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 12: case 14: case 16: break;
+        case 11: case 13: case 15:  // chunks of R taps: the SGPR pairs of complex taps do not fit
+            if (!h->real_taps) return -1;
+            break;
         default: return -1;
     }
     return (h->n_eff + static_cast<int>(rate) - 1) / static_cast<int>(rate) * (h->real_taps ? 1 : 2);
@@ -551,7 +560,7 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
     COMMS_ARG(h != nullptr, "handle is NULL");
     COMMS_ARG((d_in && d_out) || !n, "NULL device pointer");
     COMMS_ARG(comms_fir_decim_supported(h, rate) != 0,
-              "the decimating chain kernel supports <= 257 taps and rates 2,3,4,5,6,8,10,12,16");
+              "the decimating chain kernel supports <= 257 taps and rates 2 ... 16 (11, 13, 15: real taps)");
     COMMS_ARG(n % rate == 0, "n must be a multiple of the decimation rate");
     COMMS_ARG((mode & COMMS_CHAIN_DEC) && !((mode & COMMS_CHAIN_PRE) && (mode & COMMS_CHAIN_POST)), "bad chain mode");
     COMMS_TRY(use_device(h->device));
@@ -636,9 +645,15 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
         case 4: st = launch_decim<4>(a, real, opl, tile, s); break;
         case 5: st = launch_decim<5>(a, real, opl, tile, s); break;
         case 6: st = launch_decim<6>(a, real, opl, tile, s); break;
+        case 7: st = launch_decim<7>(a, real, 2, tile, s); break;
         case 8: st = launch_decim<8>(a, real, opl, tile, s); break;
+        case 9: st = launch_decim<9>(a, real, 2, tile, s); break;
         case 10: st = launch_decim<10>(a, real, 2, tile, s); break;
+        case 11: st = launch_decim_real<11>(a, s); break;
         case 12: st = launch_decim<12>(a, real, 2, tile, s); break;
+        case 13: st = launch_decim_real<13>(a, s); break;
+        case 14: st = launch_decim<14>(a, real, 2, tile, s); break;
+        case 15: st = launch_decim_real<15>(a, s); break;
         case 16: st = launch_decim<16>(a, real, 2, tile, s); break;
         default: return fail(COMMS_ERR_ARG, "no decimating kernel for rate %d", R);
     }

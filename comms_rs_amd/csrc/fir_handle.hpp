@@ -158,6 +158,8 @@ struct comms_fir : comms::Handle {
     comms::Scratch conv;        // converted copy, for the kernels that do not read wire formats themselves
     float* d_qt = nullptr;      // decimating chain kernel, four outputs per lane: tap quadruples for rate qt_rate
     int qt_rate = 0;
+    float2* d_any_taps = nullptr;  // any-rate chain kernel: taps zero-padded to 32 * any_nt
+    int any_nt = 0;
     // direct form
     int NP = 0;          // taps padded to a multiple of 8
     float2* d_taps_pad = nullptr;

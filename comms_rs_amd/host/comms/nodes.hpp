@@ -891,7 +891,7 @@ public:
         if (st != COMMS_OK) return to_node_error(st);
         return out;
     }
-    int fused_kind() const {  // 0 four kernels, 1 overlap-save fusion, 2 time-domain decimating kernel
+    int fused_kind() const {  // 0 four kernels, 1 overlap-save fusion, 2 time-domain decimating kernel, 3 its any-rate form
         int32_t f = 0;
         comms_chain_is_fused(h_, &f);
         return f;

@@ -466,10 +466,10 @@ class ChainNode(_Handle):
 
     @property
     def kernel(self):
-        """"unfused", "freq" (fir_os1024_kernel) or "time" (fir_decim_kernel)."""
+        """"unfused", "freq" (fir_os1024_kernel), "time" (fir_decim_kernel) or "time_any" (fir_decim_any_kernel)."""
         f = C.c_int32()
         check(lib().comms_chain_is_fused(self._h, C.byref(f)))
-        return ("unfused", "freq", "time")[f.value]
+        return ("unfused", "freq", "time", "time_any")[f.value]
 
     _fmt = "c32"
 

@@ -1059,10 +1059,10 @@ def test_metric_chain_fir_mixer_decimate_fused(c, rate, kernel):
     dphase = 2 * np.pi * 0.1
     node = c.ChainNode(dphase, 0.3, taps, rate, False, mixer_after_fir=True, kernel=kernel)
     assert node.fused
-    if kernel == "time":  # forced: every rate with an instantiation, whatever taps/rate is
-        assert node.kernel == ("time" if rate in (2, 5, 8) else "freq")
-    elif kernel == "auto":  # 255 real taps: 32 MACs per input sample at rate 8, 128 at rate 2
-        assert node.kernel == ("time" if rate == 8 else "freq")
+    if kernel == "time":  # forced: the per-rate kernel where it is built, its any-rate form elsewhere (rate 1: nothing to drop)
+        assert node.kernel == ("time" if rate in (2, 5, 8) else "time_any" if rate > 1 else "freq")
+    elif kernel == "auto":  # 255 real taps: 32 MACs per input sample at rate 8, 128 at rate 2; any-rate kernel from rate 17
+        assert node.kernel == ("time" if rate == 8 else "time_any" if rate >= 17 else "freq")
     ost, om = oracle.default_state(taps), oracle.Mixer(0.3, dphase)
     cut = (n // 3) - (n // 3) % rate
     for a, b in [(0, cut), (cut, n)]:
@@ -1077,7 +1077,7 @@ def test_fused_fm_chain_rates_and_fallbacks(c, rate, kernel):
     x = fm_stream(n)
     taps = lowpass_taps(63, 1 / (2.5 * rate))
     node = c.ChainNode(0.3, 0.1, taps, rate, True, kernel=kernel)
-    assert node.fused and node.kernel == (kernel if rate != 64 else "freq")
+    assert node.fused and node.kernel == (kernel if rate != 64 else "time_any" if kernel == "time" else "freq")
     ost, om, ofm = oracle.default_state(taps), oracle.Mixer(0.1, 0.3), oracle.FM()
     for a, b in [(0, 768 * rate), (768 * rate, n)]:
         w = ofm.demod(oracle.decimate(oracle.batch_fir(om.mix(x[a:b]), taps, ost, norotate=True), rate))
@@ -1090,11 +1090,84 @@ def test_fused_fm_chain_rates_and_fallbacks(c, rate, kernel):
     # mixer / FIR / decimate with the demodulator as its own kernel behind it; four kernels beyond 257 taps
     assert c.ChainNode(0.3, 0.1, lowpass_taps(255, 0.1), 8, True).kernel == "time"
     assert c.ChainNode(0.3, 0.1, lowpass_taps(255, 0.1), 8, True, kernel="freq").kernel == "freq"
-    assert c.ChainNode(0.3, 0.1, lowpass_taps(255, 0.1), 7, True).kernel == "freq"      # no time kernel for /7
-    assert c.ChainNode(0.3, 0.1, lowpass_taps(63, 0.1), 128, True).kernel == "freq"
+    assert c.ChainNode(0.3, 0.1, lowpass_taps(255, 0.1), 7, True).kernel == "time"      # per-rate kernel for /7 since round 3
+    assert c.ChainNode(0.3, 0.1, lowpass_taps(63, 0.1), 128, True).kernel == "time_any"  # any-rate kernel from /17
+    assert c.ChainNode(0.3, 0.1, lowpass_taps(300, 0.1), 100, False).kernel == "time_any"  # ... and up to 512 taps
     assert not c.ChainNode(0.3, 0.1, lowpass_taps(300, 0.1), 8, False).fused     # > 257 taps
     with pytest.raises(c.CommsError):
         c.ChainNode(0.3, 0.1, taps, 8, True).run(x[:12])  # n not a multiple of rate
+
+
+@pytest.mark.parametrize("fm", [False, True])
+@pytest.mark.parametrize("after", [False, True])
+@pytest.mark.parametrize("n_taps,rate,cplx", [(255, 19, False), (255, 21, True), (127, 17, False), (255, 20, False), (255, 25, True),
+                                              (63, 47, False), (255, 48, False), (200, 100, True), (63, 128, False),
+                                              (255, 1000, False), (400, 24, False), (512, 300, True), (1, 33, False), (33, 18, True)])
+def test_chain_any_rate(c, n_taps, rate, cplx, after, fm):
+    """fir_decim_any_kernel -- the time-domain chain at rates the per-rate kernel is not built for (DecimateNode takes
+    any rate, resample_node.rs:23,:53-65): both mixer positions (in front: folded into the taps), with and without FM
+    demod, real and complex taps, the LDS-staged form (rate < 48) and the direct one, ragged call lengths with the
+    FIR history, oscillator phase and FM.prev carried across calls -- against the oracle's four nodes in series."""
+    rng = np.random.default_rng(n_taps * 7 + rate)
+    n = rate * (5000 if rate < 200 else 600)
+    x = fm_stream(n) if fm else rand_c(rng, n)
+    taps = lowpass_taps(n_taps, min(0.45, 1 / (2.5 * rate))) if n_taps > 1 else np.array([0.8 + 0j], np.complex64)
+    if cplx:
+        taps = (taps * np.exp(0.2j * np.arange(n_taps))).astype(np.complex64)
+    node = c.ChainNode(0.3, 0.1, taps, rate, fm, kernel="time", mixer_after_fir=after)
+    assert node.fused and node.kernel == "time_any"
+    ost, om, ofm = oracle.default_state(taps), oracle.Mixer(0.1, 0.3), oracle.FM()
+
+    def ref(seg):
+        if after:
+            return oracle.decimate(om.mix(oracle.batch_fir(seg, taps, ost, norotate=True)), rate)
+        return oracle.decimate(oracle.batch_fir(om.mix(seg), taps, ost, norotate=True), rate)
+
+    cuts = [0, rate, 3 * rate, 1003 * rate if rate < 200 else 100 * rate, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        y = ref(x[a:b])
+        got = node.run(x[a:b])
+        if fm:
+            w = ofm.demod(y)
+            mag = np.minimum(np.abs(y), np.abs(np.concatenate([[1.0], y[:-1]])))
+            ok = mag > 0.05
+            assert got.dtype == np.float32 and np.max(circ(got.astype(np.float64) - w)[ok], initial=0.0) <= 1e-4, (a, b)
+        else:
+            fir_close(got, y, taps, x)
+    assert np.array_equal(node.fir_state(n_taps), x[::-1][:n_taps])      # raw samples, newest first
+    assert circ(np.array([node.phase - om.phase.value]))[0] < 1e-6
+
+
+@pytest.mark.parametrize("fm", [False, True])
+@pytest.mark.parametrize("after", [False, True])
+@pytest.mark.parametrize("n_taps,rate,cplx", [(255, 7, False), (255, 7, True), (127, 9, False), (200, 9, True), (255, 11, False),
+                                              (63, 13, False), (255, 14, False), (100, 14, True), (257, 15, False)])
+def test_chain_per_rate_kernel_at_the_rates_added_in_round_3(c, n_taps, rate, cplx, after, fm):
+    """fir_decim_kernel at rates 7, 9, 11, 13, 14, 15 (11 / 13 / 15: real taps): the same checks as at the other rates."""
+    rng = np.random.default_rng(n_taps * 3 + rate)
+    n = rate * 4000
+    x = fm_stream(n) if fm else rand_c(rng, n)
+    taps = lowpass_taps(n_taps, 1 / (2.5 * rate))
+    if cplx:
+        taps = (taps * np.exp(0.2j * np.arange(n_taps))).astype(np.complex64)
+    node = c.ChainNode(0.3, 0.1, taps, rate, fm, kernel="time", mixer_after_fir=after)
+    assert node.fused and node.kernel == "time"
+    ost, om, ofm = oracle.default_state(taps), oracle.Mixer(0.1, 0.3), oracle.FM()
+    cuts = [0, rate, 3 * rate, 1003 * rate, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        seg = x[a:b]
+        y = (oracle.decimate(om.mix(oracle.batch_fir(seg, taps, ost, norotate=True)), rate) if after else
+             oracle.decimate(oracle.batch_fir(om.mix(seg), taps, ost, norotate=True), rate))
+        got = node.run(seg)
+        if fm:
+            w = ofm.demod(y)
+            mag = np.minimum(np.abs(y), np.abs(np.concatenate([[1.0], y[:-1]])))
+            assert np.max(circ(got.astype(np.float64) - w)[mag > 0.05], initial=0.0) <= 1e-4, (a, b)
+        else:
+            fir_close(got, y, taps, x)
+    assert np.array_equal(node.fir_state(n_taps), x[::-1][:n_taps])
+    assert c.ChainNode(0.3, 0.1, (lowpass_taps(63, 0.05) * np.exp(0.2j * np.arange(63))).astype(np.complex64), 13, fm,
+                       kernel="time").kernel == "time_any"   # complex taps at 11 / 13 / 15: the any-rate kernel
 
 
 @pytest.mark.parametrize("n_taps,rate,after", [(255, 7, False), (255, 20, True), (200, 100, False), (63, 128, True),
