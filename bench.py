@@ -556,7 +556,9 @@ def run_config2(ctx):
                                "node by node, device-resident" % int(np.log2(n)),
                    "samples_per_gpu_per_step": n, "n_taps": N_TAPS, "dec_rate": DEC_RATE,
                    "fir_kernel": algo, "sharding": "contiguous stream shards, one-off RCCL halo",
-                   "variant": args.variant, "backend": args.backend},
+                   "variant": args.variant, "backend": args.backend,
+                   "leg_order": "headline first" if (args.head_first or not args.stream_log2) else
+                                "2^%d-sample stream leg first (clock warm-up), then the headline" % args.stream_log2},
         "roofline": {"bound": "hbm", "kernel": algo, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": pmc_traffic(algo, n),

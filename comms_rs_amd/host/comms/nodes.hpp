@@ -621,8 +621,10 @@ inline std::vector<double> qfilt_taps(uint32_t n_taps, double alpha, uint32_t sa
 // the device.  Every node owns a stream (DevStream); run() is
 //     wait_ready(in)  ->  one asynchronous launch on the node's stream  ->  record_use(in),
 //     record_ready(out)  ->  send(out)
-// so the consumer's stream starts its own launch only after the producer's has finished, on the
-// same or on another GPU, while the node threads themselves run ahead of the device.  Output
+// so the consumer's stream starts its own launch only after the producer's has finished, while the
+// node threads themselves run ahead of the device.  An edge stays on ONE GPU: the buffer's events
+// belong to its device and the kernels read it directly, so a message whose device is not the node's is a
+// DataError (COMMS_ERR_ARG) -- between GPUs the host copies or sends the samples itself (sharding, above).  Output
 // buffers come from the library's cache (no hipMalloc / hipFree in steady state); a buffer's
 // memory is recycled only after the launches that read it.  to_host() waits for the producer.
 class DevStream {
@@ -638,6 +640,7 @@ public:
     // `launch(stream)` is the node's *_run_dev call
     template <class TI, class TO, class F>
     comms_status_t run(const DeviceBuf<TI>& in, DeviceBuf<TO>& out, F&& launch) {
+        if (in.device() != device_ || out.device() != device_) return COMMS_ERR_ARG;  // no cross-device edges (see above)
         comms_status_t st = comms_buf_wait_ready(in.raw(), s_);
         if (st == COMMS_OK) st = launch(s_);
         if (st == COMMS_OK) st = comms_buf_record_use(in.raw(), s_);
