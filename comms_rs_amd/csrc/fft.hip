@@ -388,6 +388,9 @@ struct BluArgs {
     unsigned n, logM;
     const cf* chirp;
     const cf* bspec;
+    unsigned tr_rows;  // mode 0, N >= 1024: rows per transform of a four-step row pass whose output is stored TRANSPOSED
+                       // (out[b][k1 + tr_rows * k] for row k1 of transform b: the row pass of N = 2^21, 2^22 without a
+                       // separate transpose launch); 0: the tile goes back where it came from
 };
 // RAD = 128 / 512 stand for N = 2 x 64 / 2 x 256: a radix-2 butterfly over the two halves of a
 // transform (x W_N^{n2}) on the way into LDS, then the 64- / 256-point form; lanes load both
@@ -587,9 +590,22 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
             }
         }
     };
-    if (first_tile + blockIdx.x < n_tiles) fetch(first_tile + blockIdx.x);
+    // Tile of this workgroup's g-th step.  Plain launches: blockIdx.x + g * gridDim.x.  Transposed row pass on the full
+    // grid of 256 workgroups: the R tiles that make up sixteen adjacent rows (one 128-byte run of the transposed output
+    // per output index) go to R workgroups of ONE XCD in the same step (workgroup b runs on XCD b % 8), so that their
+    // XPT * 8-byte pieces meet in that XCD's L2 and leave it as whole lines.
+    const bool grouped = BLU == 0 && !PART && C1024 && blu.tr_rows != 0 && gridDim.x == 256 && first_tile == 0;
+    auto tile_of = [&](size_t g) -> size_t {
+        if (!grouped) return first_tile + blockIdx.x + g * gridDim.x;
+        const unsigned x = blockIdx.x & 7u, y = blockIdx.x >> 3;
+        return static_cast<size_t>(R) * (x + 8u * (y / R) + (256u / R) * g) + (y % R);
+    };
+    const size_t n_steps = grouped ? (n_tiles + 255) / 256 : (n_tiles > first_tile + blockIdx.x ? (n_tiles - first_tile - blockIdx.x + gridDim.x - 1) / gridDim.x : 0);
+    if (n_steps && tile_of(0) < n_tiles) fetch(tile_of(0));
 
-    for (size_t tix = first_tile + blockIdx.x; tix < n_tiles; tix += gridDim.x) {
+    for (size_t g = 0; g < n_steps; ++g) {
+        const size_t tix = tile_of(g);
+        if (tix >= n_tiles) continue;  // (grouped, ragged last step; workgroup-uniform)
         __syncthreads();  // previous tile fully stored (and the tables are in place)
         // ---- radix-RAD over n1, times W_N^{n2*k1}, row k1 -> buffer j*RAD + k1, position n2 = tid
         if constexpr (PRE2) {  // radix-2 over the halves; half-spectrum k1 of transform tr -> slot 2 tr + k1 of row 2 rp + h
@@ -632,7 +648,7 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
             }
         }
         __syncthreads();
-        if (tix + gridDim.x < n_tiles) fetch(tix + gridDim.x);
+        if (g + 1 < n_steps && tile_of(g + 1) < n_tiles) fetch(tile_of(g + 1));
         // ---- this wave's 1024 points: one 1024-point transform, 16 of 64 points or 4 of 256 points
         rx_wave_core<DIR, C64, C256, C16N>(buf, tw1, tw2, l, q0, q1);
         __syncthreads();
@@ -669,6 +685,16 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
             } else if constexpr (RAD == 512) {  // transform tid >> 9: slot 2 tr + k1, frequency k2
                 const unsigned k = static_cast<unsigned>(tid) & 511u;
                 xo = bufs[u * BUF + (2 * (static_cast<unsigned>(tid) >> 9) + (k & 1u)) * F256_T + (k >> 1)];
+            } else if (BLU == 0 && blu.tr_rows) {
+                // transposed store: consecutive lanes take the XPT rows of the tile at one output index k, so that a
+                // wave writes XPT * 8 B pieces at stride tr_rows * 8 B (the tile's rows are XPT adjacent rows k1 of one
+                // transform: XPT divides tr_rows)
+                const unsigned j = i % XPT, k = i / XPT;         // row of the tile, output index 0 .. N - 1
+                const unsigned k1 = k % R, k2 = k / R;
+                xo = bufs[(j * R + k1) * BUF + k2 + (k2 >> 4)];
+                const size_t row = tix * XPT + j;                 // row of the batch: transform row / tr_rows, its row k1
+                dp = out + (row / blu.tr_rows) * (static_cast<size_t>(blu.tr_rows) * N) + (row % blu.tr_rows) +
+                     static_cast<size_t>(blu.tr_rows) * k;
             } else {
                 const unsigned k1 = i % R, k2 = (i / R) & 1023u, j = i / N;
                 xo = bufs[(j * R + k1) * BUF + k2 + (k2 >> 4)];
@@ -1215,7 +1241,7 @@ static comms_status_t launch_fast(Pow2Plan& pl, const float2* src, float2* dst, 
 
 template <int RAD>
 static comms_status_t launch_rx(Pow2Plan& pl, const float2* src, float2* dst, size_t n_points, bool inverse,
-                                hipStream_t s, const BluArgs& blu = BluArgs{0, 0, 0, nullptr, nullptr}) {
+                                hipStream_t s, const BluArgs& blu = BluArgs{0, 0, 0, nullptr, nullptr, 0}) {
     const size_t n_full = n_points / 16384, rem = n_points % 16384;
     const cf* a = reinterpret_cast<const cf*>(src);
     cf* d = reinterpret_cast<cf*>(dst);
@@ -1288,7 +1314,7 @@ static comms_status_t launch_cols(Pow2Plan& pl, const float2* src, float2* dst, 
 
 // All of a batch on the single-pass kernel (plain, or as one half of a Bluestein pair).
 static comms_status_t run_rx(Pow2Plan& pl, const float2* in, float2* out, size_t n_points, bool inverse, hipStream_t s,
-                             const BluArgs& blu = BluArgs{0, 0, 0, nullptr, nullptr}) {
+                             const BluArgs& blu = BluArgs{0, 0, 0, nullptr, nullptr, 0}) {
     switch (pl.rx_rad) {
             case -1: COMMS_TRY(launch_rx<0>(pl, in, out, n_points, inverse, s, blu)); break;
             case -2: COMMS_TRY(launch_rx<256>(pl, in, out, n_points, inverse, s, blu)); break;
@@ -1319,6 +1345,14 @@ static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size
         FftTileParams p = pl.pass[0];
         p.n_tiles = batch * p.tiles_per_xform;
         COMMS_TRY(launch_fast(pl, in, scratch, p, inverse, s));
+        // Two passes where the row pass can store transposed in pieces of at least 64 B (N = 2^21: eight 2048-point
+        // rows per tile): 32 B/point instead of 48.  Beyond, the pieces shrink to 32 ... 8 B and the separate
+        // transpose wins (profiles/r03_bench_fft_large.txt); COMMS_FFT_LARGE_2PASS = max log2 N of the two-pass form.
+        static const int two_pass_max = [] { const char* v = getenv("COMMS_FFT_LARGE_2PASS"); return v && *v ? atoi(v) : 21; }();
+        if (ilog2(pl.N) <= two_pass_max && pl.rows->rx_rad >= 1) {
+            BluArgs tr{0, 0, 0, nullptr, nullptr, 1024u};
+            return run_rx(*pl.rows, scratch, out, batch * pl.N, inverse, s, tr);
+        }
         COMMS_TRY(run_rx(*pl.rows, scratch, scratch, batch * pl.N, inverse, s));
         const unsigned cols = static_cast<unsigned>(pl.N >> 10);
         const size_t n_tiles = batch * (1024 / TR_T) * (cols / TR_T);
@@ -1596,9 +1630,9 @@ comms_status_t comms_fft_run_dev(comms_fft_t* h, const comms_c32* d_in, size_t n
             // two launches: [x * chirp, pad, forward, * bspec] -> work;  [inverse, * chirp, first N] -> out
             const cf* chirp = reinterpret_cast<const cf*>(h->d_chirp);
             COMMS_TRY(run_rx(h->plan, in + b0 * h->N, a, nb * M, false, s,
-                             BluArgs{1, static_cast<unsigned>(h->N), logM, chirp, reinterpret_cast<const cf*>(h->d_bspec)}));
+                             BluArgs{1, static_cast<unsigned>(h->N), logM, chirp, reinterpret_cast<const cf*>(h->d_bspec), 0}));
             COMMS_TRY(run_rx(h->plan, a, o + b0 * h->N, nb * M, true, s,
-                             BluArgs{2, static_cast<unsigned>(h->N), logM, chirp, nullptr}));
+                             BluArgs{2, static_cast<unsigned>(h->N), logM, chirp, nullptr, 0}));
             continue;
         }
         blu_pre_kernel<<<dim3(4 * kNumCU), dim3(256), 0, s>>>(reinterpret_cast<const cf*>(in + b0 * h->N), reinterpret_cast<const cf*>(h->d_chirp), reinterpret_cast<cf*>(a), h->N, M, nb);

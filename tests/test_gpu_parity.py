@@ -869,9 +869,10 @@ def test_fft_four_step_column_pass(c, logn, inverse):
 @pytest.mark.parametrize("inverse", [False, True])
 def test_fft_above_2p20_columns_rows_transpose(c, logn, batch, inverse):
     """N = 2^21 ... 2^24 (fft_node.rs:65-74 accepts any size): 1024-point columns at stride N / 1024 with the
-    four-step twiddle, N / 1024-point rows in place, a tiled transpose.  Device-resident, out of place and in
-    place; against numpy's f64 FFT of the same counter-based input (the oracle's own FFT is checked against
-    numpy in the CPU suite)."""
+    four-step twiddle, then N / 1024-point rows -- stored transposed (N = 2^21: two passes), or in place with a tiled
+    transpose behind them (three launches; `COMMS_FFT_LARGE_2PASS=24 pytest -k fft` runs every size on the two-pass
+    form, as scripts/steps/r03_p.txt did).  Device-resident, out of place and in place; against numpy's f64 FFT of
+    the same counter-based input (the oracle's own FFT is checked against numpy in the CPU suite)."""
     import torch
 
     n = 1 << logn
