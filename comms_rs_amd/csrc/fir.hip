@@ -188,21 +188,22 @@ __global__ __launch_bounds__(256, WPS) void fir_os4096_kernel(In in,
                                                             size_t n, int hblk, size_t nseg,
                                                             OsTables tb, float2* __restrict__ new_hist,
                                                             int delay, int accumulate, int interleave) {
-    __shared__ __attribute__((aligned(16))) cf lds[OS_LDS + 256];
+    __shared__ __attribute__((aligned(16))) cf lds[OS_LDS];
     const int t = threadIdx.x;
     if (!accumulate) hist_advance(hist, in, n, new_hist, hist_len);  // once per call (first partition)
     const int hi = t >> 4, lo = t & 15;
 
-    // persistent per-lane constants: stage-1 twiddles and the filter spectrum in
-    // VGPRs, the 16x16 stage-2 twiddle table in LDS (read as tw2[j*16 + lo])
-    cf tw1r[16], hr[16];
+    // persistent per-lane constants, all in VGPRs: stage-1 twiddles, the filter spectrum and (round 3) the lane's
+    // column of the stage-2 twiddle table W256^{lo*j} -- it depends on the lane only, and as an LDS table (in the same
+    // array as the exchange buffers, so every read had to wait for the write before it) it cost two chains of fifteen
+    // read -> wait -> multiply -> write steps per segment
+    cf tw1r[16], hr[16], tw2r[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         tw1r[j] = tb.tw1[j * 256 + t];
         hr[j] = tb.hdev[j * 256 + t];
+        tw2r[j] = tb.tw2[j * 16 + lo];
     }
-    cf* tw2 = lds + OS_LDS;
-    tw2[t] = tb.tw2[t];
 
     const int H = 256 * hblk;
     const int V = OSF - H;
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256, WPS) void fir_os4096_kernel(In in,
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             cf x = v[R16_POS(k)];
-            if (k) x = cmulf(x, tw2[k * 16 + lo]);
+            if (k) x = cmulf(x, tw2r[k]);
             lds[(hi * 16 + k) * OS_S2 + lo] = x;
         }
         __syncthreads();
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256, WPS) void fir_os4096_kernel(In in,
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             cf x = w[R16_POS(c)];
-            if (c) x = cmulcf(x, tw2[c * 16 + lo]);
+            if (c) x = cmulcf(x, tw2r[c]);
             lds[hi * 288 + c * OS_S2 + lo] = x;  // [k0][c][k1]
         }
         __syncthreads();
@@ -271,10 +272,9 @@ __global__ __launch_bounds__(256, WPS) void fir_os4096_kernel(In in,
         __syncthreads();
         // ---- inverse stage 1': lane (b,c) = t: over k0 -> a
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            cf x = lds[k * OS_S1 + t];
-            v[k] = k ? cmulcf(x, tw1r[k]) : x;
-        }
+        for (int k = 0; k < 16; ++k) v[k] = lds[k * OS_S1 + t];  // (all sixteen reads out before the first multiply)
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[k] = cmulcf(v[k], tw1r[k]);
         radix16<1>(v);
         // ---- store the V valid outputs: y[256a + t], a >= hblk
         const size_t obase = seg * static_cast<size_t>(V) + t;
