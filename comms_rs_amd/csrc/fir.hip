@@ -1465,12 +1465,12 @@ static int fir_pick(const comms_fir* h, size_t n) {
         }
     }
     if (algo == COMMS_FIR_OVERLAP_SAVE) {
-        // 16384-point kernel (halo 1024 * ceil((taps - 1) / 1024)): 71-73 us per 2^24 samples up to 2049 taps, 74-78 at
-        // 4097.  4096-point kernel (halo 256 * ceil((taps - 1) / 256)): 61-67 us up to 1025 taps, 74 at 1281, 75 at
-        // 1537, 81 at 1793, 88 at 2049 (2^24; the same order at 2^26).  Below 2^23 samples the 16384-point segments are
+        // 16384-point kernel (halo 1024 * ceil((taps - 1) / 1024)): 72-74 us per 2^24 samples up to 2049 taps, 74-78 at
+        // 4097.  4096-point kernel (halo 256 * ceil((taps - 1) / 256)): 56-58 us up to 769 taps, 62 at 1025, 66 at 1281, 70
+        // at 1537, 74 at 1793, 80 at 2049 (2^24; the same order at 2^26).  Below 2^23 samples the 16384-point segments are
         // too few to fill the chip and the 4096-point kernel wins at every tap count -- scripts/sweep_os.py,
         // profiles/r03_sweep_os.txt.
-        const bool big = h->n_eff > 2049 || (h->n_eff > 1281 && n >= (static_cast<size_t>(1) << 23));
+        const bool big = h->n_eff > 2049 || (h->n_eff > 1537 && n >= (static_cast<size_t>(1) << 23));
         algo = h->n_eff <= 257 ? COMMS_FIR_OS1024 : big ? COMMS_FIR_OS16K : COMMS_FIR_OS4096;
     }
     return algo;

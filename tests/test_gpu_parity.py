@@ -377,12 +377,12 @@ def test_fir_auto_selection_and_errors(c):
     assert node.algo_for(1 << 24) == c.FIR_OS1024
     assert c.BatchFirNode(np.ones(258, np.complex64)).algo_for(1 << 24) == c.FIR_OS4096
     assert c.BatchFirNode(np.ones(2050, np.complex64)).algo_for(1 << 24) == c.FIR_OS16K
-    # 1282 ... 2049 taps: the 16384-point kernel on long streams (a halo of 2048 of 16384 points; the 4096-point
-    # kernel's halo is 1536 ... 2048 of 4096 there), the 4096-point one below 2^23 samples
+    # 1538 ... 2049 taps: the 16384-point kernel on long streams (a halo of 2048 of 16384 points; the 4096-point
+    # kernel's halo is 1792 ... 2048 of 4096 there), the 4096-point one below 2^23 samples
     assert c.BatchFirNode(np.ones(1793, np.complex64)).algo_for(1 << 24) == c.FIR_OS16K
     assert c.BatchFirNode(np.ones(1793, np.complex64)).algo_for(1 << 22) == c.FIR_OS4096
-    assert c.BatchFirNode(np.ones(1282, np.complex64)).algo_for(1 << 24) == c.FIR_OS16K
-    assert c.BatchFirNode(np.ones(1281, np.complex64)).algo_for(1 << 24) == c.FIR_OS4096
+    assert c.BatchFirNode(np.ones(1538, np.complex64)).algo_for(1 << 24) == c.FIR_OS16K
+    assert c.BatchFirNode(np.ones(1537, np.complex64)).algo_for(1 << 24) == c.FIR_OS4096
     assert node.algo_for(4) == c.FIR_DIRECT
     assert c.BatchFirNode(np.ones(8, np.complex64)).algo_for(1 << 24) == c.FIR_DIRECT
     assert c.BatchFirNode(np.ones(63, np.complex64)).algo_for(1 << 24) == c.FIR_OS1024
