@@ -209,7 +209,7 @@ __device__ __forceinline__ void fw_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int DIR, int NW>
+template <int DIR, int NW, bool TWS = false>  // TWS: the four-step store twiddle in its factored form (pass 1 of N >= 2^20)
 __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void fft1024x16_kernel(const cf* in, cf* out, FftTileParams p,
                                                              const cf* __restrict__ tw1g,
                                                              const cf* __restrict__ tw2g) {
@@ -217,6 +217,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void fft1024x16_kernel(c
     cf* tw1 = reinterpret_cast<cf*>(smem);  // [16][64]  W1024^{lane*k0}
     cf* tw2 = tw1 + 1024;                   // [16][4]   W64^{c*k1}
     cf* bufs = tw2 + 64;                    // [16][FW_BUF]
+    cf* twu = bufs + NW * FW_BUF;           // [16][16]  W_N^{64 C u} of the tile's columns (four-step store twiddle)
     const int tid = threadIdx.x;
     const int l = tid & 63, wave = tid >> 6;
     const int q0 = l & 15, q1 = l >> 4;
@@ -262,6 +263,21 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void fft1024x16_kernel(c
         const size_t tl = tix - b * p.tiles_per_xform;
         cf* dst = out + b * p.N + tl * p.tile_step_out;
         __syncthreads();  // previous tile fully stored (and the tables are in place)
+        // Four-step twiddle of the store stage, W_N^{C k} with C = col0 + c and k = (tid >> 4) + 64 u: factored into
+        // W_N^{C (tid >> 4)} (one value per thread) and W_N^{64 C u} (one per column and u: 256 per tile, in LDS), both
+        // fetched here, a whole transform ahead of their use.  (Looked up per stored element -- two dependent gathers
+        // and a product each, waited for one at a time -- the stores of pass 1 were a chain of sixteen L2 round trips.)
+        cf tw_a = cf{1.f, 0.f};
+        constexpr bool tw_split = TWS;
+        if (tw_split) {
+            const unsigned col0 = static_cast<unsigned>(tl) * NW;
+            const unsigned ea = (col0 + (tid & 15)) * static_cast<unsigned>(tid >> 4);
+            tw_a = g_mul(p.tw_hi[ea >> 12], p.tw_lo[ea & 4095]);
+            if (tid < 256) {
+                const unsigned eb = (col0 + (tid & 15)) * 64u * static_cast<unsigned>(tid >> 4);
+                twu[tid] = g_mul(p.tw_hi[eb >> 12], p.tw_lo[eb & 4095]);
+            }
+        }
         if (!PREFETCH) fetch(tile_src(tix), pre);
         if (p.in_c_fast) {
             cf* d = bufs + (tid & (NW - 1)) * FW_BUF + (tid >> LOG);
@@ -329,7 +345,9 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void fft1024x16_kernel(c
                     k = i & 1023;
                 }
                 cf x = bufs[c * FW_BUF + k + (k >> 4)];
-                if (p.apply_tw) {
+                if (tw_split) {
+                    x = tw_apply<DIR>(x, g_mul(tw_a, twu[u * 16 + c]));
+                } else if (p.apply_tw) {
                     const unsigned e = (col0 + c) * k;  // < N <= 2^24
                     x = tw_apply<DIR>(x, g_mul(p.tw_hi[e >> 12], p.tw_lo[e & 4095]));
                 }
@@ -1133,10 +1151,14 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
         COMMS_HIP_TRY(hipMalloc(&pl.d_fw2, t2.size() * sizeof(float2)));
         COMMS_HIP_TRY(hipMemcpy(pl.d_fw1, t1.data(), t1.size() * sizeof(float2), hipMemcpyHostToDevice));
         COMMS_HIP_TRY(hipMemcpy(pl.d_fw2, t2.data(), t2.size() * sizeof(float2), hipMemcpyHostToDevice));
-        const int fw_lds = (1024 + 64 + 16 * FW_BUF) * static_cast<int>(sizeof(float2));
+        const int fw_lds = (1024 + 64 + 16 * FW_BUF + 256) * static_cast<int>(sizeof(float2));
         COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft1024x16_kernel<1, 16>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
         COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft1024x16_kernel<-1, 16>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft1024x16_kernel<1, 16, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft1024x16_kernel<-1, 16, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
         COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft1024x16_kernel<1, 8>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
@@ -1221,14 +1243,19 @@ static comms_status_t launch_fast(Pow2Plan& pl, const float2* src, float2* dst, 
     const cf* a = reinterpret_cast<const cf*>(src);
     cf* d = reinterpret_cast<cf*>(dst);
     if (p.C == 16) {  // one 16-wave workgroup per CU
-        const size_t lds = (1024 + 64 + 16 * FW_BUF) * sizeof(float2);
+        const size_t lds = (1024 + 64 + 16 * FW_BUF + 256) * sizeof(float2);
         const unsigned blocks = static_cast<unsigned>(p.n_tiles < static_cast<size_t>(kNumCU) ? p.n_tiles : kNumCU);
-        if (inverse)
+        if (p.apply_tw && p.out_c_fast) {
+            if (inverse)
+                fft1024x16_kernel<1, 16, true><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, p, t1, t2);
+            else
+                fft1024x16_kernel<-1, 16, true><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, p, t1, t2);
+        } else if (inverse)
             fft1024x16_kernel<1, 16><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, p, t1, t2);
         else
             fft1024x16_kernel<-1, 16><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, p, t1, t2);
     } else {  // two 8-wave workgroups per CU: one loads/stores while the other computes
-        const size_t lds = (1024 + 64 + 8 * FW_BUF) * sizeof(float2);
+        const size_t lds = (1024 + 64 + 8 * FW_BUF + 256) * sizeof(float2);
         const size_t slots = 2 * static_cast<size_t>(kNumCU);
         const unsigned blocks = static_cast<unsigned>(p.n_tiles < slots ? p.n_tiles : slots);
         if (inverse)
