@@ -803,12 +803,32 @@ __global__ __launch_bounds__(1024, 4) void fft_cols_kernel(const cf* in, cf* out
         }
         __syncthreads();
         if (tix + gridDim.x < n_tiles) fetch(tix + gridDim.x);
+        // Four-step twiddle of the store stage, W_N^{n2 k1} with n2 = col0 + (tid % C) (one column per thread) and
+        // k1 = tid / C + S u, S = 1024 / C: three table look-ups per thread and tile -- W^{n2 (tid / C)}, the step W^{n2 S}
+        // and the step of four W^{n2 4 S} -- issued here, a transform ahead of their use; the sixteen factors are then
+        // stepped from them (at most six products deep: ~4e-7) instead of two dependent gathers per stored element
+        // waited for one at a time.  (Seven look-ups kept in registers -- every fourth factor exact -- spilled.)
+        const unsigned col0 = static_cast<unsigned>(tix % TPX) * C;
+        cf tw_a0, tw_s1, tw_s4;
+        auto tw_fetch = [&]() {
+            constexpr unsigned S = 1024u / C;
+            const unsigned n2 = col0 + (static_cast<unsigned>(tid) % C);
+            auto look = [&](unsigned ee) { return g_mul(tw_hi[ee >> 12], tw_lo[ee & 4095]); };  // ee < N1 * 1024 <= 2^19
+            tw_a0 = look(n2 * (static_cast<unsigned>(tid) / C));
+            tw_s1 = look(n2 * S);
+            tw_s4 = look(n2 * S * 4);
+        };
+        // (the 128- and 512-point forms have no six registers to spare across the transform: they fetch behind it --
+        // three independent look-ups, one L2 round trip per tile)
+        constexpr bool TW_EARLY = KIND != 128 && KIND != 512;
+        if (TW_EARLY) tw_fetch();
         rx_wave_core<DIR, C64, C256, C16N>(buf, tw1, tw2, l, q0, q1);
+        if (!TW_EARLY) tw_fetch();
         __syncthreads();
         // ---- store transposed back, times W_N^{n2*k1}
         cf* dst = out + base_of(tix);
-        const unsigned col0 = static_cast<unsigned>(tix % TPX) * C;
-#pragma unroll 8
+        cf tw_g = tw_a0, tw_w = tw_a0;  // factor of u = 4 (u >> 2), and of u
+#pragma unroll
         for (int u = 0; u < 16; ++u) {
             const unsigned e = static_cast<unsigned>(tid) + 1024u * u;
             const unsigned k1 = e / C, c = e % C, wb = c / TPW, t = c % TPW;
@@ -820,8 +840,8 @@ __global__ __launch_bounds__(1024, 4) void fft_cols_kernel(const cf* in, cf* out
                 pos = C64 ? t + 17 * k1 : t * SLOT + k1;
             }
             cf x = bufs[wb * BUF + pos];
-            const unsigned ee = (col0 + c) * k1;  // < 2^19
-            x = tw_apply<DIR>(x, g_mul(tw_hi[ee >> 12], tw_lo[ee & 4095]));
+            if (u) tw_w = (u & 3) ? g_mul(tw_w, tw_s1) : (tw_g = g_mul(tw_g, tw_s4));
+            x = tw_apply<DIR>(x, tw_w);
             dst[k1 * 1024u + c] = x;
         }
     }
