@@ -207,7 +207,8 @@ def test_config5_full_shard_2p27_second_rank(c):
 
 
 @pytest.mark.parametrize("n_taps,lg,spacing,algo", [(255, 24, 1000, "FIR_OS1024"), (1025, 24, 3000, "FIR_OS4096"),
-                                                   (4097, 27, 50000, "FIR_OS16K"), (63, 22, 257, "FIR_OS1024")])
+                                                   (4097, 27, 50000, "FIR_OS16K"), (63, 22, 257, "FIR_OS1024"),
+                                                   (1793, 24, 5000, "FIR_OS16K"), (3000, 24, 7001, "FIR_OS16K")])  # halo rows 2 / 3
 def test_fir_full_size_impulse_comb_every_output(c, n_taps, lg, spacing, algo):
     """Size-independent property at the BASELINE sizes, checked on EVERY output sample (the oracle comparisons
     above look through windows): a comb of complex impulses further apart than the filter is long must come out as
@@ -245,7 +246,10 @@ def test_fir_full_size_impulse_comb_every_output(c, n_taps, lg, spacing, algo):
 
 @pytest.mark.parametrize("n_taps,rate,lg,after,kernel", [(255, 8, 24, True, "time"), (127, 8, 26, False, "time"),
                                                          (63, 5, 24, False, "time"), (255, 8, 24, True, "freq"),
-                                                         (127, 3, 24, False, "freq"), (600, 16, 24, False, "auto")])
+                                                         (127, 3, 24, False, "freq"), (600, 16, 24, False, "auto"),
+                                                         (255, 7, 24, True, "time"), (127, 13, 24, False, "time"),
+                                                         (255, 20, 24, True, "time_any"), (127, 33, 24, False, "time_any"),
+                                                         (255, 100, 24, True, "time_any"), (400, 1000, 24, False, "time_any")])
 def test_chain_full_size_impulse_comb_every_output(c, n_taps, rate, lg, after, kernel):
     """The same property through the fused mixer / FIR / decimate chains at the BASELINE sizes (without the
     demodulator, which is not linear): impulse a_i at p_i comes out as a_i h[jR - p_i] times the oscillator's
@@ -265,7 +269,7 @@ def test_chain_full_size_impulse_comb_every_output(c, n_taps, rate, lg, after, k
     pt, at = torch.from_numpy(pos).to(dev), torch.from_numpy(amp).to(dev)
     x[pt] = at
     dphase, phase = 2 * np.pi * 0.05, 0.3
-    node = c.ChainNode(dphase, phase, taps, rate, False, mixer_after_fir=after, kernel=kernel)
+    node = c.ChainNode(dphase, phase, taps, rate, False, mixer_after_fir=after, kernel="time" if kernel == "time_any" else kernel)
     if kernel != "auto":
         assert node.kernel == kernel
     y = torch.empty(n // rate, dtype=torch.complex64, device=dev)
@@ -290,7 +294,8 @@ def test_chain_full_size_impulse_comb_every_output(c, n_taps, rate, lg, after, k
 
 
 @pytest.mark.parametrize("n_taps,rate,lg,kernel", [(127, 8, 26, "time"), (63, 5, 24, "time"), (255, 8, 24, "time"),
-                                                   (127, 8, 24, "freq"), (255, 7, 24, "freq"), (600, 16, 24, "auto")])
+                                                   (127, 8, 24, "freq"), (255, 7, 24, "freq"), (600, 16, 24, "auto"),
+                                                   (255, 9, 24, "time"), (255, 25, 24, "time_any"), (127, 64, 24, "time_any")])
 def test_fm_chain_full_size_tone_every_output(c, n_taps, rate, lg, kernel):
     """Every output of a full-size FM chain (config 3's shape at 2^26 among them): a complex tone of frequency w
     through mixer (dphi) -> low-pass -> /R -> FM::demod is the constant R (w + dphi) once the filter has filled --
@@ -304,7 +309,7 @@ def test_fm_chain_full_size_tone_every_output(c, n_taps, rate, lg, kernel):
     x = torch.polar(torch.ones(n, device=dev, dtype=torch.float64), w * t + 0.2).to(torch.complex64)
     del t
     taps = lowpass_taps(n_taps, 1 / (2.5 * rate))
-    node = c.ChainNode(dphi, 0.7, taps, rate, True, kernel=kernel)
+    node = c.ChainNode(dphi, 0.7, taps, rate, True, kernel="time" if kernel == "time_any" else kernel)
     if kernel != "auto":
         assert node.kernel == kernel
     y = torch.empty(n // rate, dtype=torch.float32, device=dev)
