@@ -509,3 +509,34 @@ impl Clone for DeviceBuf {
 impl Drop for DeviceBuf {
     fn drop(&mut self) { unsafe { comms_buf_release(self.b) }; }
 }
+
+/// One stream over several GPUs (host arithmetic of `include/comms_hip.h`, "stream shards"):
+/// contiguous shards, and per neighbour pair one hand-over of the raw samples in front of the shard.
+pub mod shard {
+    use super::*;
+    /// `[start, stop)` of `rank`'s share of `total` units (samples, or FFT transforms)
+    pub fn range(total: usize, world: u32, rank: u32) -> (usize, usize) {
+        let (mut a, mut b) = (0usize, 0usize);
+        let st = unsafe { comms_shard_range(total, world, rank, &mut a, &mut b) };
+        assert_eq!(st, COMMS_OK, "comms_shard_range failed");
+        (a, b)
+    }
+    /// the samples before a shard (time order, as many as taps) -> `BatchFirNode::new(taps, Some(state))`
+    pub fn state_from_halo(halo: &[Complex<f32>]) -> Vec<Complex<f32>> {
+        let mut st = vec![Complex::new(0.0f32, 0.0); halo.len()];
+        unsafe { comms_state_from_halo(halo.as_ptr(), halo.len(), st.as_mut_ptr()) };
+        st
+    }
+    /// oscillator phase of stream sample `first_index` -> `MixerNode::new(dphase, Some(phase))` of the shard's node
+    pub fn mixer_phase(phase0: f64, dphase: f64, first_index: i64) -> f64 {
+        let mut ph = 0.0f64;
+        unsafe { comms_shard_mixer_phase(phase0, dphase, first_index, &mut ph) };
+        ph
+    }
+    /// raw samples a fused chain shard runs through first (outputs dropped): FIR history + the sample FM.prev comes from
+    pub fn chain_prefix_len(n_taps: usize, rate: usize, fm_demod: bool) -> usize {
+        let mut n = 0usize;
+        unsafe { comms_chain_prefix_len(n_taps, rate, fm_demod as i32, &mut n) };
+        n
+    }
+}
