@@ -130,12 +130,12 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
     const bool can_decim = !(flags & (COMMS_CHAIN_UNFUSED | COMMS_CHAIN_FREQ_DOMAIN)) &&
                            (decim_ok == 2 || (decim_ok == 1 && (flags & COMMS_CHAIN_TIME_DOMAIN)));
     // Rates the per-rate kernel is not built for (17 and up; 11 / 13 / 15 with complex taps): the any-rate kernel (half
-    // a wave per output).  Against the overlap-save launch it replaces (58-60 us at 2^24 samples whatever the rate): 255
-    // taps 67 us at rate 17, 58 at 20, 42 at 32, 30 at 100, 11 at 1000; 127 taps 56 at 17; 63 taps 51 at 17
-    // (profiles/r03_bench_chain_rates.txt) -- so from rate 17 up to 160 taps, from rate 20 beyond; taps up to 512, where
-    // the alternative is four kernels in series.  COMMS_CHAIN_TIME_DOMAIN forces it wherever it can run.
-    static const int any_min_rate = [] { const char* v = getenv("COMMS_ANY_MIN_RATE"); return v && *v ? atoi(v) : 0; }();
-    const size_t any_from = any_min_rate > 0 ? static_cast<size_t>(any_min_rate) : n_taps <= 160 || n_taps > 257 ? 17 : 20;
+    // a wave per output).  Against the overlap-save launch it replaces (58-61 us at 2^24 samples whatever the rate): 255
+    // taps 60 us at rate 17, 53 at 20, 39 at 32, 30 at 100, 11 at 1000; 127 taps 49 at 17; 63 taps 45 at 17
+    // (profiles/r03_bench_chain_rates.txt) -- so from rate 17; taps up to 512, where the alternative is four kernels in
+    // series.  COMMS_CHAIN_TIME_DOMAIN forces it wherever it can run.
+    static const int any_min_rate = [] { const char* v = getenv("COMMS_ANY_MIN_RATE"); return v && *v ? atoi(v) : 17; }();
+    const size_t any_from = static_cast<size_t>(any_min_rate);
     const bool can_any = st == COMMS_OK && !can_decim && !(flags & (COMMS_CHAIN_UNFUSED | COMMS_CHAIN_FREQ_DOMAIN)) &&
                          comms_fir_decim_any_supported(h->fir, static_cast<uint32_t>(rate)) &&
                          ((flags & COMMS_CHAIN_TIME_DOMAIN) || rate >= any_from);

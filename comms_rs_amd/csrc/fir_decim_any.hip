@@ -207,30 +207,29 @@ __global__ __launch_bounds__(ANY_WG, 4) void fir_decim_any_kernel(const AnyArgs 
                 }
                 acc[q] = half_sum32(acc[q]);
                 const int tq = to + 8 * q;
-                if (i == 0 && tq < T) {
-                    cf y = acc[q];
-                    if (post) y = cmulf(y, cmulf(tt, rt[tq]));
-                    if (fm && jb + tq < 0) y = to_cf(a.fm_prev[0]);  // FM.prev of the previous call stands in for y[-1]
-                    ys[tq] = y;
-                }
+                if (i == 0 && tq < T) ys[tq] = acc[q];  // (the rotor comes in the store pass: once per output, not per half-wave step)
             }
         }
-        if (post) {
-            const double nc = tt_c * a.tile_c - tt_s * a.tile_s;
-            tt_s = tt_c * a.tile_s + tt_s * a.tile_c;
-            tt_c = nc;
-        }
         __syncthreads();  // ys complete; every read of xs is done
+        auto mixed = [&](int to) -> float2 {  // output `to` of the tile behind the mixer (FM.prev of the previous call for y[-1])
+            if (fm && jb + to < 0) return a.fm_prev[0];
+            return post ? to_f2(cmulf(ys[to], cmulf(tt, rt[to]))) : to_f2(ys[to]);
+        };
         for (int to = tid + ovl; to < T; to += ANY_WG) {
             const long long j = jb + to;
             if (j >= static_cast<long long>(a.n_out)) break;
-            const float2 y = to_f2(ys[to]);
+            const float2 y = mixed(to);
             if (fm) {
-                static_cast<float*>(a.out)[j] = fm_step(y, to_f2(ys[to - 1]));
+                static_cast<float*>(a.out)[j] = fm_step(y, mixed(to - 1));
                 if (j == static_cast<long long>(a.n_out) - 1) a.fm_prev_new[0] = y;
             } else {
                 static_cast<float2*>(a.out)[j] = y;
             }
+        }
+        if (post) {  // the next tile of this workgroup
+            const double nc = tt_c * a.tile_c - tt_s * a.tile_s;
+            tt_s = tt_c * a.tile_s + tt_s * a.tile_c;
+            tt_c = nc;
         }
     }
 }
@@ -300,10 +299,12 @@ comms_status_t comms_fir_run_decim_any_dev(comms_fir_t* h, const void* d_in, siz
         h->any_nt = NT;
     }
     const bool fm = (mode & COMMS_CHAIN_FM) != 0;
-    // STAGED below the rate where the windows of neighbouring outputs stop sharing most of their samples
-    // (scripts/bench_chain_rates.py, profiles/r03_bench_chain_rates.txt); COMMS_ANY_STAGED=0/1 forces one form
+    // STAGED while neighbouring windows share most of their samples: below rate max(48, 0.4 taps) (255 taps: staged 33 us
+    // against 42 direct at rate 64, a tie at 100; 127 and 63 taps: direct ahead from rate 64, a tie at 48 --
+    // scripts/bench_chain_any.py, profiles/r03_bench_chain_rates.txt); COMMS_ANY_STAGED=0/1 forces one form
     static const int forced = [] { const char* v = getenv("COMMS_ANY_STAGED"); return v && *v ? atoi(v) : -1; }();
-    bool staged = forced >= 0 ? forced != 0 : R < 48;
+    const int staged_below = 2 * N / 5 > 48 ? 2 * N / 5 : 48;
+    bool staged = forced >= 0 ? forced != 0 : R < staged_below;
     AnyArgs a{};
     a.in = d_in;
     a.fmt = h->in_fmt;
