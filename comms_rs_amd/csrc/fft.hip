@@ -406,9 +406,12 @@ struct BluArgs {
     unsigned n, logM;
     const cf* chirp;
     const cf* bspec;
-    unsigned tr_rows;  // mode 0, N >= 1024: rows per transform of a four-step row pass whose output is stored TRANSPOSED
-                       // (out[b][k1 + tr_rows * k] for row k1 of transform b: the row pass of N = 2^21, 2^22 without a
-                       // separate transpose launch); 0: the tile goes back where it came from
+    // mode 3 (N = 1024 * the kernel's row length R * 1024, i.e. 2^21 ... 2^24): the COLUMN pass of the four-step split.  A tile
+    // is XPT = 16 / R adjacent columns of the [R * 1024][1024] matrix, gathered in pieces of XPT * 8 B (the R tiles that
+    // share 128-byte lines on one XCD in the same step); its spectra leave times W_N^{column * k} in runs of 16 XPT points,
+    // laid out [k / 16][column][k % 16] so that the row pass reads whole contiguous tiles (16 adjacent k, all 1024 columns)
+    const cf* tw_lo = nullptr;  // W_N^e, e < 4096
+    const cf* tw_hi = nullptr;  // W_N^{4096 e}
 };
 // RAD = 128 / 512 stand for N = 2 x 64 / 2 x 256: a radix-2 butterfly over the two halves of a
 // transform (x W_N^{n2}) on the way into LDS, then the 64- / 256-point form; lanes load both
@@ -546,6 +549,12 @@ __device__ __forceinline__ void rx_wave_core(cf* buf, const cf* tw1, const cf* t
     }
 }
 
+// Buffer stride of the column form (BluArgs mode 3).  Its lanes run over the tile's columns first: stage 1 writes column j's row k
+// to buffer j R + k, and the store reads 16 consecutive k of one column (rows k % R, 16 / R consecutive positions each).  An odd
+// stride keeps the former apart, = 9 / 9 / 5 / 1 (mod 32 slots of 8 B) for R = 2 / 4 / 8 / 16 the latter.
+constexpr int rx_cols_buf(int r) { return r == 8 ? 1093 : r == 16 ? 1089 : 1097; }
+constexpr size_t rx_cols_lds(int r) { return static_cast<size_t>(1024 + 64 + r * 16 + r * 64 + 16 * rx_cols_buf(r)) * sizeof(float2); }
+
 // PART: the launch covers a partly filled tile (whole transforms only): zeros in, nothing out past
 // the end.  Full tiles run the unguarded instantiation.
 template <int DIR, int RAD, int BLU = 0, bool PART = false>
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
                                                              const cf* __restrict__ tw1g, const cf* __restrict__ tw2g,
                                                              const cf* __restrict__ twag, const cf* __restrict__ twbg,
                                                              const BluArgs blu) {
-    constexpr int R = RxGeom<RAD>::R, N = R * 1024, XPT = 16 / R, BUF = RxGeom<RAD>::BUF;
+    constexpr int R = RxGeom<RAD>::R, N = R * 1024, XPT = 16 / R, BUF = BLU == 3 ? rx_cols_buf(RxGeom<RAD>::R) : RxGeom<RAD>::BUF;
     constexpr bool C64 = RxGeom<RAD>::C64, C256 = RxGeom<RAD>::C256, C16 = RxGeom<RAD>::C16, PRE2 = RxGeom<RAD>::PRE2;
     constexpr bool C1024 = !C64 && !C256 && !C16;
     constexpr int C16N = RxGeom<RAD>::C16N, SLOTW = C256 ? F256_T : C64 ? FW_S1 : 18;  // slot stride of a half-spectrum (PRE2)
@@ -592,6 +601,12 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
                 const unsigned m = static_cast<unsigned>(g) & ((1u << blu.logM) - 1u);
                 pre[u] = ((!PART || i < left) && m < blu.n) ? g_mul(in[(g >> blu.logM) * blu.n + m], blu.chirp[m]) : cf{0.f, 0.f};
             }
+        } else if constexpr (BLU == 3) {  // lane (j = tid % XPT, tt = tid / XPT) holds column j, rows tt + (1024 / XPT) u
+            constexpr unsigned TPX = 1024u / XPT;  // tiles per transform
+            const cf* col = in + (tix / TPX) * (static_cast<size_t>(N) * 1024u) + (tix % TPX) * XPT;
+            const unsigned o0 = (static_cast<unsigned>(tid) / XPT) * 1024u + static_cast<unsigned>(tid) % XPT;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) pre[u] = col[o0 + static_cast<unsigned>(u) * (1024u / XPT) * 1024u];
         } else if constexpr (!PART) {
             if constexpr (PRE2) {
 #pragma unroll
@@ -608,11 +623,11 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
             }
         }
     };
-    // Tile of this workgroup's g-th step.  Plain launches: blockIdx.x + g * gridDim.x.  Transposed row pass on the full
-    // grid of 256 workgroups: the R tiles that make up sixteen adjacent rows (one 128-byte run of the transposed output
-    // per output index) go to R workgroups of ONE XCD in the same step (workgroup b runs on XCD b % 8), so that their
-    // XPT * 8-byte pieces meet in that XCD's L2 and leave it as whole lines.
-    const bool grouped = BLU == 0 && !PART && C1024 && blu.tr_rows != 0 && gridDim.x == 256 && first_tile == 0;
+    // Tile of this workgroup's g-th step.  Plain launches: blockIdx.x + g * gridDim.x.  Column pass (mode 3) on the full grid
+    // of 256 workgroups: the R tiles that share the 128-byte lines of sixteen adjacent columns go to R workgroups of ONE
+    // XCD in the same step (workgroup b runs on XCD b % 8), so that a line fetched for one of them is in that XCD's L2 for
+    // the others (32-byte pieces: 0.40 -> 0.30 ms per 2^26 points, scripts/probes/strided_tiles.hip).
+    const bool grouped = BLU == 3 && gridDim.x == 256 && first_tile == 0;
     auto tile_of = [&](size_t g) -> size_t {
         if (!grouped) return first_tile + blockIdx.x + g * gridDim.x;
         const unsigned x = blockIdx.x & 7u, y = blockIdx.x >> 3;
@@ -650,7 +665,24 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
             for (int u = 0; u < 16; ++u) bufs[u * BUF + (tid >> 8) * F256_T + (tid & 255)] = pre[u];
         }
 #pragma unroll
-        for (int j = 0; j < (C1024 ? XPT : 0); ++j) {
+        for (int m = 0; m < (C1024 && BLU == 3 ? XPT : 0); ++m) {  // column j = tid % XPT, rows n1 = 1024 a + t
+            cf v[R];
+#pragma unroll
+            for (int a = 0; a < R; ++a) v[a] = pre[a * XPT + m];
+            if constexpr (RAD == 2) radix2<DIR>(v[0], v[1]);
+            if constexpr (RAD == 4) radix4<DIR>(v[0], v[1], v[2], v[3]);
+            if constexpr (RAD == 8) radix8<DIR>(v);
+            if constexpr (RAD == 16) radix16<DIR>(v);
+            const unsigned t = static_cast<unsigned>(tid) / XPT + (1024u / XPT) * m, jc = static_cast<unsigned>(tid) % XPT;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                cf x = v[RAD == 16 ? R16_POS(k) : k];
+                if (k) x = tw_mul<DIR>(x, cmulf(twa[k * 16 + (t >> 6)], twb[k * 64 + (t & 63u)]));
+                bufs[(jc * R + k) * BUF + t] = x;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < (C1024 && BLU != 3 ? XPT : 0); ++j) {
             cf v[R];
 #pragma unroll
             for (int a = 0; a < R; ++a) v[a] = pre[j * R + a];
@@ -667,12 +699,44 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
         }
         __syncthreads();
         if (g + 1 < n_steps && tile_of(g + 1) < n_tiles) fetch(tile_of(g + 1));
+        // Four-step twiddle of the column pass's store, W_N^{c k} for this lane's column c and k = kk + (1024 / XPT) u:
+        // W_N^{c kk} and the step W_N^{c 1024 / XPT}, looked up here, a whole transform ahead of their use
+        cf cw0 = cf{1.f, 0.f}, cws = cf{1.f, 0.f};
+        if constexpr (BLU == 3) {
+            const unsigned t4 = static_cast<unsigned>(tid) >> 4;
+            const unsigned c = static_cast<unsigned>(tix % (1024u / XPT)) * XPT + t4 % XPT;
+            const unsigned e0 = c * (16u * (t4 / XPT) + (static_cast<unsigned>(tid) & 15u)), es = c * (1024u / XPT);  // < 2^24
+            cw0 = g_mul(blu.tw_hi[e0 >> 12], blu.tw_lo[e0 & 4095]);
+            cws = g_mul(blu.tw_hi[es >> 12], blu.tw_lo[es & 4095]);
+        }
         // ---- this wave's 1024 points: one 1024-point transform, 16 of 64 points or 4 of 256 points
         rx_wave_core<DIR, C64, C256, C16N>(buf, tw1, tw2, l, q0, q1);
         __syncthreads();
         // ---- store: tile element i = j*N + RAD*k2 + k1 is output i
         cf* dst = out + tix * (16u * 1024u);
         const size_t left_out = n_points - tix * (16u * 1024u);
+        if constexpr (BLU == 3) {
+            // tile element (j, k) -> [k / 16][column][k % 16] of its transform: lane (k % 16 = tid & 15, j = (tid >> 4) % XPT)
+            // writes k = kk + (1024 / XPT) u; the twiddle W_N^{c k} = cw0 * cws^u as a product of at most four of
+            // cws, cws^2, cws^4, cws^8 (a chain of fifteen products would carry fifteen roundings)
+            constexpr unsigned TPX = 1024u / XPT;
+            const unsigned t4 = static_cast<unsigned>(tid) >> 4, js = t4 % XPT, kk = 16u * (t4 / XPT) + (static_cast<unsigned>(tid) & 15u);
+            cf* xo_base = out + (tix / TPX) * (static_cast<size_t>(N) * 1024u) + static_cast<size_t>(kk >> 4) * 16384u + ((tix % TPX) * XPT + js) * 16u + (kk & 15u);
+            const cf* lsrc = bufs + (js * R + kk % R) * BUF + kk / R + ((kk / R) >> 4);
+            const cf p1 = cws, p2 = g_mul(p1, p1), p4 = g_mul(p2, p2), p8 = g_mul(p4, p4);
+            cf l8 = cw0, l4 = cw0, l2 = cw0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (u == 8) l8 = g_mul(cw0, p8);
+                if ((u & 3) == 0) l4 = (u & 4) ? g_mul(l8, p4) : l8;
+                if ((u & 1) == 0) l2 = (u & 2) ? g_mul(l4, p2) : l4;
+                const cf w = (u & 1) ? g_mul(l2, p1) : l2;
+                // k = kk + 64 R u: row k % R = kk % R, position k / R = kk / R + 64 u of it, padded by one slot per sixteen
+                const cf x = lsrc[68 * u];
+                xo_base[static_cast<size_t>(u) * (TPX / 16u) * 16384u] = tw_apply<DIR>(x, w);
+            }
+            continue;
+        }
 #pragma unroll 8
         for (int u = 0; u < 16; ++u) {
             const unsigned i = static_cast<unsigned>(tid) + 1024u * u;
@@ -703,16 +767,6 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
             } else if constexpr (RAD == 512) {  // transform tid >> 9: slot 2 tr + k1, frequency k2
                 const unsigned k = static_cast<unsigned>(tid) & 511u;
                 xo = bufs[u * BUF + (2 * (static_cast<unsigned>(tid) >> 9) + (k & 1u)) * F256_T + (k >> 1)];
-            } else if (BLU == 0 && blu.tr_rows) {
-                // transposed store: consecutive lanes take the XPT rows of the tile at one output index k, so that a
-                // wave writes XPT * 8 B pieces at stride tr_rows * 8 B (the tile's rows are XPT adjacent rows k1 of one
-                // transform: XPT divides tr_rows)
-                const unsigned j = i % XPT, k = i / XPT;         // row of the tile, output index 0 .. N - 1
-                const unsigned k1 = k % R, k2 = k / R;
-                xo = bufs[(j * R + k1) * BUF + k2 + (k2 >> 4)];
-                const size_t row = tix * XPT + j;                 // row of the batch: transform row / tr_rows, its row k1
-                dp = out + (row / blu.tr_rows) * (static_cast<size_t>(blu.tr_rows) * N) + (row % blu.tr_rows) +
-                     static_cast<size_t>(blu.tr_rows) * k;
             } else {
                 const unsigned k1 = i % R, k2 = (i / R) & 1023u, j = i / N;
                 xo = bufs[(j * R + k1) * BUF + k2 + (k2 >> 4)];
@@ -1100,6 +1154,21 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
         a.twL = reinterpret_cast<const cf*>(pl.d_tw[0]);
         a.tw_lo = reinterpret_cast<const cf*>(pl.d_tw[2]);
         a.tw_hi = reinterpret_cast<const cf*>(pl.d_tw[3]);
+        // row pass of the two-pass form: tile t = the 16 adjacent outputs k of every column, as the column pass left them
+        // ([k / 16][column][k % 16]); 1024-point transforms over the columns; X[k + N2 k2] in 128-byte pieces
+        FftTileParams& b = pl.pass[1];
+        tile_geometry(b, 1024, 16);
+        b.in_c_fast = 1;
+        b.out_c_fast = 1;
+        b.in_cs = 1;
+        b.in_ls = 16;
+        b.out_cs = 1;
+        b.out_ks = N2;
+        b.tiles_per_xform = N2 / 16;
+        b.tile_step_in = 16384;
+        b.tile_step_out = 16;
+        b.N = N;
+        b.twL = a.twL;
         pl.rows = new (std::nothrow) Pow2Plan;
         COMMS_ARG(pl.rows != nullptr, "out of host memory");
         COMMS_TRY(pow2_plan_build(*pl.rows, N2));
@@ -1288,7 +1357,7 @@ static comms_status_t launch_fast(Pow2Plan& pl, const float2* src, float2* dst, 
 
 template <int RAD>
 static comms_status_t launch_rx(Pow2Plan& pl, const float2* src, float2* dst, size_t n_points, bool inverse,
-                                hipStream_t s, const BluArgs& blu = BluArgs{0, 0, 0, nullptr, nullptr, 0}) {
+                                hipStream_t s, const BluArgs& blu = BluArgs{0, 0, 0, nullptr, nullptr}) {
     const size_t n_full = n_points / 16384, rem = n_points % 16384;
     const cf* a = reinterpret_cast<const cf*>(src);
     cf* d = reinterpret_cast<cf*>(dst);
@@ -1333,6 +1402,34 @@ static comms_status_t launch_rx(Pow2Plan& pl, const float2* src, float2* dst, si
     return launch_ok("fft_rx1024_kernel");
 }
 
+// Column pass of N = 2^21 ... 2^24 (BluArgs mode 3) on the row plan's tables: `rows` is the plan of the N / 1024-point transforms.
+template <int RAD>
+static comms_status_t launch_rx_cols(Pow2Plan& rows, const float2* src, float2* dst, size_t n_points, bool inverse, hipStream_t s,
+                                     const cf* tw_lo, const cf* tw_hi) {
+    constexpr size_t lds = rx_cols_lds(RAD);
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rx1024_kernel<1, RAD, 3>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rx1024_kernel<-1, RAD, 3>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    }
+    BluArgs blu{3, 0, 0, nullptr, nullptr, tw_lo, tw_hi};
+    const size_t n_tiles = n_points / 16384;  // whole transforms of at least 2^21 points: no partial tile
+    const unsigned blocks = static_cast<unsigned>(n_tiles < static_cast<size_t>(kNumCU) ? n_tiles : kNumCU);
+    const cf* a = reinterpret_cast<const cf*>(src);
+    cf* d = reinterpret_cast<cf*>(dst);
+    const cf* t1 = reinterpret_cast<const cf*>(rows.d_fw1);
+    const cf* t2 = reinterpret_cast<const cf*>(rows.d_fw2);
+    const cf* ta = reinterpret_cast<const cf*>(rows.d_rxa);
+    const cf* tb = reinterpret_cast<const cf*>(rows.d_rxb);
+    if (inverse)
+        fft_rx1024_kernel<1, RAD, 3><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, n_tiles, 0, n_points, t1, t2, ta, tb, blu);
+    else
+        fft_rx1024_kernel<-1, RAD, 3><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, n_tiles, 0, n_points, t1, t2, ta, tb, blu);
+    return launch_ok("fft_rx1024_kernel (columns)");
+}
+
 template <int KIND>
 static comms_status_t launch_cols(Pow2Plan& pl, const float2* src, float2* dst, size_t batch, bool inverse,
                                   hipStream_t s) {
@@ -1361,7 +1458,7 @@ static comms_status_t launch_cols(Pow2Plan& pl, const float2* src, float2* dst, 
 
 // All of a batch on the single-pass kernel (plain, or as one half of a Bluestein pair).
 static comms_status_t run_rx(Pow2Plan& pl, const float2* in, float2* out, size_t n_points, bool inverse, hipStream_t s,
-                             const BluArgs& blu = BluArgs{0, 0, 0, nullptr, nullptr, 0}) {
+                             const BluArgs& blu = BluArgs{0, 0, 0, nullptr, nullptr}) {
     switch (pl.rx_rad) {
             case -1: COMMS_TRY(launch_rx<0>(pl, in, out, n_points, inverse, s, blu)); break;
             case -2: COMMS_TRY(launch_rx<256>(pl, in, out, n_points, inverse, s, blu)); break;
@@ -1388,18 +1485,29 @@ static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size
         return v && *v && *v != '0';
     }();
     if (pl.rx_rad && !no_rx) return run_rx(pl, in, out, batch * pl.N, inverse, s);
-    if (pl.rows) {  // N = 2^21 ... 2^24: columns (in -> scratch), rows (in place), transpose (scratch -> out)
+    if (pl.rows) {
+        // N = 2^21 ... 2^24 in two passes: N / 1024-point columns gathered in pieces of 64 ... 8 B (small pieces cost far less
+        // on the read side than on the write side: scripts/probes/strided_tiles.hip), spectra out in runs of 1 KiB ... 128 B;
+        // then 1024-point rows, sixteen adjacent ones per tile, stored transposed in 128-byte pieces.
+        static const int gather_max = [] { const char* v = getenv("COMMS_FFT_LARGE_GATHER"); return v && *v ? atoi(v) : 23; }();
+        if (ilog2(pl.N) <= gather_max && pl.rows->rx_rad >= 2) {
+            const cf* lo = pl.pass[0].tw_lo;
+            const cf* hi = pl.pass[0].tw_hi;
+            switch (pl.rows->rx_rad) {
+                case 2: COMMS_TRY(launch_rx_cols<2>(*pl.rows, in, scratch, batch * pl.N, inverse, s, lo, hi)); break;
+                case 4: COMMS_TRY(launch_rx_cols<4>(*pl.rows, in, scratch, batch * pl.N, inverse, s, lo, hi)); break;
+                case 8: COMMS_TRY(launch_rx_cols<8>(*pl.rows, in, scratch, batch * pl.N, inverse, s, lo, hi)); break;
+                default: COMMS_TRY(launch_rx_cols<16>(*pl.rows, in, scratch, batch * pl.N, inverse, s, lo, hi)); break;
+            }
+            FftTileParams q = pl.pass[1];
+            q.n_tiles = batch * q.tiles_per_xform;
+            return launch_fast(pl, scratch, out, q, inverse, s);
+        }
+        // N = 2^24 (8-byte pieces): three launches on 128-byte pieces throughout -- 1024-point columns (in -> scratch), rows (in
+        // place), transpose (scratch -> out) -- are faster (0.78 against 0.82 ms per 2^26 points)
         FftTileParams p = pl.pass[0];
         p.n_tiles = batch * p.tiles_per_xform;
         COMMS_TRY(launch_fast(pl, in, scratch, p, inverse, s));
-        // Two passes where the row pass can store transposed in pieces of at least 64 B (N = 2^21: eight 2048-point
-        // rows per tile): 32 B/point instead of 48.  Beyond, the pieces shrink to 32 ... 8 B and the separate
-        // transpose wins (profiles/r03_bench_fft_large.txt); COMMS_FFT_LARGE_2PASS = max log2 N of the two-pass form.
-        static const int two_pass_max = [] { const char* v = getenv("COMMS_FFT_LARGE_2PASS"); return v && *v ? atoi(v) : 21; }();
-        if (ilog2(pl.N) <= two_pass_max && pl.rows->rx_rad >= 1) {
-            BluArgs tr{0, 0, 0, nullptr, nullptr, 1024u};
-            return run_rx(*pl.rows, scratch, out, batch * pl.N, inverse, s, tr);
-        }
         COMMS_TRY(run_rx(*pl.rows, scratch, scratch, batch * pl.N, inverse, s));
         const unsigned cols = static_cast<unsigned>(pl.N >> 10);
         const size_t n_tiles = batch * (1024 / TR_T) * (cols / TR_T);
@@ -1677,9 +1785,9 @@ comms_status_t comms_fft_run_dev(comms_fft_t* h, const comms_c32* d_in, size_t n
             // two launches: [x * chirp, pad, forward, * bspec] -> work;  [inverse, * chirp, first N] -> out
             const cf* chirp = reinterpret_cast<const cf*>(h->d_chirp);
             COMMS_TRY(run_rx(h->plan, in + b0 * h->N, a, nb * M, false, s,
-                             BluArgs{1, static_cast<unsigned>(h->N), logM, chirp, reinterpret_cast<const cf*>(h->d_bspec), 0}));
+                             BluArgs{1, static_cast<unsigned>(h->N), logM, chirp, reinterpret_cast<const cf*>(h->d_bspec)}));
             COMMS_TRY(run_rx(h->plan, a, o + b0 * h->N, nb * M, true, s,
-                             BluArgs{2, static_cast<unsigned>(h->N), logM, chirp, nullptr, 0}));
+                             BluArgs{2, static_cast<unsigned>(h->N), logM, chirp, nullptr}));
             continue;
         }
         blu_pre_kernel<<<dim3(4 * kNumCU), dim3(256), 0, s>>>(reinterpret_cast<const cf*>(in + b0 * h->N), reinterpret_cast<const cf*>(h->d_chirp), reinterpret_cast<cf*>(a), h->N, M, nb);

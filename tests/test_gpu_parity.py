@@ -873,11 +873,11 @@ def test_fft_four_step_column_pass(c, logn, inverse):
 @pytest.mark.parametrize("logn,batch", [(21, 3), (22, 2), (23, 1), (24, 2)])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_fft_above_2p20_columns_rows_transpose(c, logn, batch, inverse):
-    """N = 2^21 ... 2^24 (fft_node.rs:65-74 accepts any size): 1024-point columns at stride N / 1024 with the
-    four-step twiddle, then N / 1024-point rows -- stored transposed (N = 2^21: two passes), or in place with a tiled
-    transpose behind them (three launches; `COMMS_FFT_LARGE_2PASS=24 pytest -k fft` runs every size on the two-pass
-    form, as scripts/steps/r03_p.txt did).  Device-resident, out of place and in place; against numpy's f64 FFT of
-    the same counter-based input (the oracle's own FFT is checked against numpy in the CPU suite)."""
+    """N = 2^21 ... 2^24 (fft_node.rs:65-74 accepts any size).  2^21 ... 2^23 take two passes: N / 1024-point columns
+    gathered in pieces of 64 ... 16 B with the four-step twiddle (`fft_rx1024_kernel`, mode 3), then 1024-point rows
+    stored transposed.  2^24 takes three launches (1024-point columns, 16384-point rows in place, tiled transpose).
+    Device-resident, out of place and in place; against numpy's f64 FFT of the same counter-based input (the oracle's
+    own FFT is checked against numpy in the CPU suite)."""
     import torch
 
     n = 1 << logn
@@ -923,6 +923,34 @@ def test_fft_tones_every_bin(c, logn, batch, inverse):
     want[torch.arange(batch, device=dev), bins] = torch.from_numpy((amp * N).astype(np.complex64)).to(dev)
     err = float((y.reshape(batch, N) - want).abs().max())
     assert err <= 2e-6 * N * np.sqrt(logn), (err, N)
+
+
+@pytest.mark.parametrize("gather_max", [0, 24])
+def test_fft_above_2p20_the_other_form_of_every_size(gather_max):
+    """COMMS_FFT_LARGE_GATHER = the largest log2 N on the two-pass form (default 23): 0 runs 2^21 ... 2^23 on the three
+    launches, 24 runs 2^24 on the two passes (8-byte pieces).  The switch is read once per process: own process."""
+    import subprocess
+    import sys
+
+    code = r'''
+import sys; sys.path.insert(0, %r)
+import numpy as np, torch, comms_rs_amd as c
+for logn, inverse in ((21, False), (22, True), (23, False), (24, True)):
+    n = 1 << logn
+    x = torch.empty(n, dtype=torch.complex64, device="cuda:0")
+    c.synth_iq_dev(x.data_ptr(), n, 0, 90 + logn)
+    y = torch.empty_like(x)
+    c.FFTBatchNode(n, inverse).run_dev(x.data_ptr(), n, y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    xs = c.synth_iq(n, 0, 90 + logn).astype(np.complex128)
+    want = np.fft.ifft(xs) * n if inverse else np.fft.fft(xs)
+    d = np.linalg.norm(y.cpu().numpy().astype(np.complex128) - want) / np.linalg.norm(want)
+    assert d <= %r, (logn, d)
+print("ok")
+''' % (ROOT, TOL)
+    env = dict(os.environ, COMMS_FFT_LARGE_GATHER=str(gather_max))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
 
 def test_fft_bluestein_on_a_padded_length_above_2p20(c):
