@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void fir_direct_kernel(In in,
                                                          int hist_len,
                                                          const float2* __restrict__ taps_pad,
                                                          int NP, float2* __restrict__ out,
-                                                         size_t n, int out_vec4,
+                                                         size_t n,
                                                          float2* __restrict__ new_hist) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x;
@@ -146,15 +146,33 @@ __global__ __launch_bounds__(256) void fir_direct_kernel(In in,
         for (int j = 0; j < 8; ++j) wh[j] = wl[j];
     }
 
-    const size_t ob = o0 + static_cast<size_t>(t) * DT;
-    if (out_vec4 && ob + DT <= n) {
-        cf2* o4 = reinterpret_cast<cf2*>(out + ob);
+    // A lane's DT outputs are 64 contiguous bytes: stored as they are, one instruction would write 16-byte pieces at a
+    // stride of 64 B.  They go through LDS instead (the sample window is dead once every wave has left the tap loop; a
+    // wave reads back only what it wrote), so that each store instruction covers 1 KiB of whole lines.
+    __syncthreads();
+    cf* ex = xt + (t & ~63) * DROW;           // the wave's 512 outputs in output order, a lane's eight in an 80-byte row
+    const int lane = t & 63;
+    {
+        cf2* w4 = reinterpret_cast<cf2*>(ex + lane * DROW);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o4[j] = cf2{acc[2 * j].x, acc[2 * j].y, acc[2 * j + 1].x, acc[2 * j + 1].y};
-    } else {
+        for (int j = 0; j < 4; ++j) w4[j] = cf2{acc[2 * j].x, acc[2 * j].y, acc[2 * j + 1].x, acc[2 * j + 1].y};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const size_t ow = o0 + static_cast<size_t>(t & ~63) * DT;  // the wave's first output
+    const unsigned left = ow < n ? static_cast<unsigned>(n - ow < 64u * DT ? n - ow : 64u * DT) : 0u;
 #pragma unroll
-        for (int j = 0; j < DT; ++j)
-            if (ob + j < n) out[ob + j] = to_f2(acc[j]);
+    for (int i = 0; i < DT / 2; ++i) {
+        const unsigned e = (static_cast<unsigned>(i) * 64u + lane) * 2u;
+        const cf* src = ex + (e >> 3) * DROW + (e & 7u);
+        if (e + 1 < left) {
+            const cf2 v = *reinterpret_cast<const cf2*>(src);
+            float2 q[2] = {make_float2(v.x, v.y), make_float2(v.z, v.w)};
+            __builtin_memcpy(out + ow + e, q, 16);
+        } else if (e < left) {
+            out[ow + e] = to_f2(src[0]);
+        }
     }
 }
 
@@ -1068,19 +1086,32 @@ struct PulseArgs {
 template <int SPS, bool REAL, bool MIX>
 __global__ __launch_bounds__(256) void pulse_poly_kernel(const PulseArgs a) {
     constexpr int SPSP = SPS + (SPS & 1);
+    constexpr bool XS = true;  // outputs leave through a per-wave LDS block, CW phases at a time (CW * 2 KiB per workgroup)
+    constexpr int CW = SPS <= 8 ? SPS : SPS % 8 == 0 ? 8 : SPS % 6 == 0 ? 6 : SPS % 5 == 0 ? 5 : SPS % 4 == 0 ? 4 : SPS % 3 == 0 ? 3 : SPS % 2 == 0 ? 2 : 1;
     __shared__ cf sh[256 + PP_JMAX];
+    __shared__ __attribute__((aligned(16))) cf xch[256 * CW];
     const int tid = threadIdx.x;
     const int halo = a.J - 1;
     const size_t ntiles = (a.n_sym + 255) / 256;
     hist_advance(a.hist, a.sym, a.n_sym, a.new_hist, a.hist_len);
     double rc = 1.0, rs = 0.0;  // rotor of this lane's first output of the current tile
     if (MIX) pulse_rotor_at(a.mx.turns0 + (static_cast<uint64_t>(blockIdx.x) * 256 + tid) * SPS * a.mx.frac, rc, rs);
+    // the next tile's symbols are requested before this tile's taps run and land in LDS at the top of the next step: a
+    // tile's own work is short, and without this every step began with an exposed round trip to HBM
+    cf nx0 = cf{0.f, 0.f}, nx1 = cf{0.f, 0.f};  // window elements tid and 256 + tid (the latter: tid < halo <= 127)
+    auto fetch = [&](size_t t) {
+        const long long w0 = static_cast<long long>(t) * 256 - halo;
+        nx0 = to_cf(stream_at(a.sym, a.hist, a.hist_len, w0 + tid, a.n_sym));
+        if (tid < halo) nx1 = to_cf(stream_at(a.sym, a.hist, a.hist_len, w0 + 256 + tid, a.n_sym));
+    };
+    if (blockIdx.x < ntiles) fetch(blockIdx.x);
     for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const long long m0 = static_cast<long long>(t) * 256;
         __syncthreads();
-        for (int i = tid; i < 256 + halo; i += 256)
-            sh[i] = to_cf(stream_at(a.sym, a.hist, a.hist_len, m0 - halo + i, a.n_sym));
+        sh[tid] = nx0;
+        if (tid < halo) sh[256 + tid] = nx1;
         __syncthreads();
+        if (t + gridDim.x < ntiles) fetch(t + gridDim.x);
         cf acc[SPS];
 #pragma unroll
         for (int p = 0; p < SPS; ++p) acc[p] = cf{0.f, 0.f};
@@ -1112,7 +1143,68 @@ __global__ __launch_bounds__(256) void pulse_poly_kernel(const PulseArgs a) {
             rs = rc * a.mx.sweep_s + rs * a.mx.sweep_c;
             rc = nc;
         }
-        if (m < a.n_sym) {
+        if constexpr (XS) {
+            // A lane's SPS outputs are one run of SPS * 8 B, so a plain store instruction covers a wave's 64 SPS outputs in
+            // pieces of 16 B at a stride of SPS * 8 B.  Through the wave's own LDS block instead, CW <= 8 phases at a time:
+            // instruction i writes elements 64 i ... 64 i + 63 of the block [64 symbols][CW], i.e. whole lines for SPS <= 8
+            // and runs of CW * 8 B above (63 taps x 4, 2^26 outputs: 183 -> 134 us; 127 taps x 8, 2^24: 48.8 -> 29.7 us).
+            cf* ex = xch + (tid & ~63) * CW;
+            const int lane = tid & 63;
+            const size_t mw = static_cast<size_t>(m0) + (tid & ~63);                      // the wave's first symbol
+            const unsigned nel = mw < a.n_sym ? static_cast<unsigned>(a.n_sym - mw < 64 ? a.n_sym - mw : 64) * CW : 0u;  // valid elements per chunk
+#pragma unroll
+            for (int c = 0; c < SPS / CW; ++c) {
+                if (c) {  // the previous chunk has been read
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+#pragma unroll
+                for (int p = 0; p < CW; ++p) ex[lane * CW + p] = acc[c * CW + p];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (a.mx.out_i16) {  // the transmit chain straight into the IQOutput wire format: 4 B per output
+                    constexpr int W = CW % 4 == 0 ? 4 : CW % 2 == 0 ? 2 : 1;  // outputs per lane and store
+                    short2* o = reinterpret_cast<short2*>(a.out) + mw * SPS + c * CW;
+#pragma unroll
+                    for (int i = 0; i < CW / W; ++i) {
+                        const unsigned e = (static_cast<unsigned>(i) * 64u + lane) * W;
+                        if (e < nel) {  // (nel is a multiple of CW, hence of W)
+                            short2 q[W];
+#pragma unroll
+                            for (int w = 0; w < W; ++w) q[w] = c32_as_i16(to_f2(ex[e + w]), a.mx.out_scale);
+                            short2* dp = o + (e / CW) * SPS + e % CW;
+                            if constexpr (W == 4) {
+                                u32x4 qv;
+                                __builtin_memcpy(&qv, q, 16);
+                                store_b128_dword_aligned(dp, qv);
+                            } else if constexpr (W == 2) {
+                                __builtin_memcpy(dp, q, 8);
+                            } else {
+                                dp[0] = q[0];
+                            }
+                        }
+                    }
+                } else {
+                    constexpr int W = CW % 2 == 0 ? 2 : 1;
+                    float2* o = a.out + mw * SPS + c * CW;
+#pragma unroll
+                    for (int i = 0; i < CW / W; ++i) {
+                        const unsigned e = (static_cast<unsigned>(i) * 64u + lane) * W;
+                        if (e < nel) {
+                            float2* dp = o + (e / CW) * SPS + e % CW;
+                            if constexpr (W == 2) {
+                                const cf u0 = ex[e], u1 = ex[e + 1];
+                                float2 q[2] = {to_f2(u0), to_f2(u1)};
+                                __builtin_memcpy(dp, q, 16);
+                            } else {
+                                dp[0] = to_f2(ex[e]);
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (m < a.n_sym) {
             if (a.mx.out_i16) {  // the transmit chain straight into the IQOutput wire format: 4 B per output
                 short2* o = reinterpret_cast<short2*>(a.out) + m * SPS;
 #pragma unroll
@@ -1447,18 +1539,18 @@ static comms_status_t fir_prepare_direct(comms_fir* h) {
 static int fir_pick(const comms_fir* h, size_t n) {
     int algo = h->algo;
     if (algo == COMMS_FIR_AUTO) {
-        // Measured on MI355X (launch to completion, `scripts/bench_fir.py`), 16 ... 255 taps, 2^16 ... 2^24
-        // samples: the direct kernel costs about 6.5 us + 0.025 us/tap + n * (3.3 + 0.038 * taps) ps,
-        // the 1024-point overlap-save kernel about 12.4 us + n * 2.0 ps for any tap count up to 257.
-        // Radio-sized batches (2^18 samples) of the 32- and 63-tap filters the reference's examples
-        // use are therefore direct-form work (8 us against 13); long streams are not.
+        // Measured on MI355X (launch to completion, `scripts/bench_fir.py` / `scripts/ab_libs.py`), 8 ... 255 taps, 2^16 ...
+        // 2^24 samples: the direct kernel costs about 6.5 us + 0.025 us/tap + n * (2.2 + 0.024 * taps) ps (its stores
+        // coalesced through LDS since round 3: 3.3 -> 2.2 ps), the 1024-point overlap-save kernel about 12.4 us + n * 2.0 ps
+        // for any tap count up to 257.  Radio-sized batches (2^18 ... 2^20 samples) of the 32- and 63-tap filters the
+        // reference's examples use are therefore direct-form work (7-9 us against 9-13); long streams are not.
         if (h->n_eff > DIRECT_MAX_TAPS) {
             algo = COMMS_FIR_OVERLAP_SAVE;
-        } else if (h->n_eff <= 8 || n < 1024) {
-            algo = COMMS_FIR_DIRECT;  // <= 8 taps: a tie on long streams (66 us both at 2^24); less than one segment
+        } else if (n < 1024) {
+            algo = COMMS_FIR_DIRECT;  // less than one segment
         } else {
             const double t = static_cast<double>(h->n_eff), nn = static_cast<double>(n);
-            const double direct_ps = 6.5e6 + 0.025e6 * t + nn * (3.3 + 0.038 * t);
+            const double direct_ps = 6.5e6 + 0.025e6 * t + nn * (2.2 + 0.024 * t);
             // (4-wave workgroups, used up to 1024 segments, take about 1.1 us off the fixed part)
             const double os_ps = (nn <= 768.0 * 4 * kNumCU ? 11.3e6 : 12.4e6) + nn * 2.0;
             algo = direct_ps < os_ps ? COMMS_FIR_DIRECT : COMMS_FIR_OVERLAP_SAVE;
@@ -1645,11 +1737,11 @@ static void launch_os16k_hr(int hr, unsigned blocks, size_t lds, hipStream_t s, 
 }
 template <class In>
 static void launch_direct_in(comms_fir* h, In in, const float2* hist, float2* o, size_t n, float2* nh, unsigned blocks,
-                             size_t lds, int vec4, hipStream_t s) {
+                             size_t lds, hipStream_t s) {
     if (h->real_taps)
-        fir_direct_kernel<true, In><<<dim3(blocks), dim3(256), lds, s>>>(in, hist, h->n_eff, h->d_taps_pad, h->NP, o, n, vec4, nh);
+        fir_direct_kernel<true, In><<<dim3(blocks), dim3(256), lds, s>>>(in, hist, h->n_eff, h->d_taps_pad, h->NP, o, n, nh);
     else
-        fir_direct_kernel<false, In><<<dim3(blocks), dim3(256), lds, s>>>(in, hist, h->n_eff, h->d_taps_pad, h->NP, o, n, vec4, nh);
+        fir_direct_kernel<false, In><<<dim3(blocks), dim3(256), lds, s>>>(in, hist, h->n_eff, h->d_taps_pad, h->NP, o, n, nh);
 }
 
 extern "C" {
@@ -1682,14 +1774,13 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
         const unsigned blocks = static_cast<unsigned>((n + DTILE - 1) / DTILE);
         const int nrows = (DTILE + h->NP) / 8;
         const size_t lds = static_cast<size_t>(nrows) * DROW * sizeof(float2) + static_cast<size_t>(h->NP) * sizeof(float2);
-        const int vec4 = (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
         h->tic(s);
         if (h->in_fmt == COMMS_IQ_I16)
-            launch_direct_in(h, InI16{static_cast<const short2*>(d_in), h->in_scale}, hist, o, n, nh, blocks, lds, vec4, s);
+            launch_direct_in(h, InI16{static_cast<const short2*>(d_in), h->in_scale}, hist, o, n, nh, blocks, lds, s);
         else if (h->in_fmt == COMMS_IQ_U8)
-            launch_direct_in(h, InU8{static_cast<const uchar2*>(d_in)}, hist, o, n, nh, blocks, lds, vec4, s);
+            launch_direct_in(h, InU8{static_cast<const uchar2*>(d_in)}, hist, o, n, nh, blocks, lds, s);
         else
-            launch_direct_in(h, in, hist, o, n, nh, blocks, lds, vec4, s);
+            launch_direct_in(h, in, hist, o, n, nh, blocks, lds, s);
         h->toc(s);
         COMMS_TRY(launch_ok("fir_direct_kernel"));
     } else if (algo == COMMS_FIR_OS1024) {

@@ -109,10 +109,15 @@ struct BufRows<InU8> {
 // saturates, and maps NaN to 0 -- what IQOutput then writes (src/io/raw_iq.rs:173-178).  Shared by the
 // stand-alone conversion kernel (iqformat.hip) and the pulse shaper's i16 store stage.
 __device__ __forceinline__ short rust_as_i16(float v) {
-    if (v != v) return 0;                 // NaN -> 0
-    if (v >= 32767.0f) return 32767;      // saturate
-    if (v <= -32768.0f) return -32768;
-    return static_cast<short>(static_cast<int>(v));  // truncation toward zero
+    float c = __builtin_fminf(__builtin_fmaxf(v, -32768.0f), 32767.0f);  // saturate (selects, no branches)
+    c = v != v ? 0.0f : c;                                                // NaN -> 0
+    return static_cast<short>(static_cast<int>(c));                       // truncation toward zero
+}
+// 16 bytes to an address that is only 4-byte aligned (an i16 IQ stream at any sample offset): one store instruction
+// (the compiler splits such a store into 12 + 4 bytes)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_b128_dword_aligned(void* p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ short2 c32_as_i16(float2 v, float scale) {
     return make_short2(rust_as_i16(scale * v.x), rust_as_i16(scale * v.y));

@@ -1,4 +1,4 @@
-"""A/B timing of two builds of the library in ONE process, launch by launch (FIR node; ALGO=os1024|os4096|os16k|auto).
+"""A/B timing of two builds of the library in ONE process, launch by launch (FIR node; ALGO=os1024|os4096|os16k|direct|auto).
 usage: python scripts/ab_libs.py <libA.so> <libB.so> [n_taps] [log2 n] [reps]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,7 +20,7 @@ for p in paths:
     l.comms_fir_create.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int32, C.POINTER(C.c_void_p)]
     assert l.comms_fir_create(taps.ctypes.data, taps.size, None, 0, 0, C.byref(h)) == 0
     l.comms_fir_set_algo.argtypes = [C.c_void_p, C.c_int32]
-    assert l.comms_fir_set_algo(h, {"os1024": c.FIR_OS1024, "os4096": c.FIR_OS4096, "os16k": c.FIR_OS16K, "auto": c.FIR_AUTO}[os.environ.get("ALGO", "os1024")]) == 0
+    assert l.comms_fir_set_algo(h, {"os1024": c.FIR_OS1024, "os4096": c.FIR_OS4096, "os16k": c.FIR_OS16K, "auto": c.FIR_AUTO, "direct": c.FIR_DIRECT}[os.environ.get("ALGO", "os1024")]) == 0
     l.comms_fir_run_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     hs.append((l, h))
 run = lambda i: hs[i][0].comms_fir_run_dev(hs[i][1], x.data_ptr(), n, y.data_ptr(), s)

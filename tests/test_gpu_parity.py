@@ -389,7 +389,10 @@ def test_fir_auto_selection_and_errors(c):
     assert c.BatchFirNode(np.ones(1538, np.complex64)).algo_for(1 << 24) == c.FIR_OS16K
     assert c.BatchFirNode(np.ones(1537, np.complex64)).algo_for(1 << 24) == c.FIR_OS4096
     assert node.algo_for(4) == c.FIR_DIRECT
-    assert c.BatchFirNode(np.ones(8, np.complex64)).algo_for(1 << 24) == c.FIR_DIRECT
+    # (up to round 3 filters of at most 8 taps always went the direct way: a tie at 2^24 then, a point behind now)
+    assert c.BatchFirNode(np.ones(8, np.complex64)).algo_for(1 << 24) == c.FIR_OS1024
+    assert c.BatchFirNode(np.ones(8, np.complex64)).algo_for(1 << 22) == c.FIR_DIRECT
+    assert c.BatchFirNode(np.ones(63, np.complex64)).algo_for(1 << 20) == c.FIR_DIRECT
     assert c.BatchFirNode(np.ones(63, np.complex64)).algo_for(1 << 24) == c.FIR_OS1024
     assert c.BatchFirNode(np.ones(63, np.complex64)).algo_for(4096) == c.FIR_DIRECT
     # radio-sized batches of the examples' 32- / 63-tap filters are direct-form work, long filters are not
