@@ -899,13 +899,13 @@ def test_fft_above_2p20_columns_rows_transpose(c, logn, batch, inverse):
     assert torch.equal(torch.view_as_real(x), torch.view_as_real(y))
 
 
-@pytest.mark.parametrize("logn,batch", [(6, 4096), (10, 512), (14, 64), (17, 16), (20, 8), (22, 2)])
+@pytest.mark.parametrize("logn,batch", [(6, 4096), (10, 512), (14, 64), (17, 16), (20, 8), (21, 3), (22, 2), (23, 2), (24, 1)])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_fft_tones_every_bin(c, logn, batch, inverse):
     """Every bin of every transform of a batch: transform b holds one complex tone of its own frequency k_b and
     amplitude, so its spectrum is N a_b at bin k_b (N - k_b for the inverse direction's sign) and numerically
     nothing anywhere else -- one case per FFT kernel family (in-register, one pass, column + row passes, 2^20
-    two-pass, columns + rows + transpose)."""
+    two-pass, gathered columns + rows at 2^21 ... 2^23, columns + rows + transpose at 2^24)."""
     import torch
 
     N = 1 << logn
