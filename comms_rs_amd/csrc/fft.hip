@@ -793,7 +793,13 @@ struct ColGeom {
     static constexpr int N1 = KIND == 0 ? 64 : KIND;
     static constexpr int C = 16384 / N1;    // columns per tile
     static constexpr int TPW = 1024 / N1;   // columns per wave buffer
-    static constexpr int BUF = C64 ? 1120 : 1160;
+    // Per-wave buffer stride.  Staging and the transposed store walk the lanes over the tile's columns, i.e. over buffers
+    // (column / TPW) and slots (column % TPW) at one row: with a stride that is a multiple of 32 slots of 8 B (1120, and
+    // 1160 = 8 mod 32 against the 256-point slots' 16 mod 32) the buffers of a half-wave fell on the same banks -- 70 % of
+    // the LDS cycles of the 256- and 512-point forms were bank conflicts (SQ_LDS_BANK_CONFLICT).  An odd stride spreads
+    // them; the 256-point core reads 16-byte pairs from its buffer and needs an even one (1154 = 2 mod 32), the 16-point form
+    // keeps its stride.
+    static constexpr int BUF = C16 ? 1160 : C256 ? 1154 : 1089;  // (the 256-point core uses 1150 slots of its buffer, the 64-point one 1087)
     static constexpr int SLOT = C64 ? FW_S1 : C256 ? F256_T : 18;
     static constexpr size_t LDS = (1024 + 64 + 256 + 16 * BUF) * sizeof(float2);
 };
