@@ -322,11 +322,11 @@ def test_fm_chain_full_size_tone_every_output(c, n_taps, rate, lg, kernel):
     assert err <= 2e-4, err
 
 
-@pytest.mark.parametrize("sps,n_taps", [(4, 63), (8, 255), (5, 40), (7, 33)])
+@pytest.mark.parametrize("sps,n_taps", [(4, 63), (8, 255), (5, 40), (7, 33), (2, 31), (16, 255), (20, 100)])
 def test_pulse_shaper_full_size_impulse_comb_every_output(c, sps, n_taps):
     """PulseNode (pulse.rs:82-92: zero-stuff by sam_per_sym, then the FIR) at 2^24 output samples, every output:
     isolated symbols come out as copies of the taps at sps * position, zero elsewhere (polyphase kernels for
-    sps 4 / 8 / 5, the generic kernel for 7)."""
+    sps 4 / 8 / 5 / 2, with the outputs leaving in chunks of 8 / 5 phases at 16 / 20; the generic kernel for 7)."""
     import torch
 
     n_sym = (1 << 24) // sps
