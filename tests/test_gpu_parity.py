@@ -180,6 +180,42 @@ def test_config5_4097_taps_windowed_sinc_long_stream(c):
         fir_close(y[a:a + 3000].cpu().numpy(), want, taps, xs)
 
 
+def test_config5_filter_every_output_against_the_oracle(c):
+    """BASELINE config 5's 4097-tap filter on the 16384-point kernel, every output of 2^21 samples (what one core of the
+    oracle's literal batch_fir does in a few seconds -- the sample `bench.py --config 5` times as its CPU baseline),
+    in two ragged calls with the history carried over."""
+    n = 1 << 21
+    k = np.arange(4097) - 2048
+    taps = (0.25 * np.sinc(0.25 * k) * np.hamming(4097)).astype(np.float32).astype(np.complex64)
+    x = c.synth_iq(n, 0, 55)
+    node = c.BatchFirNode(taps).set_algo(c.FIR_OS16K)
+    cut = 12288 * 57 + 1234
+    got = np.concatenate([node.run(x[:cut]), node.run(x[cut:])])
+    want = oracle.batch_fir(x, taps, oracle.default_state(taps), norotate=True)
+    fir_close(got, want, taps, x)
+
+
+def test_config1_every_output_against_the_oracle(c):
+    """BASELINE config 1 at its full size: 2^18 PRBS7 / BPSK symbols -> PulseNode(rrc_taps(63, 4, 0.25), 4) with the mixer
+    fused (one launch) = 2^20 samples, every one against oracle.pulse -> Mixer::mix; and the literal example
+    (32 taps, no mixer, x8192 -> i16 written by the kernel's store stage) against the oracle's `as i16`."""
+    n_sym = 1 << 18
+    bits, _ = oracle.prns_u8(0xC0, 0x01, n_sym)
+    sym = (2.0 * bits.astype(np.float32) - 1.0).astype(np.complex64)
+    taps = oracle.rrc_taps(63, 4.0, 0.25)
+    dphase = 2 * np.pi * 0.1
+    got = c.PulseNode(taps, 4).set_mixer(dphase, 0.0).run(sym)
+    want = oracle.Mixer(0.0, dphase).mix(oracle.pulse(sym, taps, 4, oracle.default_state(taps)))
+    fir_close(got, want, taps, sym)
+    taps32 = oracle.rrc_taps(32, 4.0, 0.25)
+    w32 = oracle.pulse(sym, taps32, 4, oracle.default_state(taps32))
+    g32 = c.PulseNode(taps32, 4).run(sym)
+    fir_close(g32, w32, taps32, sym)
+    # the i16 store stage converts what the f32 store stage writes: bit-identical to converting the node's own output
+    gi = c.PulseNode(taps32, 4).set_output_format("i16", 8192.0).run(sym)
+    assert np.array_equal(np.asarray(gi).reshape(-1), oracle.iq_c32_to_i16(g32, 8192.0).reshape(-1))
+
+
 def test_config5_full_shard_2p27_second_rank(c):
     """BASELINE config 5 at one GPU's full share: 2^30 samples over 8 GPUs = 2^27 per rank, 4097 taps.
     Rank 1's shard (stream samples 2^27 .. 2^28) with the halo handed over as FIR state, checked
@@ -441,6 +477,38 @@ def test_fir_os1024_ticketed_and_fixed_run_kernels_agree(c, n_taps):
         want = oracle.batch_fir(xs, taps, oracle.default_state(taps), norotate=True)[a - lo:]
         fir_close(ys[1][a:a + 4096].cpu().numpy(), want, taps, xs)
     assert c.BatchFirNode(taps).set_algo(c.FIR_OS1024).kernel_for(1 << 20) == "fir_os1024_kernel"
+
+
+def test_config2_every_output_against_the_oracle(c):
+    """BASELINE config 2 at its full size, every output, against the oracle on the whole stream (no windows): the
+    255-tap `rrc_taps(255, 8, 0.35)` BatchFirNode on 2^24 synthetic samples (the headline kernel), then MixerNode and
+    DecimateNode(8) node by node -- the chain `bench.py` times, against the chain its `cpu_baseline` times
+    (batch_fir -> Mixer::mix in f64 -> decimate; a few seconds of one core)."""
+    import torch
+
+    n = 1 << 24
+    taps = oracle.rrc_taps(255, 8.0, 0.35)
+    dphase = 2 * np.pi * 0.1
+    x = torch.empty(n, dtype=torch.complex64, device="cuda:0")
+    c.synth_iq_dev(x.data_ptr(), n, 0, 0xC0FFEE)
+    s = torch.cuda.current_stream().cuda_stream
+    y = torch.empty_like(x)
+    m = torch.empty_like(x)
+    d = torch.empty(n // 8, dtype=torch.complex64, device="cuda:0")
+    fir = c.BatchFirNode(taps)
+    assert fir.kernel_for(n) == "fir_os1024_dyn_kernel"
+    fir.run_dev(x.data_ptr(), n, y.data_ptr(), s)
+    c.MixerNode(dphase).run_dev(y.data_ptr(), n, m.data_ptr(), s)
+    c.DecimateNode(8).run_dev(m.data_ptr(), n, 8, d.data_ptr(), s)
+    torch.cuda.synchronize()
+    xs = c.synth_iq(n, 0, 0xC0FFEE)
+    want_y = oracle.batch_fir(xs, taps, oracle.default_state(taps), norotate=True)  # (bit-identical to the rotating form: CPU suite)
+    scale = float(np.sum(np.abs(taps))) * float(np.max(np.abs(xs)))
+    got_y = y.cpu().numpy()
+    assert float(np.max(np.abs(got_y - want_y))) <= TOL * scale
+    want_d = oracle.decimate(oracle.Mixer(0.0, dphase).mix(want_y), 8)
+    del want_y, got_y
+    assert float(np.max(np.abs(d.cpu().numpy() - want_d))) <= 2 * TOL * scale  # FIR error + the mixer's own rounding of |y| <= scale
 
 
 def test_fir_full_size_config2_properties(c):
@@ -1445,6 +1513,41 @@ def test_config3_full_size_2p26_fused_vs_nodes(c):
         d = (fa - fb).abs()
         d = torch.minimum(d, 2 * np.pi - d)
         assert float((d * mag).max()) <= 4 * TOL * scale  # angle error x magnitude ~ FIR error
+
+
+def test_config3_every_output_against_the_oracle(c):
+    """BASELINE config 3 at its full size (2^26 samples), every output of the fused launch against the oracle run over
+    the whole stream: Mixer::mix (f64) -> 127-tap batch_fir -> decimate(8) -> FM::demod.  (~10 s of one core.)"""
+    import torch
+
+    n = 1 << 26
+    taps = lowpass_taps(127, 1 / 16)
+    dphase = 2 * np.pi * 0.05
+    t = torch.arange(n, device="cuda:0", dtype=torch.float64)
+    ph = -2 * np.pi * 0.05 * t + 8.0 * torch.cos(2 * np.pi * t / 4096)  # fm_stream(): an FM tone the mixer brings to DC
+    x = torch.polar(torch.ones_like(ph), ph).to(torch.complex64)
+    del t, ph
+    s = torch.cuda.current_stream().cuda_stream
+    y = torch.empty(n // 8, dtype=torch.complex64, device="cuda:0")
+    f = torch.empty(n // 8, dtype=torch.float32, device="cuda:0")
+    c.ChainNode(dphase, 0.0, taps, 8, False).run_dev(x.data_ptr(), n, y.data_ptr(), s)
+    node = c.ChainNode(dphase, 0.0, taps, 8, True)
+    assert node.kernel == "time"
+    node.run_dev(x.data_ptr(), n, f.data_ptr(), s)
+    torch.cuda.synchronize()
+    xs = x.cpu().numpy()
+    del x
+    w = oracle.Mixer(0.0, dphase).mix(xs)
+    del xs
+    w = oracle.decimate(oracle.batch_fir(w, taps, oracle.default_state(taps), norotate=True), 8)
+    scale = float(np.sum(np.abs(taps)))
+    assert float(np.max(np.abs(y.cpu().numpy() - w))) <= TOL * scale
+    wf = oracle.FM().demod(w)
+    dd = np.abs(f.cpu().numpy().astype(np.float64) - wf)
+    dd = np.minimum(dd, 2 * np.pi - dd)
+    mag = np.minimum(np.abs(w), np.abs(np.concatenate([[1.0], w[:-1]])))
+    assert float(np.max(dd * mag)) <= 4 * TOL * scale  # angle error x magnitude ~ FIR error (the tone sits in the passband: |y| ~ 1)
+    assert float(np.max(dd[mag > 0.5])) <= 1e-4
 
 
 def test_fm_radio_example_chain(c):
