@@ -2056,15 +2056,24 @@ static bool pulse_poly_try(comms_pulse* h, const float2* sym, size_t n_sym, floa
             mix_host_rotor(static_cast<uint64_t>(p) * h->frac, c, sn);
             a.step[p] = make_float2(static_cast<float>(c), static_cast<float>(sn));
         }
-        if (h->real_taps)
-            comms::pulse_poly_kernel<SPS, true, true><<<dim3(blocks), dim3(256), 0, s>>>(a);
-        else
-            comms::pulse_poly_kernel<SPS, false, true><<<dim3(blocks), dim3(256), 0, s>>>(a);
-    } else if (h->real_taps) {
-        comms::pulse_poly_kernel<SPS, true, false><<<dim3(blocks), dim3(256), 0, s>>>(a);
-    } else {
-        comms::pulse_poly_kernel<SPS, false, false><<<dim3(blocks), dim3(256), 0, s>>>(a);
     }
+    // with a kernel timer attached: the kernel's own begin / end timestamps (events recorded around a launch of config 1's
+    // size -- 5 us -- would mostly time the dispatch gap)
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (h->timed()) h->next_events(ea, eb);
+#define COMMS_PULSE_GO(REAL, MIX)                                                                                            \
+    do {                                                                                                                     \
+        if (ea)                                                                                                              \
+            hipExtLaunchKernelGGL((comms::pulse_poly_kernel<SPS, REAL, MIX>), dim3(blocks), dim3(256), 0u, s, ea, eb, 0u, a); \
+        else                                                                                                                 \
+            comms::pulse_poly_kernel<SPS, REAL, MIX><<<dim3(blocks), dim3(256), 0, s>>>(a);                                  \
+    } while (0)
+    if (h->mix) {
+        if (h->real_taps) COMMS_PULSE_GO(true, true); else COMMS_PULSE_GO(false, true);
+    } else {
+        if (h->real_taps) COMMS_PULSE_GO(true, false); else COMMS_PULSE_GO(false, false);
+    }
+#undef COMMS_PULSE_GO
     return true;
 }
 static bool pulse_poly_launch(comms_pulse* h, const float2* sym, size_t n_sym, float2* out, hipStream_t s) {
@@ -2148,8 +2157,8 @@ comms_status_t comms_pulse_run_dev(comms_pulse_t* h, const comms_c32* d_sym, siz
     hipStream_t s = nullptr;
     COMMS_TRY(h->enter(stream, &s));
     const float2* sym = reinterpret_cast<const float2*>(d_sym);
-    h->tic(s);
     if (!pulse_poly_launch(h, sym, n_sym, reinterpret_cast<float2*>(d_out), s)) {
+        h->tic(s);
         size_t blocks = (n_out + 255) / 256;
         if (blocks > 8u * kNumCU) blocks = 8u * kNumCU;
         PulseMix mx{};
@@ -2164,8 +2173,8 @@ comms_status_t comms_pulse_run_dev(comms_pulse_t* h, const comms_c32* d_sym, siz
         pulse_kernel<<<dim3(static_cast<unsigned>(blocks)), dim3(256), h->n_taps * sizeof(float2), s>>>(
             sym, h->d_hist[h->cur], h->hist_len, h->d_taps, h->n_taps, h->sps,
             reinterpret_cast<float2*>(d_out), n_sym, h->d_hist[h->cur ^ 1], mx);
+        h->toc(s);
     }
-    h->toc(s);
     COMMS_TRY(launch_ok("pulse kernel"));  // (workgroup 0 of the same launch advanced the history)
     h->cur ^= 1;
     if (h->mix) h->turns += static_cast<uint64_t>(n_out) * h->frac;

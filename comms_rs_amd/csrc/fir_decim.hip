@@ -18,6 +18,8 @@
 // i.e. scalar loads into SGPR pairs that the packed FMA reads directly (op_sel picks the
 // half): no tap ever occupies a VGPR or an LDS slot.  Four workgroups per CU (37 KiB of LDS
 // each at R = 8) cover each other's load / compute / store phases.
+#include <hip/hip_ext.h>
+
 #include <cmath>
 #include <vector>
 
@@ -421,6 +423,11 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
 #undef DC_STAMP
 }
 
+// Event pair of an attached kernel timer for the launch about to be made (set by comms_fir_run_decim_dev, taken by
+// launch_decim_v): the kernel's own begin / end timestamps, as the FIR kernels' timed launches -- events recorded
+// around the launch would include the dispatch gap in front of it whenever the launch before it carried no events.
+static thread_local hipEvent_t g_decim_ev_start = nullptr, g_decim_ev_stop = nullptr;
+
 template <int R, int OPL, bool REAL, bool PRE, int TILE = DC_TILE, int CHX = 0>
 static comms_status_t launch_decim_v(const DecimArgs& a, hipStream_t s) {
     using G = DcGeom<R, OPL, TILE>;
@@ -432,15 +439,18 @@ static comms_status_t launch_decim_v(const DecimArgs& a, hipStream_t s) {
     if (attr_once.need())
         COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_decim_kernel<R, OPL, REAL, PRE, TILE, CHX>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    DecimArgs b = a;
     if (a.interleave) {
         // a workgroup's next tile is `blocks` tiles on: the per-step rotor of its tile-wide phase follows the grid
-        DecimArgs b = a;
         const uint64_t ts = static_cast<uint64_t>(TILE) - ((a.mode & COMMS_CHAIN_FM) ? 1 : 0);
         mix_host_rotor(static_cast<uint64_t>(R) * ts * blocks * a.frac, b.tile_c, b.tile_s);
-        fir_decim_kernel<R, OPL, REAL, PRE, TILE, CHX><<<dim3(blocks), dim3(G::WG), lds, s>>>(b);
-    } else {
-        fir_decim_kernel<R, OPL, REAL, PRE, TILE, CHX><<<dim3(blocks), dim3(G::WG), lds, s>>>(a);
     }
+    hipEvent_t ea = g_decim_ev_start, eb = g_decim_ev_stop;
+    g_decim_ev_start = g_decim_ev_stop = nullptr;
+    if (ea)
+        hipExtLaunchKernelGGL((fir_decim_kernel<R, OPL, REAL, PRE, TILE, CHX>), dim3(blocks), dim3(G::WG), static_cast<uint32_t>(lds), s, ea, eb, 0u, b);
+    else
+        fir_decim_kernel<R, OPL, REAL, PRE, TILE, CHX><<<dim3(blocks), dim3(G::WG), lds, s>>>(b);
     return launch_ok("fir_decim_kernel");
 }
 
@@ -637,7 +647,7 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
         a.are[m] = in_range ? h->taps[k].re : 0.f;
         a.aim[m] = in_range ? h->taps[k].im : 0.f;
     }
-    h->tic(s);
+    if (h->timed()) h->next_events(g_decim_ev_start, g_decim_ev_stop);
     comms_status_t st;
     switch (R) {
         case 2: st = launch_decim<2>(a, real, opl, tile, s); break;
@@ -655,9 +665,8 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
         case 14: st = launch_decim<14>(a, real, 2, tile, s); break;
         case 15: st = launch_decim_real<15>(a, s); break;
         case 16: st = launch_decim<16>(a, real, 2, tile, s); break;
-        default: return fail(COMMS_ERR_ARG, "no decimating kernel for rate %d", R);
+        default: g_decim_ev_start = g_decim_ev_stop = nullptr; return fail(COMMS_ERR_ARG, "no decimating kernel for rate %d", R);
     }
-    h->toc(s);
     COMMS_TRY(st);
     h->cur ^= 1;
     return COMMS_OK;

@@ -680,6 +680,13 @@ class KernelTimer:
         self._node, self._setter = node, name
         return self
 
+    def enable(self, on):
+        """Detach from / re-attach to the node without touching what was recorded (to bracket only some launches)."""
+        on = bool(on)
+        if on != getattr(self, "_on", True):
+            check(getattr(lib(), self._setter)(self._node._h, self._h if on else None))
+            self._on = on
+
     def reset(self):
         check(lib().comms_timer_reset(self._h))
 
