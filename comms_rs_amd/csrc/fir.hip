@@ -1086,7 +1086,7 @@ struct PulseArgs {
 template <int SPS, bool REAL, bool MIX>
 __global__ __launch_bounds__(256) void pulse_poly_kernel(const PulseArgs a) {
     constexpr int SPSP = SPS + (SPS & 1);
-    constexpr bool XS = true;  // outputs leave through a per-wave LDS block, CW phases at a time (CW * 2 KiB per workgroup)
+    // outputs leave through a per-wave LDS block, CW phases at a time (CW * 2 KiB per workgroup)
     constexpr int CW = SPS <= 8 ? SPS : SPS % 8 == 0 ? 8 : SPS % 6 == 0 ? 6 : SPS % 5 == 0 ? 5 : SPS % 4 == 0 ? 4 : SPS % 3 == 0 ? 3 : SPS % 2 == 0 ? 2 : 1;
     __shared__ cf sh[256 + PP_JMAX];
     __shared__ __attribute__((aligned(16))) cf xch[256 * CW];
@@ -1134,7 +1134,6 @@ __global__ __launch_bounds__(256) void pulse_poly_kernel(const PulseArgs a) {
                     mac_tap<REAL>(acc[p], sv[jj], tr[e >> 1], ti[e >> 1], (e & 1) != 0);
                 }
         }
-        const size_t m = static_cast<size_t>(m0) + tid;
         if (MIX) {
             const cf r0 = cf{static_cast<float>(rc), static_cast<float>(rs)};
 #pragma unroll
@@ -1143,7 +1142,7 @@ __global__ __launch_bounds__(256) void pulse_poly_kernel(const PulseArgs a) {
             rs = rc * a.mx.sweep_s + rs * a.mx.sweep_c;
             rc = nc;
         }
-        if constexpr (XS) {
+        {
             // A lane's SPS outputs are one run of SPS * 8 B, so a plain store instruction covers a wave's 64 SPS outputs in
             // pieces of 16 B at a stride of SPS * 8 B.  Through the wave's own LDS block instead, CW <= 8 phases at a time:
             // instruction i writes elements 64 i ... 64 i + 63 of the block [64 symbols][CW], i.e. whole lines for SPS <= 8
@@ -1203,16 +1202,6 @@ __global__ __launch_bounds__(256) void pulse_poly_kernel(const PulseArgs a) {
                         }
                     }
                 }
-            }
-        } else if (m < a.n_sym) {
-            if (a.mx.out_i16) {  // the transmit chain straight into the IQOutput wire format: 4 B per output
-                short2* o = reinterpret_cast<short2*>(a.out) + m * SPS;
-#pragma unroll
-                for (int p = 0; p < SPS; ++p) o[p] = c32_as_i16(to_f2(acc[p]), a.mx.out_scale);
-            } else {
-                float2* o = a.out + m * SPS;
-#pragma unroll
-                for (int p = 0; p < SPS; ++p) o[p] = to_f2(acc[p]);
             }
         }
     }
