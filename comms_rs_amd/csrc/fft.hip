@@ -1758,15 +1758,19 @@ comms_status_t comms_fft_run_dev(comms_fft_t* h, const comms_c32* d_in, size_t n
         if (h->N <= 128) {
             const size_t groups = (batch + 256 / h->N - 1) / (256 / h->N);
             const unsigned gb = static_cast<unsigned>(groups < 8u * kNumCU ? groups : 8u * kNumCU);
+            h->tic(s);
             dft_small_kernel<<<dim3(gb), dim3(256), 0, s>>>(reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(o),
                                                             static_cast<int>(h->N), batch,
                                                             reinterpret_cast<const cf*>(h->d_twN), h->inverse ? 1 : 0);
+            h->toc(s);
             return launch_ok("dft_small_kernel");
         }
         unsigned blocks = static_cast<unsigned>(batch < 4u * kNumCU ? batch : 4u * kNumCU);
+        h->tic(s);
         dft_direct_kernel<<<dim3(blocks), dim3(256), 2 * h->N * sizeof(float2), s>>>(
             reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(o), static_cast<int>(h->N), batch,
             reinterpret_cast<const cf*>(h->d_twN), h->inverse ? 1 : 0);
+        h->toc(s);
         return launch_ok("dft_direct_kernel");
     }
     // Bluestein, in chunks that bound the work buffer
@@ -1785,6 +1789,13 @@ comms_status_t comms_fft_run_dev(comms_fft_t* h, const comms_c32* d_in, size_t n
     const bool fuse = h->plan.rx_rad != 0 && !no_fuse;  // padded length on the single-pass kernel (M <= 16384)
     unsigned logM = 0;
     while ((static_cast<size_t>(1) << logM) < M) ++logM;
+    // (a timer brackets all the launches of the call, as on the power-of-two paths; the pair is closed on every exit)
+    struct Bracket {
+        comms_fft* h;
+        hipStream_t s;
+        Bracket(comms_fft* hh, hipStream_t ss) : h(hh), s(ss) { h->tic(s); }
+        ~Bracket() { h->toc(s); }
+    } bracket(h, s);
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = batch - b0 < chunk ? batch - b0 : chunk;
         if (fuse) {
