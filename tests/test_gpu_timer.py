@@ -32,14 +32,14 @@ def _cases(c):
     x, y, s = _buffers(n)
     c.synth_iq_dev(x.data_ptr(), n, 0, 9)
     f, _, _ = _buffers(n, real_out=True)
+    big = 1 << 23  # enough segments for the ticketed kernel
+    xb, yb, _ = _buffers(big)
+    c.synth_iq_dev(xb.data_ptr(), big, 0, 9)
     out = []
     for name, algo, taps in (("direct", c.FIR_DIRECT, 32), ("os1024 fixed runs", c.FIR_OS1024, 255), ("os4096", c.FIR_OS4096, 511),
                              ("os16k", c.FIR_OS16K, 2100)):
         node = c.BatchFirNode(_lp(taps)).set_algo(algo)
         out.append(("fir " + name, node, lambda node=node: node.run_dev(x.data_ptr(), n, y.data_ptr(), s)))
-    big = 1 << 23  # enough segments for the ticketed kernel
-    xb, yb, _ = _buffers(big)
-    c.synth_iq_dev(xb.data_ptr(), big, 0, 9)
     dyn = c.BatchFirNode(_lp(255))
     assert dyn.kernel_for(big) == "fir_os1024_dyn_kernel"
     out.append(("fir os1024 ticketed", dyn, lambda: dyn.run_dev(xb.data_ptr(), big, yb.data_ptr(), s)))
@@ -49,8 +49,9 @@ def _cases(c):
     out.append(("fm demod", fm, lambda: fm.run_dev(x.data_ptr(), n, f.data_ptr(), s)))
     for N in (1024, 1 << 16, 1 << 21, 1000, 10):  # one pass, four-step, gathered columns, Bluestein, direct DFT
         ft = c.FFTBatchNode(N, False)
-        m = (n // N) * N
-        out.append(("fft %d" % N, ft, lambda ft=ft, m=m: ft.run_dev(x.data_ptr(), m, y.data_ptr(), s)))
+        src, dst, tot = (x, y, n) if N <= n else (xb, yb, big)
+        m = (tot // N) * N
+        out.append(("fft %d" % N, ft, lambda ft=ft, m=m, src=src, dst=dst: ft.run_dev(src.data_ptr(), m, dst.data_ptr(), s)))
     for ask, kern, rate, taps in (("time", "time", 8, 127), ("time", "time_any", 20, 127), ("freq", "freq", 8, 127)):
         ch = c.ChainNode(0.2, 0.0, _lp(taps), rate, True, kernel=ask)
         assert ch.kernel == kern
