@@ -57,11 +57,16 @@ def _cases(c):
         assert ch.kernel == kern
         m = (n // rate) * rate
         out.append(("chain " + kern, ch, lambda ch=ch, m=m: ch.run_dev(x.data_ptr(), m, f.data_ptr(), s)))
+    cu = c.ChainNode(0.2, 0.0, _lp(127), 8, True, unfused=True)       # the four kernels in series: the FIR stage is timed
+    out.append(("chain unfused", cu, lambda: cu.run_dev(x.data_ptr(), n, f.data_ptr(), s)))
+    cl = c.ChainNode(0.2, 0.0, _lp(511), 16, False)                   # beyond 257 taps: FIR launch + mixer/decimator pass
+    yl, _, _ = _buffers(n // 16)
+    out.append(("chain 511 taps", cl, lambda: cl.run_dev(x.data_ptr(), n, yl.data_ptr(), s)))
     pp = c.PulseNode(_lp(63), 4).set_mixer(0.3, 0.0)
     out.append(("pulse polyphase", pp, lambda: pp.run_dev(x.data_ptr(), n // 4, y.data_ptr(), s)))
     pg = c.PulseNode(_lp(63), 7)
     out.append(("pulse generic", pg, lambda: pg.run_dev(x.data_ptr(), n // 8, y.data_ptr(), s)))
-    return out, (x, y, f, xb, yb)
+    return out, (x, y, f, xb, yb, yl)
 
 
 def test_timer_brackets_the_dominant_kernel_of_every_node_kind(c):
