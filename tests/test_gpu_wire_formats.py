@@ -97,6 +97,34 @@ def test_fm_radio_chain_from_raw_iq(c, variant, fmt):
     assert np.max((circ(got.astype(np.float64) - want) * mag)[16:]) <= 4e-5 * np.sum(np.abs(taps))
 
 
+@pytest.mark.parametrize("fmt", ["i16", "u8"])
+@pytest.mark.parametrize("rate,n_taps,kernel", [(7, 63, "time"), (14, 127, "time"), (20, 127, "time_any"), (33, 255, "time_any"),
+                                                 (100, 63, "time_any"), (1000, 255, "time_any")])
+def test_chains_at_the_rates_of_round_3_from_raw_iq(c, rate, n_taps, kernel, fmt):
+    """Raw i16 / u8 samples into the chain kernels added in round 3 -- the per-rate kernel at 7 and 14, the any-rate kernel in
+    its LDS-staged (20, 33) and direct (100, 1000) forms -- with the mixer in front of the FIR and FM demod behind the
+    decimator: bit for bit what the same chain makes of the converted samples (the conversion sits in the load stage),
+    in ragged calls; and the oracle's convert -> mix -> batch_fir -> decimate -> FM::demod."""
+    rng = np.random.default_rng(rate + n_taps)
+    n = rate * 2600
+    k = np.arange(n_taps) - (n_taps - 1) / 2
+    taps = (np.sinc(k / (1.2 * rate)) / (1.2 * rate) * np.hamming(n_taps)).astype(np.float32).astype(np.complex64)
+    raw, x = raw_stream(rng, n, fmt)
+    dphase, phase = 0.05, 0.3
+    a = c.ChainNode(dphase, phase, taps, rate, True, kernel="time").set_input_format(fmt, 1.0 / 8192)
+    b = c.ChainNode(dphase, phase, taps, rate, True, kernel="time")
+    assert a.kernel == kernel and b.kernel == kernel
+    cuts = [0, rate * 1, rate * 700, rate * 701, n]
+    got = np.concatenate([a.run(raw[p:q]) for p, q in zip(cuts[:-1], cuts[1:])])
+    ref = np.concatenate([b.run(x[p:q]) for p, q in zip(cuts[:-1], cuts[1:])])
+    assert np.array_equal(got, ref)
+    y = oracle.decimate(oracle.batch_fir(oracle.Mixer(phase, dphase).mix(x), taps, oracle.default_state(taps), norotate=True), rate)
+    want = oracle.FM().demod(y)
+    mag = np.minimum(np.abs(y), np.abs(np.concatenate([[0.0], y[:-1]])))
+    skip = n_taps // rate + 2
+    assert np.max((circ(got.astype(np.float64) - want) * mag)[skip:]) <= 4e-5 * np.sum(np.abs(taps))
+
+
 def test_metric_chain_from_i16_full_size(c):
     """The BASELINE metric's chain (255-tap FIR -> mixer -> decimate by 8) on 2^24 i16 samples resident in HBM
     (64 MiB instead of 128): fused load-convert vs. conversion kernel + chain, bit for bit."""
