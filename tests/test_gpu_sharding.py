@@ -48,10 +48,11 @@ def fm_close(got, want, y_dec, taps, lo=0):
 
 
 # ------------------------------------------------------------------ shards through the product nodes
+@pytest.mark.parametrize("rate", [8, 20, 100])   # per-rate kernel; any-rate kernel, LDS-staged and direct (variant "time")
 @pytest.mark.parametrize("fm", [False, True])
 @pytest.mark.parametrize("after", [False, True])
 @pytest.mark.parametrize("variant", ["time", "freq", "unfused"])
-def test_chain_shards_primed_by_prefix_continue_the_stream(c, variant, after, fm):
+def test_chain_shards_primed_by_prefix_continue_the_stream(c, variant, after, fm, rate):
     """Four contiguous shards of one stream, each on its own chain node: rank r > 0 primes its node
     with the chain_prefix_len raw samples before its shard (sharding.prime_chain: FIR history,
     oscillator phase AND FM.prev in one go).  The concatenated outputs equal the reference nodes in
@@ -59,10 +60,10 @@ def test_chain_shards_primed_by_prefix_continue_the_stream(c, variant, after, fm
     import torch
     from comms_rs_amd.sharding import chain_prefix_len, prime_chain, shard_mixer_phase, shard_range
 
-    rate, n_taps, world = 8, 127, 4
-    total = rate * 4096 * world
+    n_taps, world = 127, 4
+    total = rate * (4096 if rate == 8 else 1024) * world
     x = fm_stream(total) if fm else rand_c(np.random.default_rng(11), total)
-    taps = lowpass_taps(n_taps, 1 / 16)
+    taps = lowpass_taps(n_taps, 1 / (2 * rate))
     dphase, phase0 = 2 * np.pi * 0.05, 0.3
     want, y_dec = oracle_chain(x, taps, dphase, phase0, rate, fm, after)
     W = chain_prefix_len(n_taps, rate, fm)
@@ -126,15 +127,16 @@ def test_node_by_node_shards_with_fm_prev_setter(c):
 
 
 # ------------------------------------------------------------------ checkpoint hooks
+@pytest.mark.parametrize("rate", [8, 20, 100])
 @pytest.mark.parametrize("fm", [False, True])
 @pytest.mark.parametrize("variant", ["time", "freq", "unfused"])
-def test_chain_checkpoint_and_restore(c, variant, fm):
+def test_chain_checkpoint_and_restore(c, variant, fm, rate):
     """Run half a stream, read the chain's whole cross-call state (FIR history, oscillator phase,
     FM.prev), put it into a brand-new chain and run the second half: same as one chain run in two calls."""
-    rate, n_taps = 8, 127
-    n, cut = rate * 9000, rate * 4000
+    n_taps = 127
+    n, cut = rate * 2500, rate * 1100
     x = fm_stream(n)
-    taps = lowpass_taps(n_taps, 1 / 16)
+    taps = lowpass_taps(n_taps, 1 / (2 * rate))
     dphase, phase0 = 2 * np.pi * 0.05, 1.25
     kw = dict(unfused=variant == "unfused", kernel="auto" if variant == "unfused" else variant)
     one = c.ChainNode(dphase, phase0, taps, rate, fm, **kw)
