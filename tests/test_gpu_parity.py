@@ -941,7 +941,7 @@ def test_fft_four_step_column_pass(c, logn, inverse):
     fft_close(c.FFTBatchNode(n, inverse).run(x), f(x.astype(np.complex128).reshape(batch, n)).reshape(-1))
 
 
-@pytest.mark.parametrize("logn,batch", [(21, 3), (22, 2), (23, 1), (24, 2)])
+@pytest.mark.parametrize("logn,batch", [(21, 1), (21, 3), (21, 5), (22, 2), (22, 3), (23, 1), (24, 2)])  # (tile counts below, at and off multiples of the 256-workgroup grid)
 @pytest.mark.parametrize("inverse", [False, True])
 def test_fft_above_2p20_columns_rows_transpose(c, logn, batch, inverse):
     """N = 2^21 ... 2^24 (fft_node.rs:65-74 accepts any size).  2^21 ... 2^23 take two passes: N / 1024-point columns
