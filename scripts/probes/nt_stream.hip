@@ -19,6 +19,20 @@ __global__ __launch_bounds__(256) void copy16(const f4* __restrict__ in, f4* __r
         if (NTS) __builtin_nontemporal_store(v, out + i); else out[i] = v;
     }
 }
+// U loads in flight per lane (the product mixer has one)
+template <int U>
+__global__ __launch_bounds__(256) void copy16u(const f4* __restrict__ in, f4* __restrict__ out, size_t n4) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = in[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { v[u].x += 1.0f; out[i + u * stride] = v[u]; }
+    }
+    for (; i < n4; i += stride) { f4 v = in[i]; v.x += 1.0f; out[i] = v; }
+}
 template <int NTL, int NTS>
 __global__ __launch_bounds__(256) void dec8(const f2* __restrict__ in, f2* __restrict__ out, size_t n_out) {
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
@@ -53,6 +67,11 @@ int main() {
                timeit([&] { copy16<1, 0><<<blocks, 256>>>((const f4*)in, (f4*)out, n4); }),
                timeit([&] { copy16<0, 1><<<blocks, 256>>>((const f4*)in, (f4*)out, n4); }),
                timeit([&] { copy16<1, 1><<<blocks, 256>>>((const f4*)in, (f4*)out, n4); }));
+        printf("2^%d samples  copy16, loads in flight per lane: 1 %.1f  2 %.1f  4 %.1f us;  16 workgroups per CU, 2 in flight %.1f us\n", lg,
+               timeit([&] { copy16u<1><<<blocks, 256>>>((const f4*)in, (f4*)out, n4); }),
+               timeit([&] { copy16u<2><<<blocks, 256>>>((const f4*)in, (f4*)out, n4); }),
+               timeit([&] { copy16u<4><<<blocks, 256>>>((const f4*)in, (f4*)out, n4); }),
+               timeit([&] { copy16u<2><<<2 * blocks, 256>>>((const f4*)in, (f4*)out, n4); }));
         printf("2^%d samples  dec8:   plain %.1f  nt-load %.1f  nt-store %.1f  both %.1f us\n", lg,
                timeit([&] { dec8<0, 0><<<blocks, 256>>>((const f2*)in, (f2*)out, no); }),
                timeit([&] { dec8<1, 0><<<blocks, 256>>>((const f2*)in, (f2*)out, no); }),
