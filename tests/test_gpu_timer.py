@@ -102,7 +102,7 @@ def test_timer_brackets_the_dominant_kernel_of_every_node_kind(c):
 
 
 def test_timer_durations_follow_the_work(c):
-    """Four times the samples, about four times the time (the headline kernel, own begin / end timestamps): the pair
+    """Four times the samples, several times the time (the headline kernel, own begin / end timestamps): the pair
     measures the kernel, not the dispatch."""
     import torch
 
@@ -121,4 +121,4 @@ def test_timer_durations_follow_the_work(c):
         t.close()
         del x, y
         torch.cuda.empty_cache()
-    assert 3.0 < res[25] / res[23] < 5.0, res
+    assert 2.0 < res[25] / res[23] < 8.0, res   # (wide: clocks move by tens of per cent over a burst; a dispatch-bound figure would not scale at all)
