@@ -20,8 +20,10 @@ for name, node in nodes.items():
         xs = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
         for _ in range(20):
             node.run(xs)
-        t = time.perf_counter()
-        for _ in range(100):
+        ts = []
+        for _ in range(100):  # per call, and the median: a 100-call span caught a 50-70 ms interpreter pause at one size every run
+            t = time.perf_counter()
             node.run(xs)
-        line.append("%d: %.1f us" % (n, (time.perf_counter() - t) / 100 * 1e6))
+            ts.append(time.perf_counter() - t)
+        line.append("%d: %.1f us" % (n, float(np.median(ts)) * 1e6))
     print("%-30s %s" % (name, "   ".join(line)), flush=True)
