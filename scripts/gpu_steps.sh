@@ -3,6 +3,7 @@
 # output under gpurun_out/<tag>/<name>.{out,err}.  An ordinary failure (a red test, an assertion) is
 # recorded and the next step still runs; a step that timed out or was killed ends the visit at once
 # (no further GPU work after a hang).  Steps file: one per line, "name|timeout_seconds|command".
+# Every step runs under `bash -o pipefail`: a red `pytest ... | tail` step is recorded red.
 # Usage: bash scripts/gpu_steps.sh <tag> <steps-file>
 set -o pipefail
 TAG=$1
@@ -17,7 +18,7 @@ while IFS='|' read -r name tmo cmd; do
   case "$name" in \#*) continue;; esac
   echo "== $name: $cmd" | tee -a $OUT/summary.txt
   t0=$(date +%s)
-  timeout -k 10 "$tmo" bash -c "$cmd" > $OUT/$name.out 2> $OUT/$name.err < /dev/null
+  timeout -k 10 "$tmo" bash -o pipefail -c "$cmd" > $OUT/$name.out 2> $OUT/$name.err < /dev/null
   rc=$?
   echo "   rc=$rc  $(( $(date +%s) - t0 )) s" | tee -a $OUT/summary.txt
   tail -n 6 $OUT/$name.out | cut -c1-600 | tee -a $OUT/summary.txt

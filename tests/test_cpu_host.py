@@ -251,6 +251,56 @@ def test_rust_shim_declares_every_header_symbol():
         "comms_rs_amd/rust_shim/src/ffi.rs is stale: run scripts/gen_rust_ffi.py"
 
 
+# Constructors of the reference nodes on the hot path: struct, type-parameter bound as the shim
+# narrows it, arguments of `new`, and the reference's declaration (file:line in the reference checkout).
+RUST_NODE_CONTRACT = [
+    ("FirNode", "FirSample", ["taps: Vec<Complex<T>>", "state: Option<Vec<Complex<T>>>"], "src/filter/fir_node.rs:45,89"),
+    ("BatchFirNode", "FirSample", ["taps: Vec<Complex<T>>", "state: Option<Vec<Complex<T>>>"], "src/filter/fir_node.rs:148,193"),
+    ("FFTBatchNode", "FloatSample", ["fft_size: usize", "ifft: bool"], "src/fft/fft_node.rs:28,65"),
+    ("FFTSampleNode", "FloatSample", ["fft_size: usize", "ifft: bool"], "src/fft/fft_node.rs:104,142"),
+    ("MixerNode", "MixerSample", ["dphase: f64", "phase: Option<f64>"], "src/mixer.rs:93,128"),
+    ("PulseNode", "FirSample", ["taps: Vec<Complex<T>>", "sam_per_sym: usize"], "src/pulse.rs:38,71"),
+    ("DecimateNode", "Copy + Send", ["dec_rate: usize"], "src/util/resample_node.rs:10,23"),
+    ("UpsampleNode", "Copy + Send + Zero", ["ups_rate: usize"], "src/util/resample_node.rs:74,87"),
+    ("FMDemodNode", "FloatSample", [], "src/modulation/analog_node.rs:20,43"),
+]
+
+
+def test_rust_shim_keeps_the_reference_constructors():
+    """Every reference node of the hot path has a same-named generic struct in the shim with public `input` /
+    `output` fields and a `pub fn new` of the reference's arity and argument types, so that a graph switches by
+    its `use` lines (examples/fm_radio.rs:146-153 declares `BatchFirNode<f32>`, `DecimateNode<Complex<f32>>` and
+    `DecimateNode<f32>`).  Text check only: there is no rustc here."""
+    import re
+
+    src = open(os.path.join(ROOT, "comms_rs_amd", "rust_shim", "src", "lib.rs")).read()
+    for name, bound, args, where in RUST_NODE_CONTRACT:
+        m = re.search(r"pub struct %s<T>\s*where\s*T: ([^,{]+),\s*\{(.*?)\n\}" % name, src, flags=re.S)
+        assert m, "%s<T> (%s) is not declared as a generic struct" % (name, where)
+        assert m.group(1).strip() == bound, (name, m.group(1))
+        body = m.group(2)
+        assert re.search(r"pub input: NodeReceiver<", body) and re.search(r"pub output: NodeSender<", body), name
+        im = re.search(r"impl<T> %s<T>\s*where\s*T: [^{]+\{(.*?)\n\}" % name, src, flags=re.S)
+        assert im, "no `impl<T> %s<T>`" % name
+        nm = re.search(r"pub fn new\(([^)]*)\) -> Self", im.group(1))
+        assert nm, "%s::new is missing" % name
+        got = [a.strip() for a in nm.group(1).split(",") if a.strip()]
+        assert got == args, (name, got, args, where)
+        assert re.search(r"pub fn run\(&mut self", im.group(1)), "%s::run is missing" % name
+    # the aggregate node keeps its attribute (node_derive/src/lib.rs:139-151) and the per-sample message type
+    assert re.search(r"#\[derive\(Node\)\]\s*#\[aggregate\]\s*#\[pass_by_ref\]\s*pub struct FFTSampleNode<T>", src)
+    assert "-> Result<Option<Vec<Complex<T>>>, NodeError>" in src
+    # the sealed sample traits are implemented for what the C ABI has
+    for t, tys in (("FirSample", ("f32", "i16")), ("MixerSample", ("f32", "f64")), ("FloatSample", ("f32",))):
+        for ty in tys:
+            assert "impl %s for %s" % (t, ty) in src, (t, ty)
+    # every extern function the shim calls is declared in the generated ffi.rs
+    ffi = open(os.path.join(ROOT, "comms_rs_amd", "rust_shim", "src", "ffi.rs")).read()
+    declared = set(re.findall(r"pub fn (comms_[a-z0-9_]+)\(", ffi))
+    used = set(re.findall(r"\b(comms_[a-z0-9_]+)\(", src))
+    assert used <= declared, sorted(used - declared)
+
+
 def test_library_exports_exactly_the_header():
     """The product .so exports every comms_* symbol of include/comms_hip.h and nothing else: probes,
     stamps and kernel selectors live in the diagnostic build only (`make -C comms_rs_amd/csrc diag`)."""
