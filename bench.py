@@ -62,6 +62,28 @@ FFT_N, FFT_BATCH = 1 << 20, 4096
 FFT_BYTES_PER_POINT = 16.0   # one read + one write per point
 
 
+def box_info(torch, local_rank):
+    """Which machine and GPU produced the line (best effort): HBM-resident rates differ by box."""
+    import glob
+    import socket
+
+    info = {"host": socket.gethostname()}
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        info.update(gpu=pr.name, cus=pr.multi_processor_count, hbm_GiB=round(pr.total_memory / 2 ** 30, 1))
+    except Exception:
+        pass
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+    if local_rank < len(cards):
+        for key in ("unique_id", "current_memory_partition", "current_compute_partition"):
+            try:
+                with open(os.path.join(cards[local_rank], key)) as f:
+                    info[key] = f.read().strip()
+            except Exception:
+                pass
+    return info
+
+
 def pmc_traffic(kernel, n):
     """HBM bytes per FIR launch from the committed rocprofv3 PMC passes (profiles/), or None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -76,6 +98,20 @@ def pmc_traffic(kernel, n):
     except Exception:
         pass
     return None
+
+
+def fm_radio_taps():
+    """The 63 taps of examples/fm_radio.rs:30-52 (a fixture: data the reference holds)."""
+    with open(os.path.join(ROOT, "tests", "golden", "reference_kats.json")) as f:
+        g = json.load(f)["fm_radio_taps"]
+    return np.asarray(g["taps_re"], np.float32).astype(np.complex64)
+
+
+def synth_u8(n, first=0):
+    """RTL-SDR-shaped input for the literal fm_radio chain: an FM tone on a carrier offset, quantised to u8 pairs."""
+    idx = np.arange(first, first + n, dtype=np.float64)
+    ph = -2 * np.pi * 0.05 * idx + 8.0 * np.cos(2 * np.pi * idx / 4096)
+    return np.clip(np.round(np.stack([np.cos(ph), np.sin(ph)], axis=1) * 100.0 + 127.5), 0, 255).astype(np.uint8)
 
 
 def lowpass_taps(n_taps, cutoff):
@@ -180,6 +216,48 @@ def _best_of(fn, reps=2):
     return best
 
 
+def _pipeline_s(stages, batches):
+    """one thread per node joined by unbounded queues, as start_nodes! runs the reference graph
+    (src/node/mod.rs:276-284); `stages` are the nodes' run functions (stateful closures), `batches` the source's
+    messages.  Returns the wall time from start to the last message leaving the last node."""
+    import queue
+    import threading
+
+    qs = [queue.Queue() for _ in stages]
+
+    def node(i):
+        while (v := qs[i].get()) is not None:
+            r = stages[i](v)
+            if i + 1 < len(stages):
+                qs[i + 1].put(r)
+        if i + 1 < len(stages):
+            qs[i + 1].put(None)
+
+    th = [threading.Thread(target=node, args=(i,)) for i in range(len(stages))]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for b in batches:
+        qs[0].put(b)
+    qs[0].put(None)
+    for t in th:
+        t.join()
+    return time.perf_counter() - t0
+
+
+def _all_cores_s(run_chunk, cap=64):
+    """the work cut into independent chunks over the host's cores (each chunk starts from fresh node
+    state: an upper bound for a CPU graph of such nodes).  run_chunk(i, threads) does chunk i of `threads`."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    threads = max(1, min(os.cpu_count() or 1, cap))
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(lambda i: run_chunk(i, threads), range(threads)))  # warm-up: threads, first-touch pages
+        t0 = time.perf_counter()
+        list(ex.map(lambda i: run_chunk(i, threads), range(threads)))
+        return time.perf_counter() - t0, threads
+
+
 def cpu_baseline_c1():
     """BASELINE config 1 IS the reference's CPU path (examples/single_thread_bpsk.rs:15-52 made deterministic,
     SURVEY 8d): PRBS7 -> BPSK -> PulseNode(rrc_taps(63, 4, 0.25), 4) -> Mixer, 2^18 symbols = 2^20 samples, run in
@@ -203,7 +281,19 @@ def cpu_baseline_c1():
             oracle.iq_c32_to_i16(oracle.batch_fir(oracle.upsample(sym[i:i + 4096], 4), taps32, st), 8192.0)
 
     dl = _best_of(literal)
+    # (ii) PulseNode and MixerNode on their own threads, symbol blocks of 2^14 as messages; (iii) all cores
+    pst, pmx = oracle.default_state(taps), oracle.Mixer(0.0, MIX_DPHASE)
+    blk = 1 << 14
+    dp = _pipeline_s([lambda v: oracle.pulse(v, taps, 4, pst), lambda v: pmx.mix(v)], [sym[i:i + blk] for i in range(0, nsym, blk)])
+
+    def chunk(i, threads):
+        m = nsym // threads
+        oracle.Mixer(0.0, MIX_DPHASE).mix(oracle.pulse(sym[i * m:(i + 1) * m], taps, 4, oracle.default_state(taps)))
+
+    da, threads = _all_cores_s(chunk)
     return {"value": round(4 * nsym / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "thread_per_node": {"value": round(4 * nsym / dp / 1e6, 3), "unit": "Msamples/s", "cores": 2},
+            "all_cores": {"value": round(4 * (nsym // threads) * threads / da / 1e6, 2), "unit": "Msamples/s", "cores": threads},
             "sample": "the whole config: 2^18 PRBS7 symbols -> BPSK -> oracle PulseNode (63-tap RRC, 4 samples per "
                       "symbol: fir() per output sample, rotate_right each) -> Mixer::mix (f64), 2^20 output samples, "
                       "best of 2, 1 thread of %d host cores" % (os.cpu_count() or 0),
@@ -227,7 +317,36 @@ def cpu_baseline_c3():
         oracle.FM().demod(oracle.decimate(y, C3_RATE))
 
     dt = _best_of(chain)
+    # (ii) the four nodes on their own threads (messages of 2^18 samples: the radio block of examples/fm_radio.rs:144)
+    mx, st, fm = oracle.Mixer(0.0, C3_DPHASE), oracle.default_state(taps), oracle.FM()
+    blk = 1 << 18
+    dp = _pipeline_s([lambda v: mx.mix(v), lambda v: oracle.batch_fir(v, taps, st), lambda v: oracle.decimate(v, C3_RATE),
+                      lambda v: fm.demod(v)], [x[i:i + blk] for i in range(0, n, blk)])
+
+    def chunk(i, threads):
+        m = n // threads // C3_RATE * C3_RATE
+        y = oracle.batch_fir(oracle.Mixer(0.0, C3_DPHASE).mix(x[i * m:(i + 1) * m]), taps, oracle.default_state(taps))
+        oracle.FM().demod(oracle.decimate(y, C3_RATE))
+
+    da, threads = _all_cores_s(chunk)
+    # the literal example (examples/fm_radio.rs:144-152 with its own 63 taps, tests/golden/reference_kats.json):
+    # u8 -> (x - 127.5) / 127.5 -> 63-tap FIR -> /5 -> FM demod -> (re, 0) -> 63-tap FIR -> .re -> /5, on 2^22 samples
+    t63 = fm_radio_taps()
+    nl = 1 << 22
+    u8 = synth_u8(nl)
+
+    def literal():
+        a = oracle.FM().demod(oracle.decimate(oracle.batch_fir(oracle.iq_u8_to_c32(u8), t63, oracle.default_state(t63)), 5))
+        oracle.decimate(oracle.batch_fir(a.astype(np.complex64), t63, oracle.default_state(t63)).real.copy(), 5)
+
+    dl = _best_of(literal, 1)
     return {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "thread_per_node": {"value": round(n / dp / 1e6, 3), "unit": "Msamples/s", "cores": 4},
+            "all_cores": {"value": round((n // threads // C3_RATE * C3_RATE) * threads / da / 1e6, 2), "unit": "Msamples/s",
+                          "cores": threads},
+            "literal_example": {"value": round(nl / dl / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+                                "what": "examples/fm_radio.rs as written (its 63 taps, /5, FM demod, 63 taps, /5; RTL-SDR "
+                                        "bytes in) on 2^22 input samples, 1 thread"},
             "sample": "2^25 of the config's 2^26 samples (extrapolates linearly: per-sample work is constant) through "
                       "oracle Mixer::mix (f64) -> batch_fir(127 taps, rotate_right per sample) -> decimate(8) -> "
                       "FM::demod, best of 2, 1 thread of %d host cores" % (os.cpu_count() or 0)}
@@ -246,11 +365,19 @@ def cpu_baseline_c4():
             oracle.fft(x, False)
 
     dt = _best_of(run)
+
+    def chunk(i, threads):
+        for x in xs[i::threads]:   # whole transforms per thread
+            oracle.fft(x, False)
+
+    da, threads = _all_cores_s(chunk, cap=k)
     return {"value": round(k * FFT_N / dt / 1e6, 3), "unit": "Mpoints/s", "cores": 1, "kind": "port",
+            "all_cores": {"value": round(k * FFT_N / da / 1e6, 2), "unit": "Mpoints/s", "cores": threads},
+            "thread_per_node": "one node: the one-thread figure",
             "sample": "64 of the config's 4096 transforms of 2^20 points (extrapolates linearly: transforms are "
                       "independent) through the oracle's BatchFFT::run_fft (f32 -> f64, radix-2 f64 FFT standing in "
-                      "for rustfft 2.1.0, whose plan is built once -- the oracle rebuilds its twiddles per call, a "
-                      "few %% of the time --, f64 -> f32), best of 2, 1 thread of %d host cores" % (os.cpu_count() or 0)}
+                      "for rustfft 2.1.0, twiddles planned once per length as FFTplanner does, fft_node.rs:66-67; "
+                      "f64 -> f32), best of 2, 1 thread of %d host cores" % (os.cpu_count() or 0)}
 
 
 def cpu_baseline_c5():
@@ -263,7 +390,16 @@ def cpu_baseline_c5():
     taps = lowpass_taps(C5_TAPS, 1.0 / 64)
     dt = _best_of(lambda: oracle.batch_fir(x, taps, oracle.default_state(taps)), 1)
     dn = _best_of(lambda: oracle.batch_fir(x[:m], taps, oracle.default_state(taps), norotate=True), 1) * (n / m)
+
+    def chunk(i, threads):
+        q = m // 4
+        oracle.batch_fir(x[i * q % n:i * q % n + q], taps, oracle.default_state(taps))
+
+    da, threads = _all_cores_s(chunk)
     return {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "all_cores": {"value": round((m // 4) * threads / da / 1e6, 3), "unit": "Msamples/s", "cores": threads,
+                          "what": "2^17 samples per thread, literal batch_fir"},
+            "thread_per_node": "one node: the one-thread figure",
             "sample": "2^21 of the config's 2^27 samples per GPU (extrapolates linearly: 4097 MACs + a 32 KiB "
                       "rotate_right per sample whatever the length) through the oracle's literal batch_fir, "
                       "1 thread of %d host cores" % (os.cpu_count() or 0),
@@ -416,23 +552,29 @@ class Ctx:
 
 
 TIMER_STRIDE = 4
+# The kernel timer of the timed regions holds BOTH of its instruments (comms_timer_*):
+#  * hipEvent pairs around every TIMER_STRIDE-th launch of the dominant kernel (hipExtLaunchKernelGGL start / stop
+#    events: the kernel's own begin / end as the command processor stamps them) -> `roofline.kernel_ms`.  Every 4th only,
+#    because a pair idles the stream 6.5 + 4.7 us around the launch it brackets (rocprofv3 trace of the driver's 20-step
+#    command, profiles/r03_timer_gaps_trace.txt): with every launch bracketed the region ran 5-9 % slower than the
+#    loop it measures.  A bracketed launch therefore runs ISOLATED from its neighbours by those gaps.
+#  * in-kernel stamps on EVERY launch (first workgroup in -> last wave's stores acknowledged, s_memrealtime; ordinary
+#    launches, nothing idles) -> `roofline.kernel_ms_in_stream`: the kernel back to back with its neighbours in the
+#    stream, which is what rocprofv3's --kernel-trace average over all launches sees as well.
 
 
-def sampled(timer, fn, stride=TIMER_STRIDE):
-    """`fn` with the kernel timer's event pair around every `stride`-th call only.  The events bracket the dominant
-    kernel's launch (hipExtLaunchKernelGGL start / stop events, or records around it) and each pair costs the stream
-    6.5 + 4.7 us of idle time before and after that launch in the first tens of launches of a burst, about half of that
-    later (rocprofv3 trace of the driver's 20-step command: warm-up steps back to back, timed steps with those gaps;
-    DESIGN.md section 5): bracketing every launch made the timed region 5-9 % slower than the loop it measures.
-    `launches_timed` in the line says how many launches the kernel time is the mean of."""
-    state = {"i": 0}
+def kernel_times(timer):
+    """(event-timed ms per bracketed launch, stamped in-stream ms per launch) of a 'both' timer."""
+    kms = timer.read_ms()
+    sms = timer.read_stamps_ms()
+    return kms, sms[sms > 0]
 
-    def step():
-        timer.enable(state["i"] % stride == 0)
-        state["i"] += 1
-        fn()
 
-    return step
+def in_stream_fields(sms):
+    if not sms.size:
+        return {"kernel_ms_in_stream": None, "launches_stamped": 0}
+    return {"kernel_ms_in_stream": round(float(np.mean(sms)), 5), "launches_stamped": int(sms.size),
+            "kernel_ms_in_stream_min_max": [round(float(sms.min()), 5), round(float(sms.max()), 5)]}
 
 
 def rank_report(ctx, kernel_ms):
@@ -515,9 +657,9 @@ def fir_chain_pass(ctx, n, first_index, steps, warmup, algo="auto", stride=TIMER
 
     for _ in range(warmup):
         step()
-    timer = c.KernelTimer(max(steps, 1), device=ctx.local_rank).attach(fir)
-    elapsed = ctx.timed(sampled(timer, step, stride), steps, 0)
-    kms = timer.read_ms()
+    timer = c.KernelTimer(max(steps, 1), device=ctx.local_rank, stamps="both", stride=stride).attach(fir)
+    elapsed = ctx.timed(step, steps, 0)
+    kms, sms = kernel_times(timer)
     timer.close()
     ctx.collect(z, transfer)
 
@@ -528,6 +670,7 @@ def fir_chain_pass(ctx, n, first_index, steps, warmup, algo="auto", stride=TIMER
     kernel_ms = float(np.mean(kms)) if kms.size else float("nan")
     res = {"elapsed": elapsed, "fused_elapsed": fused_elapsed, "ranks": rank_report(ctx, kernel_ms),
            "kernel_ms": kernel_ms, "launches_timed": int(kms.size), "kernel_ms_each": [round(float(v), 5) for v in kms],
+           "in_stream": in_stream_fields(sms), "in_stream_each": [round(float(v), 5) for v in sms],
            "timer_stride": stride, "algo": fir.kernel_for(n), "fused": chain.fused, "fused_kernel": chain.kernel, "transfer": transfer}
     del x, y, z, zf, fir, mixer, chain
     torch.cuda.empty_cache()
@@ -587,8 +730,12 @@ def run_config2(ctx):
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": pmc_traffic(algo, n),
                      "kernel_ms": round(kernel_ms, 5), "launches_timed": head["launches_timed"], "timer_stride": TIMER_STRIDE,
+                     **head["in_stream"],
+                     "frac_in_stream": (round(FIR_BYTES_PER_SAMPLE * n / (head["in_stream"]["kernel_ms_in_stream"] * 1e-3) / 1e9
+                                              / HBM_PEAK_GBS, 4) if head["in_stream"]["kernel_ms_in_stream"] else None),
                      "algorithmic_bytes_per_launch": FIR_BYTES_PER_SAMPLE * n},
         "ranks": head["ranks"],
+        "box": box_info(ctx.torch, ctx.local_rank),
     }
     out["fused_chain"] = {"value": round(total / head["fused_elapsed"] / 1e6, 1), "unit": "Msamples/s",
                           "ms_per_step": round(head["fused_elapsed"] / args.steps * 1e3, 4), "fused": head["fused"],
@@ -607,6 +754,7 @@ def run_config2(ctx):
             "fused_chain_value": round(st["total"] * st["steps"] / st["fused_elapsed"] / 1e6, 1),
             "fir_kernel": st["algo"], "fir_kernel_ms": round(st["kernel_ms"], 5),
             "fir_kernel_ms_each": st["kernel_ms_each"], "timer_stride": st["timer_stride"],
+            "fir_kernel_ms_in_stream": st["in_stream"]["kernel_ms_in_stream"], "fir_kernel_ms_in_stream_each": st["in_stream_each"],
             "fir_hbm_GBps": round(ach, 1), "fir_frac_of_peak": round(ach / HBM_PEAK_GBS, 4),
             "fir_kernel_ms_per_rank": st["ranks"]["kernel_ms_per_rank"],
             "note": "%.2f GiB of FIR input + output per GPU (HBM-resident once this is far past the 256 MiB "
@@ -674,16 +822,41 @@ def run_config3(ctx):
         ok = err <= 1e-5 and float((d > 1e-2).float().mean()) < 1e-3
     ctx.all_ok(ok, "config 3 shard boundary: median |d angle| %g" % err)
 
-    timer = c.KernelTimer(max(args.steps, 1), device=ctx.local_rank).attach(chain)
     for _ in range(args.warmup):
         chain.run_dev(x.data_ptr(), n, out.data_ptr(), s)
-    timer.reset()
-    elapsed = ctx.timed(sampled(timer, lambda: chain.run_dev(x.data_ptr(), n, out.data_ptr(), s)), args.steps, 0)
-    kms = timer.read_ms()
+    timer = c.KernelTimer(max(args.steps, 1), device=ctx.local_rank, stamps="both", stride=TIMER_STRIDE).attach(chain)
+    elapsed = ctx.timed(lambda: chain.run_dev(x.data_ptr(), n, out.data_ptr(), s), args.steps, 0)
+    kms, sms = kernel_times(timer)
     timer.close()
     ctx.collect(out, transfer)
     kernel_ms = float(np.mean(kms))
     ranks = rank_report(ctx, kernel_ms)
+    # ---- the literal example beside it (examples/fm_radio.rs:144-152 with its own 63 taps): RTL-SDR bytes -> 63-tap FIR
+    # -> /5 -> FM demod as ONE launch (u8 read by the kernel's load stage), then Convert2 -> 63-tap FIR -> Convert3 -> /5
+    # as the example wires them, device-resident
+    t63 = fm_radio_taps()
+    nl = n // 25 * 25
+    n1, n2 = nl // 5, nl // 25
+    blk = synth_u8(1 << 20)
+    u8 = torch.from_numpy(np.ascontiguousarray(np.tile(blk, ((nl >> 20) + 1, 1))[:nl])).to(ctx.dev)
+    front = c.ChainNode(0.0, 0.0, t63, 5, True, device=ctx.local_rank)
+    front.set_input_format("u8")
+    fir2, dec2 = c.BatchFirNode(t63, device=ctx.local_rank), c.DecimateNode(5, device=ctx.local_rank)
+    la = torch.empty(n1, dtype=torch.float32, device=ctx.dev)
+    lb, lc = torch.empty(n1, dtype=torch.complex64, device=ctx.dev), torch.empty(n1, dtype=torch.complex64, device=ctx.dev)
+    ld, le = torch.empty(n1, dtype=torch.float32, device=ctx.dev), torch.empty(n2, dtype=torch.float32, device=ctx.dev)
+
+    def literal():
+        front.run_dev(u8.data_ptr(), nl, la.data_ptr(), s)
+        c.real_to_c32_dev(la.data_ptr(), n1, lb.data_ptr(), ctx.local_rank, s)
+        fir2.run_dev(lb.data_ptr(), n1, lc.data_ptr(), s)
+        c.c32_re_dev(lc.data_ptr(), n1, ld.data_ptr(), ctx.local_rank, s)
+        dec2.run_dev(ld.data_ptr(), n1, 4, le.data_ptr(), s)
+
+    lit_steps = max(1, args.steps // 4)
+    lit_elapsed = ctx.timed(literal, lit_steps, max(1, args.warmup // 4))
+    lit_kernel = front.kernel
+    del u8, la, lb, lc, ld, le
     if rank != 0:
         return None
     ach = C3_BYTES_PER_SAMPLE * n / (kernel_ms * 1e-3) / 1e9
@@ -700,7 +873,12 @@ def run_config3(ctx):
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                         "traffic": pmc_traffic("fir_decim_kernel" if chain.kernel == "time" else chain.kernel, n),
                         "kernel_ms": round(kernel_ms, 5), "launches_timed": int(kms.size), "timer_stride": TIMER_STRIDE,
-                        "algorithmic_bytes_per_launch": C3_BYTES_PER_SAMPLE * n}}
+                        **in_stream_fields(sms), "algorithmic_bytes_per_launch": C3_BYTES_PER_SAMPLE * n}}
+    res["literal_example"] = {"value": round(float(world) * nl * lit_steps / lit_elapsed / 1e6, 1), "unit": "Msamples/s",
+                              "ms_per_step": round(lit_elapsed / lit_steps * 1e3, 4), "input_samples_per_gpu_per_step": nl,
+                              "front_kernel": lit_kernel,
+                              "what": "examples/fm_radio.rs as written, device-resident: u8 -> [63-tap FIR -> /5 -> FM demod] (one "
+                                      "launch) -> Convert2 -> 63-tap FIR -> Convert3 -> /5; 2 B read per input sample"}
     res["world_size_seen"], res["ranks"] = ranks["world_size_seen"], ranks
     if transfer:
         res["transfer"] = transfer
@@ -757,9 +935,9 @@ def run_config5(ctx):
 
     for _ in range(args.warmup):
         fir.run_dev(x.data_ptr(), n, y.data_ptr(), s)
-    timer = c.KernelTimer(max(args.steps, 1), device=ctx.local_rank).attach(fir)
-    elapsed = ctx.timed(sampled(timer, lambda: fir.run_dev(x.data_ptr(), n, y.data_ptr(), s)), args.steps, 0)
-    kms = timer.read_ms()
+    timer = c.KernelTimer(max(args.steps, 1), device=ctx.local_rank, stamps="both", stride=TIMER_STRIDE).attach(fir)
+    elapsed = ctx.timed(lambda: fir.run_dev(x.data_ptr(), n, y.data_ptr(), s), args.steps, 0)
+    kms, sms = kernel_times(timer)
     timer.close()
     ctx.collect(y, transfer)
     kernel_ms = float(np.mean(kms))
@@ -779,7 +957,7 @@ def run_config5(ctx):
            "roofline": {"bound": "hbm", "kernel": fir.kernel_for(n), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(fir.kernel_for(n), n),
                         "kernel_ms": round(kernel_ms, 5), "launches_timed": int(kms.size), "timer_stride": TIMER_STRIDE,
-                        "algorithmic_bytes_per_launch": FIR_BYTES_PER_SAMPLE * n}}
+                        **in_stream_fields(sms), "algorithmic_bytes_per_launch": FIR_BYTES_PER_SAMPLE * n}}
     res["world_size_seen"], res["ranks"] = ranks["world_size_seen"], ranks
     if transfer:
         res["transfer"] = transfer
@@ -883,7 +1061,11 @@ def run_config1(ctx):
 
     # `value`: the plain step loop (no timer attached: the pulse node's timer records two events around its launch,
     # a few us that a 10-us step would show); the kernel's duration comes from a second loop of the same launches
+    stamper = c.KernelTimer(max(args.steps + args.warmup, 1), device=ctx.local_rank, stamps=True).attach(fused)
     elapsed = ctx.timed(lambda: fused.run_dev(sym.data_ptr(), nsym, out.data_ptr(), s), args.steps, args.warmup)
+    sms = stamper.read_stamps_ms()[args.warmup:]
+    sms = sms[sms > 0]
+    stamper.close()
     timer = c.KernelTimer(max(args.steps, 1), device=ctx.local_rank).attach(fused)
     for _ in range(args.steps):
         fused.run_dev(sym.data_ptr(), nsym, out.data_ptr(), s)
@@ -916,7 +1098,7 @@ def run_config1(ctx):
            "roofline": {"bound": "hbm", "kernel": "pulse_poly_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                         "kernel_ms": round(kernel_ms, 5), "launches_timed": int(kms.size), "timer_stride": 1,
-                        "algorithmic_bytes_per_launch": bytes_per_out * n,
+                        **in_stream_fields(sms), "algorithmic_bytes_per_launch": bytes_per_out * n,
                         "note": "2^20 outputs are 10.5 MB: at this size the launch is latency-bound (the same kernel at "
                                 "2^24 outputs: DESIGN.md section 4); the kernel's own begin / end timestamps, every launch of a second loop"},
            "two_nodes": {"value": round(float(world) * n * args.steps / two_elapsed / 1e6, 1), "unit": "Msamples/s",

@@ -61,6 +61,10 @@ _PROTOS = {
     "comms_stream_destroy": [_i32, _vp],
     "comms_stream_pool_trim": [_i32],
     "comms_timer_create": [_sz, _i32, _pp],
+    "comms_timer_create_stamps": [_sz, _i32, _pp],
+    "comms_timer_add_stamps": [_vp, _sz],
+    "comms_timer_set_stride": [_vp, _sz],
+    "comms_timer_read_stamps": [_vp, _vp, _sz, _psz],
     "comms_timer_reset": [_vp],
     "comms_timer_read": [_vp, _vp, _sz, _psz],
     "comms_timer_destroy": [_vp],
@@ -143,6 +147,8 @@ _PROTOS = {
     "comms_iq_i16_to_c32_dev": [_vp, _sz, C.c_float, _vp, _i32, _vp],
     "comms_iq_c32_to_i16_dev": [_vp, _sz, C.c_float, _vp, _i32, _vp],
     "comms_iq_u8_to_c32_dev": [_vp, _sz, _vp, _i32, _vp],
+    "comms_iq_real_to_c32_dev": [_vp, _sz, _vp, _i32, _vp],
+    "comms_iq_c32_re_dev": [_vp, _sz, _vp, _i32, _vp],
     "comms_frequency_offset_estimate": [_vp, _sz, C.POINTER(_f64), _i32],
     "comms_psk_phase_estimate": [_vp, _sz, _u32, C.POINTER(_f64), _i32],
     "comms_qam_phase_estimate": [_vp, _sz, C.POINTER(_f64), _i32],

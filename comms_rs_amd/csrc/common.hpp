@@ -169,14 +169,44 @@ size_t zero_copy_limit();
 
 }  // namespace comms
 
-// Pool of hipEvent pairs recorded around a node's dominant kernel (bench/profiling).
+// Kernel timer: a pool of hipEvent pairs recorded around a node's dominant kernel, device slots that the kernels
+// themselves stamp (below), or both (bench / profiling).
 struct comms_timer {
     int32_t device = 0;
-    size_t n = 0;
-    size_t next = 0;  // launches recorded so far (wraps modulo n)
+    size_t n = 0;        // event pairs (0: a stamps-only timer)
+    size_t next = 0;     // bracketed launches so far (the pairs wrap modulo n)
+    size_t stride = 1;   // events bracket every stride-th launch of the attached node
+    size_t seq = 0;      // launches seen since the last reset
     hipEvent_t* start = nullptr;
     hipEvent_t* stop = nullptr;
+    size_t ns = 0;       // launches with stamp slots (stamping stops there until the next reset)
+    size_t snext = 0;
+    unsigned long long* d_begin = nullptr;  // [ns][kStampSlots], initialised to ~0
+    unsigned long long* d_end = nullptr;    // [ns][kStampSlots], initialised to 0
 };
+
+// In-kernel begin / end stamps of a launch: s_memrealtime (the 100 MHz counter every CU reads alike) taken by the
+// first thread of every workgroup when it starts and by every wave once its last store has been acknowledged,
+// reduced into kStampSlots slots per launch by atomic min / max (workgroups b and b + kStampSlots share a slot; the
+// host reduces the slots).  Unlike an event pair this idles nothing: the launch is an ordinary one, back to back with
+// its neighbours in the stream, so the figure is the kernel's duration IN the stream (first wave in to last wave
+// out), measured on every launch.  A null KStamp costs a scalar compare at either end of the kernel.
+constexpr int kStampSlots = 256;
+struct KStamp {
+    unsigned long long* begin;
+    unsigned long long* end;
+};
+__device__ __forceinline__ void kstamp_begin(const KStamp& k) {
+    if (k.begin != nullptr && threadIdx.x == 0)
+        atomicMin(k.begin + (blockIdx.x & (kStampSlots - 1)), static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()));
+}
+__device__ __forceinline__ void kstamp_end(const KStamp& k) {
+    if (k.end != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((threadIdx.x & 63) == 0)
+            atomicMax(k.end + (blockIdx.x & (kStampSlots - 1)), static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()));
+    }
+}
 
 namespace comms {
 
@@ -195,24 +225,41 @@ struct Handle {
     Pinned pin_in, pin_out;
     comms_timer* timer = nullptr;
 
-    // bracket the dominant kernel launch; no-ops without an attached timer
+    // Event bracketing of the dominant kernel launch (no-ops without an attached timer that holds event pairs).
+    // Every timed launch site runs exactly one of: tic ... toc, or take_events; each counts the launch once and
+    // brackets it only when it is the timer's stride-th.
+    bool has_events() const { return timer && timer->n; }
+    bool timed() const { return has_events() && timer->seq % timer->stride == 0; }
     void tic(hipStream_t s) {
-        if (timer && timer->n) (void)hipEventRecord(timer->start[timer->next % timer->n], s);
+        if (timed()) (void)hipEventRecord(timer->start[timer->next % timer->n], s);
     }
     void toc(hipStream_t s) {
-        if (timer && timer->n) {
+        if (!has_events()) return;
+        if (timed()) {
             (void)hipEventRecord(timer->stop[timer->next % timer->n], s);
             ++timer->next;
         }
+        ++timer->seq;
     }
-
-    // For launches made with hipExtLaunchKernelGGL: the pair is updated with the kernel's own
-    // begin / end timestamps (no dispatch gap), which is what rocprofv3 reports as its duration.
-    bool timed() const { return timer && timer->n; }
-    void next_events(hipEvent_t& a, hipEvent_t& b) {
-        a = timer->start[timer->next % timer->n];
-        b = timer->stop[timer->next % timer->n];
-        ++timer->next;
+    // For launches made with hipExtLaunchKernelGGL: the pair is updated with the kernel's own begin / end
+    // timestamps (no dispatch gap), which is what rocprofv3 reports as its duration.  False: launch plainly.
+    bool take_events(hipEvent_t& a, hipEvent_t& b) {
+        if (!has_events()) return false;
+        const bool on = timed();
+        ++timer->seq;
+        if (on) {
+            a = timer->start[timer->next % timer->n];
+            b = timer->stop[timer->next % timer->n];
+            ++timer->next;
+        }
+        return on;
+    }
+    // In-kernel stamps: the slots of the launch about to be made, or a null KStamp when the attached timer has none
+    // (left).  Only kernels that take a KStamp are timed this way.
+    KStamp next_stamp() {
+        if (!timer || !timer->d_begin || timer->snext >= timer->ns) return KStamp{nullptr, nullptr};
+        const size_t i = timer->snext++;
+        return KStamp{timer->d_begin + i * kStampSlots, timer->d_end + i * kStampSlots};
     }
 
     comms_status_t init(int32_t dev) {

@@ -748,10 +748,12 @@ template <int HR, bool TRACE, class In = const float2*>
 __global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(In in,
                                                                  const float2* __restrict__ hist, int hist_len,
                                                                  float2* __restrict__ out, size_t n, WTables tb,
-                                                                 float2* __restrict__ new_hist, void* trace_buf) {
+                                                                 float2* __restrict__ new_hist, void* trace_buf,
+                                                                 unsigned chunk_log2, KStamp ks) {
     constexpr int WVK = 1024 - 64 * HR, HALO = 64 * HR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WaveTrace<TRACE> trace;
+    kstamp_begin(ks);
     hist_advance(hist, in, n, new_hist, hist_len);
     cf* tw1 = reinterpret_cast<cf*>(smem);  // [16][64]
     cf* hsp = tw1 + 1024;                   // [16][64]
@@ -769,16 +771,27 @@ __global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(In in,
     __syncthreads();
     trace.setup_done();
 
-    // interior segments 1 .. nfull-1 (all 16 rows inside `in`, all outputs inside `out`), dealt
-    // to the workgroups in equal contiguous shares
+    // interior segments 1 .. nfull-1 (all 16 rows inside `in`, all outputs inside `out`).
+    // chunk_log2 >= 32: every workgroup owns one contiguous share.  Otherwise the stream is cut into chunks of
+    // 2^chunk_log2 segments dealt round-robin: chunk c goes to workgroup c mod G in sweep order, so the whole chip
+    // reads one window of G chunks and writes the same window of the output (DRAM sees two sequential streams
+    // instead of 2 G of them, spaced a power of two apart when n is one).  Sweep order runs through the
+    // workgroups of one XCD first (blocks b, b + 8, ... share one under the observed round-robin placement: speed
+    // only), so that the halo rows at a chunk's edge were just read into the same L2 by the neighbouring chunk.
     const size_t nfull = n / WVK;
     const size_t inner = nfull > 1 ? nfull - 1 : 0;
+    const bool contiguous = chunk_log2 >= 32u;
+    const unsigned G = gridDim.x;
+    const unsigned wg = (G % 8u == 0u) ? (blockIdx.x % 8u) * (G / 8u) + blockIdx.x / 8u : blockIdx.x;
     const size_t lo = 1 + blockIdx.x * inner / gridDim.x;
-    const size_t hi = 1 + (blockIdx.x + 1) * inner / gridDim.x;
+    const size_t hi = contiguous ? 1 + (blockIdx.x + 1) * inner / gridDim.x : nfull;
     auto draw = [&]() -> size_t {  // one lane draws, the wave follows
         unsigned t = 0;
         if (l == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        return lo + static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(t)));
+        const unsigned tk = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(t)));
+        if (contiguous) return lo + tk;
+        const size_t c = static_cast<size_t>(tk >> chunk_log2) * G + wg;
+        return 1 + (c << chunk_log2) + (tk & ((1u << chunk_log2) - 1u));
     };
     auto fetch = [&](size_t sg, cf (&r)[16]) {
         const size_t p = sg * WVK - HALO + l;
@@ -828,6 +841,7 @@ __global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(In in,
     }
 
     if (TRACE) trace.write(trace_buf, blockIdx.x * 16 + wave, l, count);
+    kstamp_end(ks);
 }
 
 // ---------------------------------------------------------------- overlap-save, F = 16384 (long filters)
@@ -889,7 +903,8 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
                                                             const float2* __restrict__ hist, int hist_len,
                                                             float2* __restrict__ out, size_t n, size_t nseg,
                                                             XTables tb, float2* __restrict__ new_hist, int delay,
-                                                            int accumulate) {
+                                                            int accumulate, KStamp ks) {
+    kstamp_begin(ks);
     // HR = halo rows of 1024 samples (1 ... 4: up to 1025 / 2049 / 3073 / 4097 taps): a segment keeps 16 - HR rows.
     // (A compile-time value: as a kernel argument the row loops turned into chains of uniform branches and the
     // kernel lost 11 % -- 591 -> 658 us at 2^27 samples, 4097 taps.)
@@ -998,6 +1013,7 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
             __builtin_amdgcn_raw_buffer_store_b64(bv2u{__float_as_uint(y.x), __float_as_uint(y.y)}, ors, tid * 8, row, 0);
         }
     }
+    kstamp_end(ks);
 }
 
 // ---------------------------------------------------------------- pulse shaping (polyphase)
@@ -1081,6 +1097,7 @@ struct PulseArgs {
     int hist_len, J;       // J rows of taps (multiple of PP_JB, zero rows appended)
     float are[PP_AMAX];    // A[j*SPSP + p] = Re taps[p + j*SPS]
     float aim[PP_AMAX];
+    KStamp ks;             // in-kernel begin / end stamps of a stamps timer, or null
 };
 
 template <int SPS, bool REAL, bool MIX>
@@ -1093,6 +1110,7 @@ __global__ __launch_bounds__(256) void pulse_poly_kernel(const PulseArgs a) {
     const int tid = threadIdx.x;
     const int halo = a.J - 1;
     const size_t ntiles = (a.n_sym + 255) / 256;
+    kstamp_begin(a.ks);
     hist_advance(a.hist, a.sym, a.n_sym, a.new_hist, a.hist_len);
     double rc = 1.0, rs = 0.0;  // rotor of this lane's first output of the current tile
     if (MIX) pulse_rotor_at(a.mx.turns0 + (static_cast<uint64_t>(blockIdx.x) * 256 + tid) * SPS * a.mx.frac, rc, rs);
@@ -1205,6 +1223,7 @@ __global__ __launch_bounds__(256) void pulse_poly_kernel(const PulseArgs a) {
             }
         }
     }
+    kstamp_end(a.ks);
 }
 
 }  // namespace comms
@@ -1291,11 +1310,33 @@ static int os1024_dynamic_mode() {
 extern "C" void comms_debug_os1024_dynamic(int mode) { g_os1024_dynamic.store(mode, std::memory_order_relaxed); }
 #endif
 
+// How the ticketed kernel deals its segments to the workgroups: chunks of 2^k segments round-robin (k < 32) or one
+// contiguous share each (32).  Measured with the variants interleaved launch by launch (scripts/probe_chunks.py,
+// profiles/r04_probe_chunks.txt; 255 taps): 2^24 samples 52.9 -> 51.0 us with chunks of 2 (and 57.1 -> 50.4 where the
+// output buffer sat 1 MiB further from the input: shares that start a power of two apart make the time depend on the
+// buffers' relative placement, chunks do not), 2^26 neutral, 2^28 875 -> 809 us with chunks of 8, 2^30 3.236 -> 3.213 ms.
+// Chunks of 2 keep the workgroups' loads within one segment of each other at 2^24 (85 segments each); from 16 up the
+// last round's imbalance shows (2^24: 55.9 us), at 64 everywhere.  COMMS_OS1024_CHUNK_LOG2 overrides.
+static std::atomic<int> g_os1024_chunk{-2};
+static unsigned os1024_chunk_log2(size_t nseg, unsigned grid) {
+    int env = g_os1024_chunk.load(std::memory_order_relaxed);
+    if (env == -2) {
+        env = tune_int("COMMS_OS1024_CHUNK_LOG2", -1);
+        g_os1024_chunk.store(env, std::memory_order_relaxed);
+    }
+    if (env >= 0) return static_cast<unsigned>(env);
+    return nseg < 160u * static_cast<size_t>(grid) ? 1u : 3u;  // (160 segments per workgroup: 2^25 samples at 255 taps)
+}
+#ifdef COMMS_DIAG
+extern "C" void comms_debug_os1024_chunk_log2(int k) { g_os1024_chunk.store(k, std::memory_order_relaxed); }
+#endif
+
 // One launch of fir_os1024_dyn_kernel: one 16-wave workgroup per CU (fewer for short inputs).
 template <int HR, bool TRACE = false, class In = const float2*>
 static comms_status_t launch_os1024_dyn(hipStream_t s, In in, const float2* hist, int n_eff, float2* o,
                                         size_t n, const comms::WTables& tb, float2* nh, void* trace_buf = nullptr,
-                                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+                                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
+                                        KStamp ks = KStamp{nullptr, nullptr}) {
     using namespace comms;
     const size_t lds = (2112 + 16 * W_LDS + 1) * sizeof(float2);  // tables, exchange buffers, ticket counter
     static DeviceOnce attr_once;
@@ -1306,11 +1347,12 @@ static comms_status_t launch_os1024_dyn(hipStream_t s, In in, const float2* hist
     const size_t nseg = (n + (1024 - 64 * HR) - 1) / (1024 - 64 * HR);
     const size_t want = (nseg + 15) / 16;
     const dim3 grid(static_cast<unsigned>(want < static_cast<size_t>(kNumCU) ? want : kNumCU));
+    const unsigned chunk_log2 = os1024_chunk_log2(nseg, grid.x);
     if (ev_start)  // timed launch: the events take the kernel's own begin / end timestamps
         hipExtLaunchKernelGGL((fir_os1024_dyn_kernel<HR, TRACE, In>), grid, dim3(1024), static_cast<uint32_t>(lds), s, ev_start,
-                              ev_stop, 0u, in, hist, n_eff, o, n, tb, nh, trace_buf);
+                              ev_stop, 0u, in, hist, n_eff, o, n, tb, nh, trace_buf, chunk_log2, ks);
     else
-        fir_os1024_dyn_kernel<HR, TRACE, In><<<grid, dim3(1024), lds, s>>>(in, hist, n_eff, o, n, tb, nh, trace_buf);
+        fir_os1024_dyn_kernel<HR, TRACE, In><<<grid, dim3(1024), lds, s>>>(in, hist, n_eff, o, n, tb, nh, trace_buf, chunk_log2, ks);
     return COMMS_OK;
 }
 
@@ -1691,17 +1733,17 @@ static comms_status_t fir_converted_input(comms_fir* h, const void* d_in, size_t
 
 template <int HR, class In>
 static comms_status_t launch_dyn_in(hipStream_t s, In in, comms_fir* h, float2* o, size_t n, const WTables& tb, float2* nh,
-                                    hipEvent_t ea, hipEvent_t eb) {
-    return launch_os1024_dyn<HR, false, In>(s, in, h->d_hist[h->cur], h->n_eff, o, n, tb, nh, nullptr, ea, eb);
+                                    hipEvent_t ea, hipEvent_t eb, KStamp ks) {
+    return launch_os1024_dyn<HR, false, In>(s, in, h->d_hist[h->cur], h->n_eff, o, n, tb, nh, nullptr, ea, eb, ks);
 }
 template <class In>
 static comms_status_t launch_dyn_hr(int hr, hipStream_t s, In in, comms_fir* h, float2* o, size_t n, const WTables& tb,
-                                    float2* nh, hipEvent_t ea, hipEvent_t eb) {
+                                    float2* nh, hipEvent_t ea, hipEvent_t eb, KStamp ks) {
     switch (hr) {
-        case 1: return launch_dyn_in<1>(s, in, h, o, n, tb, nh, ea, eb);
-        case 2: return launch_dyn_in<2>(s, in, h, o, n, tb, nh, ea, eb);
-        case 3: return launch_dyn_in<3>(s, in, h, o, n, tb, nh, ea, eb);
-        default: return launch_dyn_in<4>(s, in, h, o, n, tb, nh, ea, eb);
+        case 1: return launch_dyn_in<1>(s, in, h, o, n, tb, nh, ea, eb, ks);
+        case 2: return launch_dyn_in<2>(s, in, h, o, n, tb, nh, ea, eb, ks);
+        case 3: return launch_dyn_in<3>(s, in, h, o, n, tb, nh, ea, eb, ks);
+        default: return launch_dyn_in<4>(s, in, h, o, n, tb, nh, ea, eb, ks);
     }
 }
 template <class In>
@@ -1716,12 +1758,12 @@ static comms_status_t launch_fixed_hr(int hr, int wpb, size_t runs, hipStream_t 
 }
 template <class In>
 static void launch_os16k_hr(int hr, unsigned blocks, size_t lds, hipStream_t s, In in, const float2* hist, int n_eff, float2* o, size_t n,
-                            size_t nseg, const XTables& tb, float2* nh, int dl, int acc) {
+                            size_t nseg, const XTables& tb, float2* nh, int dl, int acc, KStamp ks) {
     switch (hr) {
-        case 1: fir_os16k_kernel<1, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc); break;
-        case 2: fir_os16k_kernel<2, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc); break;
-        case 3: fir_os16k_kernel<3, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc); break;
-        default: fir_os16k_kernel<4, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc); break;
+        case 1: fir_os16k_kernel<1, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc, ks); break;
+        case 2: fir_os16k_kernel<2, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc, ks); break;
+        case 3: fir_os16k_kernel<3, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc, ks); break;
+        default: fir_os16k_kernel<4, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc, ks); break;
     }
 }
 template <class In>
@@ -1779,15 +1821,19 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
         const size_t runs = os1024_runs(pl.wpb, nseg, pl.min_run);
         WTables tb{reinterpret_cast<const cf*>(h->d_wtw1), reinterpret_cast<const cf*>(h->d_wtw2), reinterpret_cast<const cf*>(h->d_whdev)};
         hipEvent_t ea = nullptr, eb = nullptr;
-        if (h->timed() && pl.wpb == 16) h->next_events(ea, eb);
-        if (!ea) h->tic(s);
+        const bool own_stamps = pl.wpb == 16;  // (16-wave launches report the kernel's own begin / end through the pair)
+        if (own_stamps)
+            (void)h->take_events(ea, eb);
+        else
+            h->tic(s);
+        const KStamp ks = pl.dyn ? h->next_stamp() : KStamp{nullptr, nullptr};
         if (pl.dyn) {
             if (h->in_fmt == COMMS_IQ_I16)
-                COMMS_TRY(launch_dyn_hr(pl.hr, s, InI16{static_cast<const short2*>(d_in), h->in_scale}, h, o, n, tb, nh, ea, eb));
+                COMMS_TRY(launch_dyn_hr(pl.hr, s, InI16{static_cast<const short2*>(d_in), h->in_scale}, h, o, n, tb, nh, ea, eb, ks));
             else if (h->in_fmt == COMMS_IQ_U8)
-                COMMS_TRY(launch_dyn_hr(pl.hr, s, InU8{static_cast<const uchar2*>(d_in)}, h, o, n, tb, nh, ea, eb));
+                COMMS_TRY(launch_dyn_hr(pl.hr, s, InU8{static_cast<const uchar2*>(d_in)}, h, o, n, tb, nh, ea, eb, ks));
             else
-                COMMS_TRY(launch_dyn_hr(pl.hr, s, in, h, o, n, tb, nh, ea, eb));
+                COMMS_TRY(launch_dyn_hr(pl.hr, s, in, h, o, n, tb, nh, ea, eb, ks));
         } else if (h->in_fmt == COMMS_IQ_I16) {
             COMMS_TRY(launch_fixed_hr(pl.hr, pl.wpb, runs, s, InI16{static_cast<const short2*>(d_in), h->in_scale}, hist, h->n_eff, o, n, nseg, tb, nh, ea, eb));
         } else if (h->in_fmt == COMMS_IQ_U8) {
@@ -1795,7 +1841,7 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
         } else {
             COMMS_TRY(launch_fixed_hr(pl.hr, pl.wpb, runs, s, in, hist, h->n_eff, o, n, nseg, tb, nh, ea, eb));
         }
-        if (!ea) h->toc(s);
+        if (!own_stamps) h->toc(s);
         COMMS_TRY(launch_ok("fir_os1024_kernel"));
     } else if (algo == COMMS_FIR_OS16K) {
         COMMS_TRY(fir_prepare_os16k(h));
@@ -1806,17 +1852,18 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
         const unsigned blocks = static_cast<unsigned>(nseg < static_cast<size_t>(kNumCU) ? nseg : kNumCU);
         const size_t lds = X_LDS_BYTES;
         h->tic(s);
+        const KStamp ks = h->next_stamp();  // (the passes of a partitioned filter stamp the same slots: the whole call)
         for (int pt = 0; pt < h->x_part; ++pt) {
             XTables tb{reinterpret_cast<const cf*>(h->d_xt[0]), reinterpret_cast<const cf*>(h->d_xt[1]),
                        reinterpret_cast<const cf*>(h->d_xt[2]), reinterpret_cast<const cf*>(h->d_xt[3]),
                        reinterpret_cast<const cf*>(h->d_xh[pt])};
             const int dl = pt * X_PART, acc = pt ? 1 : 0;
             if (h->in_fmt == COMMS_IQ_I16)
-                launch_os16k_hr(hr, blocks, lds, s, InI16{static_cast<const short2*>(d_in), h->in_scale}, hist, h->n_eff, o, n, nseg, tb, nh, dl, acc);
+                launch_os16k_hr(hr, blocks, lds, s, InI16{static_cast<const short2*>(d_in), h->in_scale}, hist, h->n_eff, o, n, nseg, tb, nh, dl, acc, ks);
             else if (h->in_fmt == COMMS_IQ_U8)
-                launch_os16k_hr(hr, blocks, lds, s, InU8{static_cast<const uchar2*>(d_in)}, hist, h->n_eff, o, n, nseg, tb, nh, dl, acc);
+                launch_os16k_hr(hr, blocks, lds, s, InU8{static_cast<const uchar2*>(d_in)}, hist, h->n_eff, o, n, nseg, tb, nh, dl, acc, ks);
             else
-                launch_os16k_hr(hr, blocks, lds, s, in, hist, h->n_eff, o, n, nseg, tb, nh, dl, acc);
+                launch_os16k_hr(hr, blocks, lds, s, in, hist, h->n_eff, o, n, nseg, tb, nh, dl, acc, ks);
         }
         h->toc(s);
         COMMS_TRY(launch_ok("fir_os16k_kernel"));
@@ -2049,7 +2096,8 @@ static bool pulse_poly_try(comms_pulse* h, const float2* sym, size_t n_sym, floa
     // with a kernel timer attached: the kernel's own begin / end timestamps (events recorded around a launch of config 1's
     // size -- 5 us -- would mostly time the dispatch gap)
     hipEvent_t ea = nullptr, eb = nullptr;
-    if (h->timed()) h->next_events(ea, eb);
+    (void)h->take_events(ea, eb);
+    a.ks = h->next_stamp();
 #define COMMS_PULSE_GO(REAL, MIX)                                                                                            \
     do {                                                                                                                     \
         if (ea)                                                                                                              \

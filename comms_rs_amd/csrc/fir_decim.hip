@@ -73,8 +73,9 @@ struct DecimArgs {
     float aim[DC_AMAX];
     const float* qt;               // OPL = 4: the taps of one LDS read stored together, Q[m][c] = A[m + R c] (device memory)
     unsigned long long* stamps;    // diagnostic (scripts/stamp_decim.py): per-wave cycles per phase, or NULL
-    int interleave;                // tile t of workgroup b: b + i gridDim.x instead of a contiguous run (kept last: the tap
-                                   // arrays' offsets decide how many scalar-cache lines a 64-byte tap load touches)
+    int interleave;                // tile t of workgroup b: b + i gridDim.x instead of a contiguous run (kept behind the tap
+                                   // arrays: their offsets decide how many scalar-cache lines a 64-byte tap load touches)
+    KStamp ks;                     // in-kernel begin / end stamps of a stamps timer, or null
 };
 
 constexpr double kTwoPiD = 2.0 * 3.14159265358979323846264338327950288;
@@ -137,6 +138,7 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
         default: hist_advance(a.hist, static_cast<const float2*>(a.in), a.n, a.new_hist, a.hist_len); break;
     }
 
+    kstamp_begin(a.ks);
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     constexpr bool pre = PRE;
     const bool post = !PRE && (a.mode & COMMS_CHAIN_POST) != 0;
@@ -420,6 +422,7 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
     }
     if (a.stamps && l == 0)
         for (int i = 0; i < 6; ++i) a.stamps[(static_cast<size_t>(blockIdx.x) * (WG / 64) + w) * 8 + i] = st_acc[i];
+    kstamp_end(a.ks);
 #undef DC_STAMP
 }
 
@@ -633,6 +636,8 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
                     if (k >= 0 && k < N) q[4 * m + c] = h->taps[k].re;
                 }
             COMMS_TRY(h->quiesce());
+            h->last_stream = s;  // (quiesce forgot the stream `enter` just recorded: the launch below must stay tracked)
+            h->launched = true;
             if (h->d_qt) (void)hipFree(h->d_qt);
             h->d_qt = nullptr;
             COMMS_HIP_TRY(hipMalloc(&h->d_qt, q.size() * sizeof(float)));
@@ -647,7 +652,13 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
         a.are[m] = in_range ? h->taps[k].re : 0.f;
         a.aim[m] = in_range ? h->taps[k].im : 0.f;
     }
-    if (h->timed()) h->next_events(g_decim_ev_start, g_decim_ev_stop);
+    // (the pair travels to launch_decim_v through thread-local slots: whatever the exit, none stays behind for the next
+    // launch on this thread, possibly another handle's)
+    struct EvGuard {
+        ~EvGuard() { g_decim_ev_start = g_decim_ev_stop = nullptr; }
+    } ev_guard;
+    (void)h->take_events(g_decim_ev_start, g_decim_ev_stop);
+    a.ks = h->next_stamp();
     comms_status_t st;
     switch (R) {
         case 2: st = launch_decim<2>(a, real, opl, tile, s); break;
@@ -665,7 +676,7 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
         case 14: st = launch_decim<14>(a, real, 2, tile, s); break;
         case 15: st = launch_decim_real<15>(a, s); break;
         case 16: st = launch_decim<16>(a, real, 2, tile, s); break;
-        default: g_decim_ev_start = g_decim_ev_stop = nullptr; return fail(COMMS_ERR_ARG, "no decimating kernel for rate %d", R);
+        default: return fail(COMMS_ERR_ARG, "no decimating kernel for rate %d", R);
     }
     COMMS_TRY(st);
     h->cur ^= 1;

@@ -322,6 +322,8 @@ comms_status_t comms_fir_run_decim_any_dev(comms_fir_t* h, const void* d_in, siz
         std::vector<float2> tp(32 * NT, make_float2(0.f, 0.f));
         for (int k = 0; k < N; ++k) tp[k] = make_float2(h->taps[k].re, h->taps[k].im);
         COMMS_TRY(h->quiesce());
+        h->last_stream = s;  // (quiesce forgot the stream `enter` just recorded: the launch below must stay tracked)
+        h->launched = true;
         if (h->d_any_taps) (void)hipFree(h->d_any_taps);
         h->d_any_taps = nullptr;
         COMMS_HIP_TRY(hipMalloc(&h->d_any_taps, tp.size() * sizeof(float2)));

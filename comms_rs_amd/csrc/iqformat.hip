@@ -38,6 +38,27 @@ __global__ __launch_bounds__(256) void u8_to_c32_kernel(const uchar2* __restrict
     }
 }
 
+// The casts examples/fm_radio.rs wraps around its second filter (Convert2Node :93-117: x -> Complex(x, 0);
+// Convert3Node :119-141: x -> x.re), so that its whole chain can stay device-resident: two samples per lane.
+__global__ __launch_bounds__(256) void real_to_c32_kernel(const float* __restrict__ in, float2* __restrict__ out, size_t n) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    const size_t pairs = n / 2;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < pairs; i += stride) {
+        const float2 v = reinterpret_cast<const float2*>(in)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(v.x, 0.f, v.y, 0.f);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = make_float2(in[n - 1], 0.f);
+}
+__global__ __launch_bounds__(256) void c32_re_kernel(const float2* __restrict__ in, float* __restrict__ out, size_t n) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    const size_t pairs = n / 2;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < pairs; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(in)[i];
+        reinterpret_cast<float2*>(out)[i] = make_float2(v.x, v.z);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = in[n - 1].x;
+}
+
 static unsigned conv_grid(size_t n) {
     size_t b = (n + 255) / 256;
     if (b > 8u * kNumCU) b = 8u * kNumCU;
@@ -90,6 +111,29 @@ comms_status_t comms_iq_u8_to_c32_dev(const uint8_t* d_in, size_t n, comms_c32* 
     u8_to_c32_kernel<<<dim3(conv_grid(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
         reinterpret_cast<const uchar2*>(d_in), reinterpret_cast<float2*>(d_out), n);
     return launch_ok("u8_to_c32_kernel");
+}
+
+comms_status_t comms_iq_real_to_c32_dev(const float* d_in, size_t n, comms_c32* d_out, int32_t device, void* stream) {
+    COMMS_ARG((d_in && d_out) || !n, "NULL device pointer");
+    COMMS_ARG((reinterpret_cast<uintptr_t>(d_in) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0,
+              "input must be 8-byte aligned, output 16-byte aligned");
+    COMMS_ARG(!ranges_overlap(d_in, n * 4, d_out, n * 8), "the cast cannot run in place");
+    COMMS_TRY(use_device(device));
+    if (!n) return COMMS_OK;
+    real_to_c32_kernel<<<dim3(conv_grid((n + 1) / 2)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        d_in, reinterpret_cast<float2*>(d_out), n);
+    return launch_ok("real_to_c32_kernel");
+}
+comms_status_t comms_iq_c32_re_dev(const comms_c32* d_in, size_t n, float* d_out, int32_t device, void* stream) {
+    COMMS_ARG((d_in && d_out) || !n, "NULL device pointer");
+    COMMS_ARG((reinterpret_cast<uintptr_t>(d_in) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 7) == 0,
+              "input must be 16-byte aligned, output 8-byte aligned");
+    COMMS_ARG(!ranges_overlap(d_in, n * 8, d_out, n * 4), "the cast cannot run in place");
+    COMMS_TRY(use_device(device));
+    if (!n) return COMMS_OK;
+    c32_re_kernel<<<dim3(conv_grid((n + 1) / 2)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        reinterpret_cast<const float2*>(d_in), d_out, n);
+    return launch_ok("c32_re_kernel");
 }
 
 comms_status_t comms_iq_i16_to_c32(const int16_t* in, size_t n, float scale, comms_c32* out, int32_t device) {

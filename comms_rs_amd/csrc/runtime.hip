@@ -447,14 +447,87 @@ comms_status_t comms_timer_create(size_t n_pairs, int32_t device, comms_timer_t*
     *out = t;
     return COMMS_OK;
 }
+static comms_status_t timer_init_stamps(comms_timer* t) {
+    const size_t bytes = t->ns * kStampSlots * sizeof(unsigned long long);
+    COMMS_HIP_TRY(hipMemsetAsync(t->d_begin, 0xFF, bytes, nullptr));
+    COMMS_HIP_TRY(hipMemsetAsync(t->d_end, 0, bytes, nullptr));
+    COMMS_HIP_TRY(hipStreamSynchronize(nullptr));  // the handles' streams do not wait for the legacy stream
+    return COMMS_OK;
+}
+comms_status_t comms_timer_add_stamps(comms_timer_t* t, size_t n_launches) {
+    COMMS_ARG(t != nullptr, "timer is NULL");
+    COMMS_ARG(n_launches >= 1 && n_launches <= (1u << 20), "n_launches out of range");
+    COMMS_ARG(t->d_begin == nullptr, "the timer has stamp slots already");
+    COMMS_TRY(use_device(t->device));
+    const size_t bytes = n_launches * kStampSlots * sizeof(unsigned long long);
+    hipError_t e = hipMalloc(&t->d_begin, bytes);
+    if (e == hipSuccess) e = hipMalloc(&t->d_end, bytes);
+    if (e != hipSuccess) {
+        if (t->d_begin) (void)hipFree(t->d_begin);
+        t->d_begin = t->d_end = nullptr;
+        return fail(COMMS_ERR_DEVICE, "stamp slots for %zu launches: %s", n_launches, hipGetErrorString(e));
+    }
+    t->ns = n_launches;
+    t->snext = 0;
+    return timer_init_stamps(t);
+}
+comms_status_t comms_timer_create_stamps(size_t n_launches, int32_t device, comms_timer_t** out) {
+    COMMS_ARG(out != nullptr, "out is NULL");
+    *out = nullptr;
+    COMMS_TRY(use_device(device));
+    comms_timer* t = new (std::nothrow) comms_timer;
+    COMMS_ARG(t != nullptr, "out of host memory");
+    t->device = device;
+    const comms_status_t st = comms_timer_add_stamps(t, n_launches);
+    if (st != COMMS_OK) {
+        comms_timer_destroy(t);
+        return st;
+    }
+    *out = t;
+    return COMMS_OK;
+}
+comms_status_t comms_timer_set_stride(comms_timer_t* t, size_t stride) {
+    COMMS_ARG(t != nullptr, "timer is NULL");
+    COMMS_ARG(stride >= 1, "stride must be at least 1");
+    t->stride = stride;
+    return COMMS_OK;
+}
 comms_status_t comms_timer_reset(comms_timer_t* t) {
     COMMS_ARG(t != nullptr, "timer is NULL");
-    t->next = 0;
+    if (t->d_begin) {  // launches that still stamp the old slots come first
+        COMMS_TRY(use_device(t->device));
+        COMMS_HIP_TRY(hipDeviceSynchronize());
+        COMMS_TRY(timer_init_stamps(t));
+    }
+    t->next = t->seq = t->snext = 0;
+    return COMMS_OK;
+}
+comms_status_t comms_timer_read_stamps(comms_timer_t* t, float* ms, size_t cap, size_t* out_count) {
+    COMMS_ARG(t && out_count && (ms || !cap), "NULL argument");
+    COMMS_TRY(use_device(t->device));
+    const size_t have = t->snext < cap ? t->snext : cap;
+    *out_count = 0;
+    if (!have) return COMMS_OK;
+    COMMS_HIP_TRY(hipDeviceSynchronize());
+    std::vector<unsigned long long> b(have * kStampSlots), e(have * kStampSlots);
+    COMMS_HIP_TRY(hipMemcpy(b.data(), t->d_begin, b.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    COMMS_HIP_TRY(hipMemcpy(e.data(), t->d_end, e.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < have; ++i) {
+        unsigned long long lo = ~0ull, hi = 0;
+        for (int k = 0; k < kStampSlots; ++k) {
+            lo = b[i * kStampSlots + k] < lo ? b[i * kStampSlots + k] : lo;
+            hi = e[i * kStampSlots + k] > hi ? e[i * kStampSlots + k] : hi;
+        }
+        // s_memrealtime ticks at 100 MHz; a launch whose kernel takes no KStamp left its slots untouched
+        ms[i] = hi > lo ? static_cast<float>(static_cast<double>(hi - lo) * 1e-5) : 0.0f;
+    }
+    *out_count = have;
     return COMMS_OK;
 }
 comms_status_t comms_timer_read(comms_timer_t* t, float* ms, size_t cap, size_t* out_count) {
     COMMS_ARG(t && out_count && (ms || !cap), "NULL argument");
     COMMS_TRY(use_device(t->device));
+    if (!t->n) return comms_timer_read_stamps(t, ms, cap, out_count);  // a stamps-only timer
     const size_t have = t->next < t->n ? t->next : t->n;
     const size_t first = t->next - have;  // oldest launch still held
     size_t w = 0;
@@ -475,6 +548,8 @@ comms_status_t comms_timer_destroy(comms_timer_t* t) {
     }
     delete[] t->start;
     delete[] t->stop;
+    if (t->d_begin) (void)hipFree(t->d_begin);
+    if (t->d_end) (void)hipFree(t->d_end);
     delete t;
     return COMMS_OK;
 }

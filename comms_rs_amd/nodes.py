@@ -565,6 +565,16 @@ def iq_c32_to_i16(x, scale=1.0, device=0):
     return out
 
 
+def real_to_c32_dev(in_ptr, n, out_ptr, device=0, stream=0):
+    """x -> Complex(x, 0) on the device (examples/fm_radio.rs Convert2Node)."""
+    check(lib().comms_iq_real_to_c32_dev(in_ptr, n, out_ptr, device, stream))
+
+
+def c32_re_dev(in_ptr, n, out_ptr, device=0, stream=0):
+    """x -> x.re on the device (examples/fm_radio.rs Convert3Node)."""
+    check(lib().comms_iq_c32_re_dev(in_ptr, n, out_ptr, device, stream))
+
+
 def iq_u8_to_c32(x, device=0):
     """uint8 (n, 2) RTL-SDR bytes -> complex64: (x - 127.5) / 127.5."""
     x = np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 2)
@@ -667,10 +677,21 @@ def synth_iq_dev(out_ptr, n, first_index=0, seed=0xC0FFEE, device=0, stream=0):
 class KernelTimer:
     """comms_timer_*: hipEvent pairs recorded around a node's dominant kernel."""
 
-    def __init__(self, n_pairs, device=0):
+    def __init__(self, n_pairs, device=0, stamps=False, stride=1):
+        """stamps=False: hipEvent pairs (every `stride`-th launch of the attached node is bracketed);
+        stamps=True: comms_timer_create_stamps -- the kernels stamp their own begin / end, no events, every launch an
+        ordinary one (the kernel's duration in the stream); stamps="both": events every stride-th launch AND stamps
+        on every launch (read_ms / read_stamps_ms)."""
         self._h = C.c_void_p()
         self.n = int(n_pairs)
-        check(lib().comms_timer_create(self.n, device, C.byref(self._h)))
+        if stamps is True:
+            check(lib().comms_timer_create_stamps(self.n, device, C.byref(self._h)))
+        else:
+            check(lib().comms_timer_create(self.n, device, C.byref(self._h)))
+            if stamps == "both":
+                check(lib().comms_timer_add_stamps(self._h, self.n))
+            if stride != 1:
+                check(lib().comms_timer_set_stride(self._h, int(stride)))
 
     def attach(self, node):
         name = {"comms_fir_destroy": "comms_fir_set_timer", "comms_mixer_destroy": "comms_mixer_set_timer",
@@ -694,6 +715,13 @@ class KernelTimer:
         out = np.zeros(self.n, np.float32)
         m = C.c_size_t()
         check(lib().comms_timer_read(self._h, _ptr(out), self.n, C.byref(m)))
+        return out[:m.value].copy()
+
+    def read_stamps_ms(self):
+        """In-stream kernel durations of the stamped launches (0.0 where the launched kernel does not stamp)."""
+        out = np.zeros(self.n, np.float32)
+        m = C.c_size_t()
+        check(lib().comms_timer_read_stamps(self._h, _ptr(out), self.n, C.byref(m)))
         return out[:m.value].copy()
 
     def close(self):

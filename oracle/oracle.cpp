@@ -142,10 +142,19 @@ void dft_f64(std::vector<Cx<double>>& a, bool inverse) {
             j ^= bit;
             if (i < j) std::swap(a[i], a[j]);
         }
-        std::vector<Cx<double>> w(n / 2);
-        for (size_t k = 0; k < n / 2; ++k) {
-            double ang = sgn * kTwoPi * static_cast<double>(k) / static_cast<double>(n);
-            w[k] = Cx<double>{std::cos(ang), std::sin(ang)};
+        // the "plan": twiddles of this length and direction, built once per thread and kept (rustfft plans once,
+        // src/fft/fft_node.rs:66-67, and the node reuses the plan for every batch)
+        static thread_local std::vector<Cx<double>> w;
+        static thread_local size_t w_n = 0;
+        static thread_local bool w_inv = false;
+        if (w_n != n || w_inv != inverse) {
+            w.resize(n / 2);
+            for (size_t k = 0; k < n / 2; ++k) {
+                double ang = sgn * kTwoPi * static_cast<double>(k) / static_cast<double>(n);
+                w[k] = Cx<double>{std::cos(ang), std::sin(ang)};
+            }
+            w_n = n;
+            w_inv = inverse;
         }
         for (size_t len = 2; len <= n; len <<= 1) {
             size_t half = len / 2, step = n / len;

@@ -23,7 +23,7 @@ while IFS='|' read -r name tmo cmd; do
   echo "   rc=$rc  $(( $(date +%s) - t0 )) s" | tee -a $OUT/summary.txt
   tail -n 6 $OUT/$name.out | cut -c1-600 | tee -a $OUT/summary.txt
   if [ $rc -ne 0 ]; then tail -n 12 $OUT/$name.err | cut -c1-400 | tee -a $OUT/summary.txt; fail=1; fi
-  if [ $rc -eq 124 ] || [ $rc -eq 137 ] || [ $rc -ge 128 ]; then
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ] || { [ $rc -ge 128 ] && [ $rc -ne 141 ]; }; then
     echo "step $name timed out or was killed: stopping the visit" | tee -a $OUT/summary.txt
     exit 1
   fi

@@ -1550,21 +1550,57 @@ def test_config3_every_output_against_the_oracle(c):
     assert float(np.max(dd[mag > 0.5])) <= 1e-4
 
 
+def fm_radio_taps():
+    """The 63 taps examples/fm_radio.rs:30-52 ships (tests/golden/reference_kats.json: data the reference holds)."""
+    import json
+    import pathlib
+
+    g = json.loads((pathlib.Path(__file__).parent / "golden" / "reference_kats.json").read_text())["fm_radio_taps"]
+    taps = np.asarray(g["taps_re"], np.float32).astype(np.complex64)
+    assert taps.size == g["n_taps"] == 63 and g["dec_rate"] == 5
+    return taps
+
+
 def test_fm_radio_example_chain(c):
-    # the literal example chain (examples/fm_radio.rs:144-152): 63-tap FIR -> /5 -> FM demod
-    # -> (re,0) -> 63-tap FIR -> .re -> /5, on a synthetic FM stream
-    t = np.array([-0.01801270027742274, -0.004656920885448867, -0.002648852132912597], np.float32)
-    rng = np.random.default_rng(63)
-    half = np.concatenate([t, rng.uniform(-0.03, 0.03, 28).astype(np.float32)])
-    taps = np.concatenate([half, [np.float32(0.18)], half[::-1]]).astype(np.complex64)
-    assert taps.size == 63
-    x = fm_stream(262144)
-    w = oracle.FM().demod(oracle.decimate(oracle.batch_fir(x, taps, oracle.default_state(taps), norotate=True), 5))
+    # the literal example chain (examples/fm_radio.rs:144-152) with the example's own 63 taps: RTL-SDR bytes ->
+    # (x - 127.5) / 127.5 -> 63-tap FIR -> /5 -> FM demod -> (re, 0) -> 63-tap FIR -> .re -> /5
+    taps = fm_radio_taps()
+    n = 262125  # ~ two of the example's radio blocks (RadioRxNode::new(rtlsdr, 0, 262144): 131072 samples); a multiple of 25,
+    #             since the fused chain node takes whole decimation periods
+    x = fm_stream(n)
+    u8 = np.clip(np.round(np.stack([x.real, x.imag], axis=1) * 127.5 + 127.5), 0, 255).astype(np.uint8)
+    xin = oracle.iq_u8_to_c32(u8)
+    w = oracle.FM().demod(oracle.decimate(oracle.batch_fir(xin, taps, oracle.default_state(taps), norotate=True), 5))
     w2 = oracle.decimate(oracle.batch_fir(w.astype(np.complex64), taps, oracle.default_state(taps), norotate=True).real.copy(), 5)
-    g = c.FMDemodNode().run(c.DecimateNode(5).run(c.BatchFirNode(taps).run(x)))
+    # node by node, as the example wires them (ConvertNode = the u8 conversion, Convert2 / Convert3 = casts)
+    g = c.FMDemodNode().run(c.DecimateNode(5).run(c.BatchFirNode(taps).run(c.iq_u8_to_c32(u8))))
     g2 = c.DecimateNode(5).run(np.ascontiguousarray(c.BatchFirNode(taps).run(g.astype(np.complex64)).real))
-    assert g2.shape == w2.shape
-    assert np.max(np.abs(g2 - w2)) <= 1e-4 * np.sum(np.abs(taps))
+    assert g2.shape == w2.shape == (-(-(-(-n // 5)) // 5),)  # ceil(ceil(n / 5) / 5): decimate keeps sample 0 of every block
+    scale = float(np.sum(np.abs(taps)))
+    assert np.max(np.abs(g2 - w2)) <= 1e-4 * scale
+    # the front half as ONE launch reading the radio's bytes (chain kernel at rate 5, u8 load stage) ...
+    front = c.ChainNode(0.0, 0.0, taps, 5, True)
+    front.set_input_format("u8")
+    gf = front.run(u8)
+    d = np.abs(gf.astype(np.float64) - w)
+    d = np.minimum(d, 2 * np.pi - d)
+    assert gf.shape == w.shape and float(np.median(d)) <= 1e-5 and float(np.max(d)) <= 2e-3
+    # ... and the audio half (real samples through the complex filter, as Convert2 / Convert3 do)
+    g3 = c.DecimateNode(5).run(np.ascontiguousarray(c.BatchFirNode(taps).run(gf.astype(np.complex64)).real))
+    assert np.max(np.abs(g3 - w2)) <= 2e-3 * scale  # (the demodulated angle's last bits pass through a filter of gain ~1)
+    # two blocks in a row keep every state the example's nodes keep (FIR histories, FM.prev; decimation restarts per block)
+    f1, fm, f2 = c.BatchFirNode(taps), c.FMDemodNode(), c.BatchFirNode(taps)
+    got = []
+    cut = 131060  # (a multiple of 5)
+    for blk in (u8[:cut], u8[cut:]):
+        a = fm.run(c.DecimateNode(5).run(f1.run(c.iq_u8_to_c32(blk))))
+        got.append(c.DecimateNode(5).run(np.ascontiguousarray(f2.run(a.astype(np.complex64)).real)))
+    o1, ofm, o2 = oracle.default_state(taps), oracle.FM(), oracle.default_state(taps)
+    want = []
+    for blk in (xin[:cut], xin[cut:]):
+        a = ofm.demod(oracle.decimate(oracle.batch_fir(blk, taps, o1, norotate=True), 5))
+        want.append(oracle.decimate(oracle.batch_fir(a.astype(np.complex64), taps, o2, norotate=True).real.copy(), 5))
+    assert np.max(np.abs(np.concatenate(got) - np.concatenate(want))) <= 1e-4 * scale
 
 
 # ------------------------------------------------------------------ raw IQ wire formats
