@@ -217,6 +217,10 @@ namespace comms {
 // event after hipStreamDestroy intermittently failed with "operation not permitted when stream is capturing".
 COMMS_INTERNAL comms_status_t stream_acquire(int32_t device, hipStream_t* out);
 COMMS_INTERNAL void stream_release(int32_t device, hipStream_t s);
+// Node handles alive per device (the per-thread handles of the handle-less entry points excepted: they only ever
+// follow their own stream).  A handle remembers the last stream it launched on, possibly a pooled one that its owner
+// has since released: comms_stream_pool_trim must not destroy streams while such a handle exists.
+COMMS_INTERNAL void handle_count(int32_t device, int delta);
 
 struct Handle {
     int32_t device = 0;
@@ -262,10 +266,14 @@ struct Handle {
         return KStamp{timer->d_begin + i * kStampSlots, timer->d_end + i * kStampSlots};
     }
 
-    comms_status_t init(int32_t dev) {
+    bool counted = false;
+    comms_status_t init(int32_t dev, bool count_me = true) {
         COMMS_TRY(use_device(dev));
         device = dev;
-        return stream_acquire(dev, &stream);
+        COMMS_TRY(stream_acquire(dev, &stream));
+        counted = count_me;
+        if (counted) handle_count(dev, +1);
+        return COMMS_OK;
     }
     // `stream` arguments of the C ABI are passed through as HIP does: NULL is the
     // legacy default stream; COMMS_STREAM_HANDLE selects the handle's own stream.
@@ -334,6 +342,8 @@ struct Handle {
         pin_out.release();
         if (stream) stream_release(device, stream);
         stream = nullptr;
+        if (counted) handle_count(device, -1);
+        counted = false;
     }
 };
 
@@ -346,7 +356,7 @@ inline comms_status_t thread_handle(int32_t device, Handle** out) {
     if (!tl[device]) {
         Handle* nh = new (std::nothrow) Handle;
         COMMS_ARG(nh != nullptr, "out of host memory");
-        comms_status_t st = nh->init(device);
+        comms_status_t st = nh->init(device, false);
         if (st != COMMS_OK) {
             delete nh;
             return st;

@@ -845,14 +845,14 @@ __global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(In in,
 }
 
 // ---------------------------------------------------------------- overlap-save, F = 16384 (long filters)
-// 2050..4097 taps (config 5).  16384 = 16 x 1024: one 16-wave workgroup owns a segment
-// (12288 new samples + 4096 of halo carried in VGPRs): every lane does a radix-16 over
-// the 1024-strided rows (twiddle W16384^{t*k0}), the 16 k0-slices are exchanged through
-// LDS so that wave k0 holds slice k0, each wave then runs the same barrier-free
+// 1538..4097 taps (config 5).  16384 = 16 x 1024: one 16-wave workgroup owns a segment
+// (16 - HR rows of 1024 new samples + HR halo rows carried in VGPRs): every lane does a radix-16 over
+// the 1024-strided rows, the 16 k0-slices are exchanged through LDS so that wave k0 holds slice k0 (and applies
+// the stage-1 twiddle W16384^{t*k0} there), each wave then runs the same barrier-free
 // 1024-point transform as fir_os1024_kernel on its slice, multiplies by its part of the
-// filter spectrum, and the mirror image brings the samples back.  Three workgroup
-// barriers per segment.  LDS: 16 x 1090 slice buffers + W1024 / W64 / W256 / W16384
-// tables = 158 KiB, one workgroup per CU.
+// filter spectrum, and the mirror image brings the samples back.  No workgroup barrier after set-up: two sets of
+// LDS counters order the two exchanges of a segment (below).  LDS: 16 x 1090 slice buffers + W1024 / W64
+// tables + counters = 158 KiB, one workgroup per CU.
 constexpr int X_BUF = 1090;    // per-wave slice buffer (>= 1088; 2180 dwords = 4 mod 64 banks)
 constexpr size_t X_LDS_BYTES = (1024 + 64 + 16 * X_BUF) * sizeof(float2) + 32 * sizeof(unsigned);  // tables, slices, counters
 #ifndef COMMS_OS16K_CARRY
@@ -875,26 +875,36 @@ struct XTables {
 // shape: every phase ended with the CU idling until its slowest wave arrived, and one of the three
 // (before stage 1's writes) ordered nothing -- thread tid writes exactly the words it has read itself
 // in the previous segment's inverse stage.  All sixteen waves of the workgroup are resident (one
-// workgroup per CU) and run the same number of segments, so every count is reached; the poll is
-// bounded anyway (a miscount would give wrong samples, which the tests see, not a hung GPU).
+// workgroup per CU) and run the same number of segments, so every count is reached.  The poll is bounded all the
+// same (a hung GPU is worse than a failed call): a wave that gives up raises the handle's sticky error word (host-
+// mapped, written at system scope) and goes on; the outputs of that launch are then wrong, and every later entry on
+// the handle -- and the state getters -- return COMMS_ERR_DEVICE until the handle is destroyed.
 __device__ __forceinline__ void x_signal(unsigned* cnt, bool lane_on) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the whole wave's LDS writes first
     if (lane_on) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void x_wait_one(const unsigned* cnt, unsigned target) {
-    for (int spin = 0; spin < (1 << 22); ++spin) {
+__device__ __forceinline__ void x_gave_up(unsigned* err, unsigned code) {
+    if (err && (threadIdx.x & 63) == 0) __hip_atomic_fetch_or(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+constexpr int X_SPINS = 1 << 22;  // x ~100 cycles per poll: a few tenths of a second
+__device__ __forceinline__ void x_wait_one(const unsigned* cnt, unsigned target, unsigned* err) {
+    int spin = 0;
+    for (; spin < X_SPINS; ++spin) {
         const unsigned c = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<int>(c)) - target) >= 0) break;
         __builtin_amdgcn_s_sleep(1);
     }
+    if (spin == X_SPINS) x_gave_up(err, 1u);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-__device__ __forceinline__ void x_wait_all16(const unsigned* cnt, unsigned target, int l) {
-    for (int spin = 0; spin < (1 << 22); ++spin) {
+__device__ __forceinline__ void x_wait_all16(const unsigned* cnt, unsigned target, int l, unsigned* err) {
+    int spin = 0;
+    for (; spin < X_SPINS; ++spin) {
         const unsigned c = __hip_atomic_load(cnt + (l & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (__all(static_cast<int>(c - target) >= 0)) break;
         __builtin_amdgcn_s_sleep(1);
     }
+    if (spin == X_SPINS) x_gave_up(err, 2u);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
@@ -903,7 +913,9 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
                                                             const float2* __restrict__ hist, int hist_len,
                                                             float2* __restrict__ out, size_t n, size_t nseg,
                                                             XTables tb, float2* __restrict__ new_hist, int delay,
-                                                            int accumulate, KStamp ks) {
+                                                            int accumulate, KStamp ks, unsigned* err, int fault) {
+    // err: the handle's sticky error word.  fault (diagnostic build, else 0): workgroup 0's wave 3 withholds one
+    // signal, so that the waits above run out and the error path can be tested.
     kstamp_begin(ks);
     // HR = halo rows of 1024 samples (1 ... 4: up to 1025 / 2049 / 3073 / 4097 taps): a segment keeps 16 - HR rows.
     // (A compile-time value: as a kernel argument the row loops turned into chains of uniform branches and the
@@ -977,7 +989,7 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
         x_signal(slice_in + (l & 15), l < 16);  // one ds_add, sixteen lanes, sixteen counters
         // ---- this wave's slice, once all sixteen waves have delivered their 64 points of it: stage-1 twiddle,
         // 1024-point transform, spectrum multiply, inverse, conjugate twiddle
-        x_wait_one(slice_in + wave, 16u * (done + 1));
+        x_wait_one(slice_in + wave, 16u * (done + 1), err);
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = buf[64 * a + l];
         wave_lds_sync();
@@ -993,12 +1005,12 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
             if (a) y = cmulcf_s(y, sta[a]);
             buf[64 * a + l] = y;
         }
-        x_signal(slice_out + wave, l == 0);
+        x_signal(slice_out + wave, l == 0 && !(fault && blockIdx.x == 0 && wave == 3 && done == 0));
         // (unconditional -- the last segment fetches itself again -- so that `rows` is redefined on every path
         // and its registers are free during the slice work)
         fetch_rows(seg + 1 < seg_hi ? seg + 1 : seg, R0);
         // ---- inverse stage 1: thread tid gathers point tid of every slice, radix-16 back to the rows
-        x_wait_all16(slice_out, done + 1, l);
+        x_wait_all16(slice_out, done + 1, l, err);
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = bufs[k * X_BUF + tid];
         radix16<1>(v);
@@ -1250,6 +1262,7 @@ static void free_fir(comms_fir* h) {
         if (q) (void)hipFree(q);
     if (h->d_hist[0]) (void)hipFree(h->d_hist[0]);
     if (h->d_hist[1]) (void)hipFree(h->d_hist[1]);
+    if (h->err_host) (void)hipHostFree(h->err_host);
     h->fini();
     delete h;
 }
@@ -1503,6 +1516,13 @@ constexpr int X_PART = 4097;  // taps per pass of the 16384-point kernel (halo 4
 
 static comms_status_t fir_prepare_os16k(comms_fir* h) {
     if (h->x_ready) return COMMS_OK;
+    if (!h->err_host) {  // sticky error word: pinned, coherent, mapped -- the kernel raises it, the host reads it without a sync
+        COMMS_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->err_host), 64, hipHostMallocMapped | hipHostMallocCoherent));
+        *h->err_host = 0;
+        void* d = nullptr;
+        COMMS_HIP_TRY(hipHostGetDevicePointer(&d, h->err_host, 0));
+        h->d_err = static_cast<unsigned*>(d);
+    }
     const int N = h->n_eff;
     h->x_part = (N + X_PART - 1) / X_PART;
     std::vector<float2> tw1(16 * 64), tw2(16 * 4), ta(16 * 16), tb(16 * 64), hdev(16 * 1024);
@@ -1597,6 +1617,15 @@ static int fir_pick(const comms_fir* h, size_t n) {
         algo = h->n_eff <= 257 ? COMMS_FIR_OS1024 : big ? COMMS_FIR_OS16K : COMMS_FIR_OS4096;
     }
     return algo;
+}
+
+// A launch of the 16384-point kernel whose LDS waits ran out has raised the handle's error word (fir_os16k_kernel):
+// its outputs are wrong, and so is everything the handle would compute from the state it left.
+static comms_status_t fir_check_sticky(const comms_fir* h) {
+    if (h->err_host && __atomic_load_n(h->err_host, __ATOMIC_RELAXED) != 0)
+        return fail(COMMS_ERR_DEVICE, "fir_os16k_kernel: a workgroup's LDS wait ran out (code %u): the outputs of that call "
+                                      "are invalid and the handle is unusable", *h->err_host);
+    return COMMS_OK;
 }
 
 static comms_status_t fir_upload_state(comms_fir* h, const comms_c32* state, size_t n_state) {
@@ -1756,14 +1785,21 @@ static comms_status_t launch_fixed_hr(int hr, int wpb, size_t runs, hipStream_t 
         default: return launch_os1024<0, 4, In>(wpb, runs, s, in, hist, n_eff, o, n, nseg, tb, nh, ChainArgs{}, ea, eb);
     }
 }
+// diagnostic build: comms_debug_os16k_fault(1) makes the next 16384-point launches withhold one LDS signal
+static std::atomic<int> g_os16k_fault{0};
+static int os16k_fault() { return g_os16k_fault.load(std::memory_order_relaxed); }
+#ifdef COMMS_DIAG
+extern "C" void comms_debug_os16k_fault(int on) { g_os16k_fault.store(on, std::memory_order_relaxed); }
+#endif
 template <class In>
 static void launch_os16k_hr(int hr, unsigned blocks, size_t lds, hipStream_t s, In in, const float2* hist, int n_eff, float2* o, size_t n,
-                            size_t nseg, const XTables& tb, float2* nh, int dl, int acc, KStamp ks) {
+                            size_t nseg, const XTables& tb, float2* nh, int dl, int acc, KStamp ks, unsigned* err) {
+    const int fault = os16k_fault();
     switch (hr) {
-        case 1: fir_os16k_kernel<1, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc, ks); break;
-        case 2: fir_os16k_kernel<2, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc, ks); break;
-        case 3: fir_os16k_kernel<3, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc, ks); break;
-        default: fir_os16k_kernel<4, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc, ks); break;
+        case 1: fir_os16k_kernel<1, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc, ks, err, fault); break;
+        case 2: fir_os16k_kernel<2, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc, ks, err, fault); break;
+        case 3: fir_os16k_kernel<3, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc, ks, err, fault); break;
+        default: fir_os16k_kernel<4, In><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, n_eff, o, n, nseg, tb, nh, dl, acc, ks, err, fault); break;
     }
 }
 template <class In>
@@ -1788,6 +1824,7 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
     COMMS_ARG(!ranges_overlap(d_in, n * in_elem, d_out, n * 8), "FIR cannot run in place");
     COMMS_ARG((reinterpret_cast<uintptr_t>(d_in) & (in_elem - 1)) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 7) == 0,
               "device pointers must be aligned to one sample");
+    COMMS_TRY(fir_check_sticky(h));
     hipStream_t s = nullptr;
     COMMS_TRY(h->enter(stream, &s));
     float2* o = reinterpret_cast<float2*>(d_out);
@@ -1859,11 +1896,11 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
                        reinterpret_cast<const cf*>(h->d_xh[pt])};
             const int dl = pt * X_PART, acc = pt ? 1 : 0;
             if (h->in_fmt == COMMS_IQ_I16)
-                launch_os16k_hr(hr, blocks, lds, s, InI16{static_cast<const short2*>(d_in), h->in_scale}, hist, h->n_eff, o, n, nseg, tb, nh, dl, acc, ks);
+                launch_os16k_hr(hr, blocks, lds, s, InI16{static_cast<const short2*>(d_in), h->in_scale}, hist, h->n_eff, o, n, nseg, tb, nh, dl, acc, ks, h->d_err);
             else if (h->in_fmt == COMMS_IQ_U8)
-                launch_os16k_hr(hr, blocks, lds, s, InU8{static_cast<const uchar2*>(d_in)}, hist, h->n_eff, o, n, nseg, tb, nh, dl, acc, ks);
+                launch_os16k_hr(hr, blocks, lds, s, InU8{static_cast<const uchar2*>(d_in)}, hist, h->n_eff, o, n, nseg, tb, nh, dl, acc, ks, h->d_err);
             else
-                launch_os16k_hr(hr, blocks, lds, s, in, hist, h->n_eff, o, n, nseg, tb, nh, dl, acc, ks);
+                launch_os16k_hr(hr, blocks, lds, s, in, hist, h->n_eff, o, n, nseg, tb, nh, dl, acc, ks, h->d_err);
         }
         h->toc(s);
         COMMS_TRY(launch_ok("fir_os16k_kernel"));
@@ -1925,6 +1962,7 @@ comms_status_t comms_fir_get_state(comms_fir_t* h, comms_c32* state, size_t n_st
     COMMS_ARG(n_state <= static_cast<size_t>(h->n_eff), "n_state %zu exceeds the %d effective taps", n_state, h->n_eff);
     COMMS_TRY(use_device(h->device));
     COMMS_TRY(h->quiesce());  // the history is advanced by the launches, on whatever stream they ran
+    COMMS_TRY(fir_check_sticky(h));
     std::vector<float2> ring(h->n_eff);
     COMMS_HIP_TRY(hipMemcpy(ring.data(), h->d_hist[h->cur], ring.size() * sizeof(float2), hipMemcpyDeviceToHost));
     for (size_t k = 0; k < n_state; ++k) {

@@ -179,6 +179,8 @@ struct comms_fir : comms::Handle {
     // overlap-save, F = 16384 (workgroup per segment), > 2049 taps; partitions of 4097 taps
     bool x_ready = false;
     int x_part = 1;
+    unsigned* err_host = nullptr;  // sticky error word of the 16384-point kernel (pinned host memory) ...
+    unsigned* d_err = nullptr;     //   ... as the device addresses it
     float2* d_xt[4] = {nullptr, nullptr, nullptr, nullptr};  // tw1, tw2, ta, tb
     std::vector<float2*> d_xh;                                // spectrum per partition
     int n_part = 1;      // (4096-pt kernel, forced) > 3841 taps: partitions of OS_PART taps

@@ -71,6 +71,11 @@ comms_status_t stream_acquire(int32_t device, hipStream_t* out) {
     return COMMS_OK;
 }
 
+static std::atomic<long> g_live_handles[64];
+void handle_count(int32_t device, int delta) {
+    if (device >= 0 && device < 64) g_live_handles[device].fetch_add(delta);
+}
+
 void stream_release(int32_t device, hipStream_t s) {
     if (!s || device < 0 || device >= 64) return;
     if (use_device(device) == COMMS_OK) (void)hipStreamSynchronize(s);  // the next owner starts on an idle stream
@@ -378,25 +383,28 @@ comms_status_t comms_stream_destroy(int32_t device, void* stream) {
 comms_status_t comms_stream_pool_trim(int32_t device) {
     COMMS_ARG(device >= 0 && device < 64, "device index out of range");
     DevicePool& p = g_pools[device];
-    COMMS_ARG(p.live_bufs.load() == 0, "%ld comms_buf objects are alive on device %d: release them first",
-              p.live_bufs.load(), device);
-    COMMS_TRY(comms_buf_pool_trim(device));
     std::vector<hipStream_t> streams;
-    {
-        std::lock_guard<std::mutex> lk(comms::g_stream_m);
-        streams.swap(comms::g_free_streams[device]);
-    }
     std::vector<hipEvent_t> events;
     {
-        std::lock_guard<std::mutex> lk(p.m);
+        // the checks and the swaps under both locks: no buffer can be allocated (its events come from this pool) and no
+        // stream handed out between them
+        std::lock_guard<std::mutex> ls(comms::g_stream_m);
+        std::lock_guard<std::mutex> lp(p.m);
+        COMMS_ARG(p.live_bufs.load() == 0, "%ld comms_buf objects are alive on device %d: release them first",
+                  p.live_bufs.load(), device);
+        COMMS_ARG(comms::g_live_handles[device].load() == 0,
+                  "%ld node handles are alive on device %d (a handle may still follow a pooled stream): destroy them first",
+                  comms::g_live_handles[device].load(), device);
+        streams.swap(comms::g_free_streams[device]);
         events.swap(p.free_events);
     }
-    if (streams.empty() && events.empty()) return COMMS_OK;
+    const comms_status_t st = comms_buf_pool_trim(device);
+    if (streams.empty() && events.empty()) return st;
     COMMS_TRY(use_device(device));
     COMMS_HIP_TRY(hipDeviceSynchronize());
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     for (hipStream_t s : streams) (void)hipStreamDestroy(s);
-    return COMMS_OK;
+    return st;
 }
 comms_status_t comms_buf_upload(comms_buf_t* b, size_t offset, const void* host, size_t bytes) {
     COMMS_ARG(b && (host || !bytes), "NULL argument");

@@ -1682,6 +1682,48 @@ def test_device_buf_size_classes_and_limits(c):
         x.release()
 
 
+def test_stream_pool_trim_success_and_refusal_with_live_handles(c):
+    """comms_stream_pool_trim destroys pooled streams: it must refuse while a node handle is alive (the handle may
+    still follow a pooled stream that its owner released -- get_state / destroy would then synchronise a destroyed
+    stream) and succeed once handles and buffers are gone; the library works on afterwards."""
+    import ctypes as C
+    import gc
+
+    import torch
+    from comms_rs_amd._lib import check, lib
+
+    gc.collect()
+    n = 1 << 16
+    x = torch.empty(n, dtype=torch.complex64, device="cuda:0")
+    y = torch.empty_like(x)
+    c.synth_iq_dev(x.data_ptr(), n, 0, 3)
+    streams = []
+    for _ in range(4):
+        sp = C.c_void_p()
+        check(lib().comms_stream_create(0, C.byref(sp)))
+        streams.append(sp)
+    fir = c.BatchFirNode(lowpass_taps(63, 0.1))
+    fir.run_dev(x.data_ptr(), n, y.data_ptr(), streams[0].value)     # the handle now follows a pooled stream ...
+    for sp in streams:
+        check(lib().comms_stream_destroy(0, sp))                      # ... which goes back to the pool
+    with pytest.raises(c.CommsError) as e:
+        check(lib().comms_stream_pool_trim(0))
+    assert e.value.code == c.COMMS_ERR_ARG and "handles" in str(e.value)
+    st = fir.state(63)                                                # drains the released (still existing) stream
+    assert st.shape == (63,)
+    del fir
+    gc.collect()
+    alive = [o for o in gc.get_objects() if type(o).__module__ == "comms_rs_amd.nodes" and getattr(o, "_h", None)]
+    if alive:
+        pytest.skip("other node handles of this process are alive: %d" % len(alive))
+    check(lib().comms_stream_pool_trim(0))                            # the success path
+    check(lib().comms_stream_pool_trim(0))                            # idempotent on an empty pool
+    fir2 = c.BatchFirNode(lowpass_taps(63, 0.1))                      # new streams are created on demand
+    got = fir2.run(c.synth_iq(4096, 0, 3))
+    want = oracle.batch_fir(c.synth_iq(4096, 0, 3), lowpass_taps(63, 0.1), oracle.default_state(lowpass_taps(63, 0.1)), norotate=True)
+    assert np.max(np.abs(got - want)) <= TOL * np.sum(np.abs(lowpass_taps(63, 0.1)))
+
+
 def test_handles_create_destroy_many_times(c):
     """Handle life cycle: thousands of create / run / destroy cycles of every node type neither leak
     device memory nor break later launches (each FIR / FFT handle owns streams, tables, scratch)."""
