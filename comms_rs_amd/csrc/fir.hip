@@ -854,7 +854,7 @@ __global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(In in,
 // LDS counters order the two exchanges of a segment (below).  LDS: 16 x 1090 slice buffers + W1024 / W64
 // tables + counters = 158 KiB, one workgroup per CU.
 constexpr int X_BUF = 1090;    // per-wave slice buffer (>= 1088; 2180 dwords = 4 mod 64 banks)
-constexpr size_t X_LDS_BYTES = (1024 + 64 + 16 * X_BUF) * sizeof(float2) + 32 * sizeof(unsigned);  // tables, slices, counters
+constexpr size_t X_LDS_BYTES = (1024 + 64 + 16 * X_BUF) * sizeof(float2) + 32 * sizeof(unsigned) + 3 * sizeof(unsigned long long);  // tables, slices, counters, aux
 #ifndef COMMS_OS16K_CARRY
 #define COMMS_OS16K_CARRY 1  // the four halo rows of a segment stay in registers from the previous one
 #endif
@@ -883,29 +883,46 @@ __device__ __forceinline__ void x_signal(unsigned* cnt, bool lane_on) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the whole wave's LDS writes first
     if (lane_on) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void x_gave_up(unsigned* err, unsigned code) {
-    if (err && (threadIdx.x & 63) == 0) __hip_atomic_fetch_or(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
+// (aux: three 64-bit words in LDS -- [0] the stamp timer's end slots and [1] the error word's address, written once by
+// thread 0, [2] the workgroup's give-up code.  A wave whose wait runs out only ORs its code into aux[2]; every wave
+// looks at that word once, when it ends, and the one that finds it set raises the host-mapped error word.  Kept out of
+// the wait loops and out of SGPRs: with the raise itself -- a 64-bit address and a system-scope atomic -- behind each
+// wait the kernel ran 6 % slower (614 against 579 us at 2^27 samples, scripts/ab_libs.py on five builds), and the kernel
+// sits at the scalar-register limit.)
 constexpr int X_SPINS = 1 << 22;  // x ~100 cycles per poll: a few tenths of a second
-__device__ __forceinline__ void x_wait_one(const unsigned* cnt, unsigned target, unsigned* err) {
-    int spin = 0;
-    for (; spin < X_SPINS; ++spin) {
+__device__ __forceinline__ void x_wait_one(const unsigned* cnt, unsigned target, unsigned* gave_up) {
+    bool ok = false;
+    for (int spin = 0; spin < X_SPINS; ++spin) {
         const unsigned c = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<int>(c)) - target) >= 0) break;
+        if (static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<int>(c)) - target) >= 0) {
+            ok = true;
+            break;
+        }
         __builtin_amdgcn_s_sleep(1);
     }
-    if (spin == X_SPINS) x_gave_up(err, 1u);
+    if (!ok) __hip_atomic_fetch_or(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-__device__ __forceinline__ void x_wait_all16(const unsigned* cnt, unsigned target, int l, unsigned* err) {
-    int spin = 0;
-    for (; spin < X_SPINS; ++spin) {
+__device__ __forceinline__ void x_wait_all16(const unsigned* cnt, unsigned target, int l, unsigned* gave_up) {
+    bool ok = false;
+    for (int spin = 0; spin < X_SPINS; ++spin) {
         const unsigned c = __hip_atomic_load(cnt + (l & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (__all(static_cast<int>(c - target) >= 0)) break;
+        if (__all(static_cast<int>(c - target) >= 0)) {
+            ok = true;
+            break;
+        }
         __builtin_amdgcn_s_sleep(1);
     }
-    if (spin == X_SPINS) x_gave_up(err, 2u);
+    if (!ok) __hip_atomic_fetch_or(gave_up, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// at a wave's end: report what any wait of the workgroup gave up on
+__device__ __forceinline__ void x_report(const unsigned long long* aux) {
+#ifndef COMMS_OS16K_NO_ERR
+    const unsigned code = static_cast<unsigned>(aux[2]);
+    unsigned* err = reinterpret_cast<unsigned*>(aux[1]);
+    if (code && err && (threadIdx.x & 63) == 0) __hip_atomic_fetch_or(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
 }
 
 template <int HR, class In = const float2*>
@@ -916,7 +933,9 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
                                                             int accumulate, KStamp ks, unsigned* err, int fault) {
     // err: the handle's sticky error word.  fault (diagnostic build, else 0): workgroup 0's wave 3 withholds one
     // signal, so that the waits above run out and the error path can be tested.
+#ifndef COMMS_OS16K_NO_STAMP
     kstamp_begin(ks);
+#endif
     // HR = halo rows of 1024 samples (1 ... 4: up to 1025 / 2049 / 3073 / 4097 taps): a segment keeps 16 - HR rows.
     // (A compile-time value: as a kernel argument the row loops turned into chains of uniform branches and the
     // kernel lost 11 % -- 591 -> 658 us at 2^27 samples, 4097 taps.)
@@ -928,9 +947,17 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
     const size_t xv = static_cast<size_t>(16 - hr) * 1024;  // new samples per segment
     unsigned* slice_in = reinterpret_cast<unsigned*>(bufs + 16 * X_BUF);  // [16]
     unsigned* slice_out = slice_in + 16;                                   // [16]
+    unsigned long long* aux = reinterpret_cast<unsigned long long*>(slice_in + 32);  // [3], see x_wait_one
+    unsigned* gave_up = reinterpret_cast<unsigned*>(aux + 2);
     const int tid = threadIdx.x;
     const int l = tid & 63, wave = tid >> 6;
     cf* buf = bufs + wave * X_BUF;
+    if (tid == 0) {
+        aux[0] = reinterpret_cast<unsigned long long>(ks.end);
+        aux[1] = reinterpret_cast<unsigned long long>(err);
+        aux[2] = 0;
+    }
+    const bool withhold = fault != 0 && blockIdx.x == 0 && wave == 3;
     if (!accumulate) hist_advance(hist, in, n, new_hist, hist_len);
     tw1[tid] = tb.tw1[tid];
     if (tid < 64) tw2[tid] = tb.tw2[tid];
@@ -947,7 +974,10 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
     const cf lane_tw = tb.tb[wave * 64 + l];
     __syncthreads();  // tables and counters: the only barrier of the launch
 
-    // workgroup g of the persistent grid owns segments [g*nseg/G, (g+1)*nseg/G)
+    // workgroup g of the persistent grid owns segments [g*nseg/G, (g+1)*nseg/G).  (Round-robin chunks of 1 ... 16 segments,
+    // what the 1024-point ticketed kernel gains from, LOSE here: 625 -> 650 ... 696 us at 2^27 samples -- a chunk's first
+    // segment reads its four halo rows again, and sixteen rows of 8 KiB per segment are long runs already;
+    // profiles/r04_probe_chunks.txt.)
     const size_t seg_lo = static_cast<size_t>(blockIdx.x) * nseg / gridDim.x;
     const size_t seg_hi = static_cast<size_t>(blockIdx.x + 1) * nseg / gridDim.x;
     // The new rows of a segment are requested one phase ahead -- between the slice work and the inverse stage 1 of the
@@ -989,7 +1019,7 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
         x_signal(slice_in + (l & 15), l < 16);  // one ds_add, sixteen lanes, sixteen counters
         // ---- this wave's slice, once all sixteen waves have delivered their 64 points of it: stage-1 twiddle,
         // 1024-point transform, spectrum multiply, inverse, conjugate twiddle
-        x_wait_one(slice_in + wave, 16u * (done + 1), err);
+        x_wait_one(slice_in + wave, 16u * (done + 1), gave_up);
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = buf[64 * a + l];
         wave_lds_sync();
@@ -1005,12 +1035,12 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
             if (a) y = cmulcf_s(y, sta[a]);
             buf[64 * a + l] = y;
         }
-        x_signal(slice_out + wave, l == 0 && !(fault && blockIdx.x == 0 && wave == 3 && done == 0));
+        x_signal(slice_out + wave, l == 0 && !(withhold && done == 0));
         // (unconditional -- the last segment fetches itself again -- so that `rows` is redefined on every path
         // and its registers are free during the slice work)
         fetch_rows(seg + 1 < seg_hi ? seg + 1 : seg, R0);
         // ---- inverse stage 1: thread tid gathers point tid of every slice, radix-16 back to the rows
-        x_wait_all16(slice_out, done + 1, l, err);
+        x_wait_all16(slice_out, done + 1, l, gave_up);
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = bufs[k * X_BUF + tid];
         radix16<1>(v);
@@ -1025,7 +1055,10 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
             __builtin_amdgcn_raw_buffer_store_b64(bv2u{__float_as_uint(y.x), __float_as_uint(y.y)}, ors, tid * 8, row, 0);
         }
     }
-    kstamp_end(ks);
+    x_report(aux);
+#ifndef COMMS_OS16K_NO_STAMP
+    kstamp_end(KStamp{nullptr, reinterpret_cast<unsigned long long*>(aux[0])});
+#endif
 }
 
 // ---------------------------------------------------------------- pulse shaping (polyphase)

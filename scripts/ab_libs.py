@@ -1,14 +1,15 @@
-"""A/B timing of two builds of the library in ONE process, launch by launch (FIR node; ALGO=os1024|os4096|os16k|direct|auto).
-usage: python scripts/ab_libs.py <libA.so> <libB.so> [n_taps] [log2 n] [reps]"""
+"""A/B timing of two or more builds of the library in ONE process, launch by launch (FIR node; ALGO=os1024|os4096|os16k|direct|auto).
+usage: python scripts/ab_libs.py <libA.so> <libB.so> [more.so ...] [n_taps] [log2 n] [reps]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import comms_rs_amd as c  # synthetic input + taps from the default build
 
-paths = sys.argv[1:3]
-n_taps = int(sys.argv[3]) if len(sys.argv) > 3 else 255
-n = 1 << (int(sys.argv[4]) if len(sys.argv) > 4 else 24)
-reps = int(sys.argv[5]) if len(sys.argv) > 5 else 300
+paths = [a for a in sys.argv[1:] if a.endswith(".so")]
+nums = [a for a in sys.argv[1:] if not a.endswith(".so")]
+n_taps = int(nums[0]) if len(nums) > 0 else 255
+n = 1 << (int(nums[1]) if len(nums) > 1 else 24)
+reps = int(nums[2]) if len(nums) > 2 else 300
 x = torch.empty(n, dtype=torch.complex64, device="cuda:0"); y = torch.empty_like(x)
 c.synth_iq_dev(x.data_ptr(), n, 0)
 taps = np.ascontiguousarray(c.rrc_taps(n_taps, 8.0, 0.35))
@@ -25,7 +26,8 @@ for p in paths:
     hs.append((l, h))
 run = lambda i: hs[i][0].comms_fir_run_dev(hs[i][1], x.data_ptr(), n, y.data_ptr(), s)
 for _ in range(20):
-    run(0); run(1)
+    for i in range(len(paths)):
+        run(i)
 ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)] for _ in paths]
 for r in range(reps):
     for i in range(len(paths)):
