@@ -995,12 +995,12 @@ def run_config4(ctx):
         rt = float((back / FFT_N - xt).abs().max())
         ok = ok and abs(ey / (FFT_N * ex) - 1.0) < 1e-5 and rt < 2e-5
     ctx.all_ok(ok, "config 4: Parseval / round trip")
-    timer = c.KernelTimer(max(args.steps, 1), device=ctx.local_rank).attach(fwd)
     for _ in range(args.warmup):
         fwd.run_dev(x.data_ptr(), n, y.data_ptr(), s)
-    timer.reset()
+    # (every call bracketed: an event pair's ~11 us are nothing against a 27-ms call)
+    timer = c.KernelTimer(max(args.steps, 1), device=ctx.local_rank, stamps="both").attach(fwd)
     elapsed = ctx.timed(lambda: fwd.run_dev(x.data_ptr(), n, y.data_ptr(), s), args.steps, 0)
-    kms = timer.read_ms()
+    kms, sms = kernel_times(timer)
     timer.close()
     ctx.collect(y, transfer)
     kernel_ms = float(np.mean(kms))
@@ -1018,7 +1018,8 @@ def run_config4(ctx):
            "roofline": {"bound": "hbm", "kernel": "fft1024x16_kernel (two passes; the timer brackets both)",
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                         "traffic": pmc_traffic("fft1024x16_kernel", n), "kernel_ms": round(kernel_ms, 5),
-                        "launches_timed": int(kms.size), "algorithmic_bytes_per_launch": FFT_BYTES_PER_POINT * n}}
+                        "launches_timed": int(kms.size), "timer_stride": 1, **in_stream_fields(sms),
+                        "algorithmic_bytes_per_launch": FFT_BYTES_PER_POINT * n}}
     res["world_size_seen"], res["ranks"] = ranks["world_size_seen"], ranks
     if transfer:
         res["transfer"] = transfer
@@ -1096,7 +1097,7 @@ def run_config1(ctx):
                                   "per GPU and step, one launch" % (int(np.log2(nsym)), int(np.log2(n))),
                       "output_samples_per_gpu_per_step": n, "n_taps": 63, "sam_per_sym": 4, "kernel": "pulse_poly_kernel<4,real,MIX>"},
            "roofline": {"bound": "hbm", "kernel": "pulse_poly_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("pulse_poly_kernel", n),
                         "kernel_ms": round(kernel_ms, 5), "launches_timed": int(kms.size), "timer_stride": 1,
                         **in_stream_fields(sms), "algorithmic_bytes_per_launch": bytes_per_out * n,
                         "note": "2^20 outputs are 10.5 MB: at this size the launch is latency-bound (the same kernel at "

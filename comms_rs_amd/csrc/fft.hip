@@ -45,6 +45,8 @@ struct FftTileParams {
     int apply_tw;                    // four-step pass 1: times W_N^{(tile*C + c) * k}
     const cf* tw_lo;             // W_N^e, e < 4096
     const cf* tw_hi;             // W_N^{4096 e}
+    KStamp ks;                   // in-kernel begin / end stamps of a stamps timer (both passes of a call stamp the same
+                                 // slots: first pass in to second pass out), or null
 };
 
 // The generic tile kernel keeps plain C++ complex arithmetic (the compiler schedules
@@ -222,6 +224,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void fft1024x16_kernel(c
     const int l = tid & 63, wave = tid >> 6;
     const int q0 = l & 15, q1 = l >> 4;
     cf* buf = bufs + wave * FW_BUF;
+    kstamp_begin(p.ks);
     for (int i = tid; i < 1024; i += 64 * NW) tw1[i] = tw1g[i];
     if (tid < 64) tw2[tid] = tw2g[tid];
 
@@ -355,6 +358,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void fft1024x16_kernel(c
             }
         }
     }
+    kstamp_end(p.ks);
 }
 
 // ---------------------------------------------------------------- N = RAD * 1024 in ONE pass (RAD = 1, 2, 4, 8, 16)
@@ -808,8 +812,9 @@ template <int DIR, int KIND>
 __global__ __launch_bounds__(1024, 4) void fft_cols_kernel(const cf* in, cf* out, size_t n_tiles, unsigned N,
                                                            const cf* __restrict__ tw1g, const cf* __restrict__ tw2g,
                                                            const cf* __restrict__ twrg, const cf* __restrict__ tw_lo,
-                                                           const cf* __restrict__ tw_hi) {
+                                                           const cf* __restrict__ tw_hi, KStamp ks) {
     using G = ColGeom<KIND>;
+    kstamp_begin(ks);
     constexpr int C = G::C, TPW = G::TPW, BUF = G::BUF, SLOT = G::SLOT, N1 = G::N1;
     constexpr bool C64 = G::C64, C256 = G::C256, PRE2 = G::PRE2;
     constexpr int C16N = G::C16N;
@@ -905,6 +910,7 @@ __global__ __launch_bounds__(1024, 4) void fft_cols_kernel(const cf* in, cf* out
             dst[k1 * 1024u + c] = x;
         }
     }
+    kstamp_end(ks);
 }
 
 // ---------------------------------------------------------------- N = 2^21 ... 2^24: third launch
@@ -1456,9 +1462,9 @@ static comms_status_t launch_cols(Pow2Plan& pl, const float2* src, float2* dst, 
     const cf* tr = reinterpret_cast<const cf*>(pl.d_colr);
     const FftTileParams& p = pl.pass[0];
     if (inverse)
-        fft_cols_kernel<1, KIND><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, n_tiles, static_cast<unsigned>(pl.N), t1, t2, tr, p.tw_lo, p.tw_hi);
+        fft_cols_kernel<1, KIND><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, n_tiles, static_cast<unsigned>(pl.N), t1, t2, tr, p.tw_lo, p.tw_hi, p.ks);
     else
-        fft_cols_kernel<-1, KIND><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, n_tiles, static_cast<unsigned>(pl.N), t1, t2, tr, p.tw_lo, p.tw_hi);
+        fft_cols_kernel<-1, KIND><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, n_tiles, static_cast<unsigned>(pl.N), t1, t2, tr, p.tw_lo, p.tw_hi, p.ks);
     return launch_ok("fft_cols_kernel");
 }
 
@@ -1485,7 +1491,10 @@ static comms_status_t run_rx(Pow2Plan& pl, const float2* in, float2* out, size_t
 }
 
 static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size_t batch,
-                               bool inverse, hipStream_t s, float2* scratch) {
+                               bool inverse, hipStream_t s, float2* scratch, KStamp ks = KStamp{nullptr, nullptr}) {
+    // only the four-step passes of N = 2^15 ... 2^20 stamp (both of them: the call from its first workgroup in to its last
+    // wave out); the column pass of the larger lengths does not, so those stay unstamped altogether
+    pl.pass[0].ks = pl.pass[1].ks = pl.rows ? KStamp{nullptr, nullptr} : ks;
     static const bool no_rx = [] {
         const char* v = getenv("COMMS_FFT_NO_RX");
         return v && *v && *v != '0';
@@ -1746,9 +1755,10 @@ comms_status_t comms_fft_run_dev(comms_fft_t* h, const comms_c32* d_in, size_t n
         COMMS_TRY(h->work.reserve(group * h->N * sizeof(float2)));
         float2* scratch = static_cast<float2*>(h->work.p);
         h->tic(s);
+        const KStamp ks = h->next_stamp();
         for (size_t b0 = 0; b0 < batch; b0 += group) {
             const size_t nb = batch - b0 < group ? batch - b0 : group;
-            COMMS_TRY(pow2_run(h->plan, in + b0 * h->N, o + b0 * h->N, nb, h->inverse, s, scratch));
+            COMMS_TRY(pow2_run(h->plan, in + b0 * h->N, o + b0 * h->N, nb, h->inverse, s, scratch, ks));
         }
         h->toc(s);
         return COMMS_OK;

@@ -285,7 +285,10 @@ class MixerNode(_Handle):
         check(lib().comms_mixer_create(float(dphase), 0.0 if phase is None else float(phase), device, C.byref(self._h)))
 
     def run(self, x):
-        """Complex<f32> samples -> MixerNode<f32>; complex128 input -> MixerNode<f64> (Complex<f64> out)."""
+        """Complex<f32> samples -> MixerNode<f32>; a numpy complex128 array (or scalar) -> MixerNode<f64>, Complex<f64>
+        out: the sample type follows the input's dtype, as the reference's generic `MixerNode<T>` (mixer.rs:93) -- note that
+        numpy's DEFAULT complex dtype is complex128.  Lists, Python scalars and every other dtype are converted to
+        complex64 (tests/test_gpu_parity.py::test_mixer_run_dtype_follows_the_input_dtype pins this)."""
         scalar = np.ndim(x) == 0
         if isinstance(x, (np.ndarray, np.generic)) and x.dtype == np.complex128:
             a = np.ascontiguousarray(np.atleast_1d(x), dtype=np.complex128)

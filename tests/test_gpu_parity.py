@@ -675,6 +675,21 @@ def test_mixer_f64_device_resident_in_place_and_alignment(c):
         node.run_f64_dev(x.data_ptr() + 8, 4, x.data_ptr() + 8, s)
 
 
+def test_mixer_run_dtype_follows_the_input_dtype(c):
+    """MixerNode.run instantiates the node on the input's sample type, as the reference's generic `MixerNode<T>` does:
+    complex64 in -> MixerNode<f32> (complex64 out), complex128 in -> MixerNode<f64> (complex128 out, the reference's own
+    test type).  Anything that is not a numpy complex128 array -- lists, Python complex scalars, other dtypes -- is
+    converted to complex64, the type every BASELINE config runs on."""
+    x64 = np.array([1 + 2j, 3 - 4j], np.complex64)
+    assert c.MixerNode(0.3).run(x64).dtype == np.complex64
+    assert c.MixerNode(0.3).run(x64.astype(np.complex128)).dtype == np.complex128
+    assert c.MixerNode(0.3).run([1 + 2j, 3 - 4j]).dtype == np.complex64
+    assert c.MixerNode(0.3).run(np.array([1.0, 2.0], np.float32)).dtype == np.complex64
+    assert np.asarray(c.MixerNode(0.3).run(1 + 2j)).dtype == np.complex64
+    a, b = c.MixerNode(0.3, 0.1).run(x64), c.MixerNode(0.3, 0.1).run(x64.astype(np.complex128))
+    assert np.max(np.abs(a - b)) <= 1e-6 * np.max(np.abs(b))
+
+
 @pytest.mark.parametrize("dphase,phase", [(0.123, 0.0), (2 * np.pi * 0.1, 0.0), (5.9, 1.0), (-0.4, 7.5), (0.0, -3.0), (40.0, 0.5)])
 def test_mixer_vs_oracle(c, dphase, phase):
     rng = np.random.default_rng(int(abs(dphase) * 1000) + 3)
