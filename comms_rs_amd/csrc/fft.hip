@@ -26,6 +26,7 @@
 
 #include "common.hpp"
 #include "fft_radix.hpp"
+#include "fir_handle.hpp"  // make_rsrc: buffer-addressed rows
 
 namespace comms {
 
@@ -782,6 +783,150 @@ __global__ __launch_bounds__(1024, 4) void fft_rx1024_kernel(const cf* in, cf* o
     }
 }
 
+// ---------------------------------------------------------------- N = 32768 in ONE pass (round 4)
+// 32768 = 32 x 1024 does not fit the tile (16384 points of LDS), but it fits the workgroup: a thread holds column
+// n2 = tid of all 32 rows in registers (64 VGPRs), does the radix-32 over n1 there (a radix-2 split into two
+// radix-16: Y[2q] = DFT16(x[r] + x[r+16]), Y[2q+1] = DFT16((x[r] - x[r+16]) W32^r)), and the 32 rows k1 then pass
+// through the sixteen wave buffers in TWO phases of sixteen rows (k1 = 0 ... 15, then 16 ... 31): times W_N^{n2 k1}, into
+// the buffer of wave k1 % 16, the barrier-free 1024-point wave transform, coalesced store of X[k1 + 32 k2] -- 128-byte
+// pieces (sixteen adjacent k1) at a stride of 256 B, the other half of every 256 B following in the second phase.
+// The twiddle W_N^{n2 k1} is a product of at most five of p1, p2, p4, p8, p16 = W_N^{n2 2^i}; n2 = tid is the same for
+// every tile of the launch, so p1, p4, p16 are three table values per thread for the whole launch (p2, p8 one squaring
+// each): no twiddle table in LDS at all.  Once the second phase's rows are in LDS all 64 data registers are free and
+// the next transform's 32 rows are requested there, in two halves behind the second wave transform and its store.
+// One HBM read and one write per point where the four-step form (fft_cols_kernel<32> + a row pass) moved 32 B/point
+// and its 16-point column form spent half of its LDS cycles in bank conflicts (profiles/r03_lds_conflicts.txt).
+constexpr int R32_BUF = 1090;  // 2180 dwords = 4 (mod 64 banks): the store's lanes (k1 % 16, k2) read conflict-free
+constexpr size_t R32_LDS = (1024 + 64 + 16 * R32_BUF) * sizeof(float2);
+
+template <int R>
+__device__ __forceinline__ cf w32() {  // forward W32^R = (cos(2 pi R / 32), -sin(2 pi R / 32)), R = 1 ... 15
+    constexpr float C[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                             0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f,
+                             0.0f, -0.19509032201612826785f, -0.38268343236508977173f, -0.55557023301960222474f,
+                             -0.70710678118654752440f, -0.83146961230254523708f, -0.92387953251128675613f, -0.98078528040323044913f};
+    constexpr float S[16] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
+                             0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f,
+                             1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                             0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
+    return cf{C[R], -S[R]};
+}
+// W_N^{n2 K}: the factors of K's set bits, folded from the highest down (common prefixes are shared between the rows)
+template <int K>
+__device__ __forceinline__ cf r32_tw(const cf (&p)[5]) {
+    static_assert(K >= 1 && K < 32, "row 1 ... 31");
+    constexpr int HI = K >= 16 ? 4 : K >= 8 ? 3 : K >= 4 ? 2 : K >= 2 ? 1 : 0;
+    constexpr int REST = K - (1 << HI);
+    if constexpr (REST == 0) {
+        return p[HI];
+    } else {
+        constexpr int LOW = (REST & -REST);                  // lowest set bit of the rest
+        constexpr int LB = LOW == 1 ? 0 : LOW == 2 ? 1 : LOW == 4 ? 2 : 3;
+        if constexpr (REST == LOW) return cmulf(p[HI], p[LB]);
+        else return cmulf(r32_tw<K - LOW>(p), p[LB]);
+    }
+}
+
+template <int DIR>
+__global__ __launch_bounds__(1024, 4) void fft_rx32k_kernel(const cf* in, cf* out, size_t n_tiles, const cf* __restrict__ tw1g,
+                                                            const cf* __restrict__ tw2g, const cf* __restrict__ twtg, KStamp ks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* tw1 = reinterpret_cast<cf*>(smem);  // [16][64]  W1024^{lane*k0}
+    cf* tw2 = tw1 + 1024;                   // [16][4]   W64^{c*k1}
+    cf* bufs = tw2 + 64;                    // [16][R32_BUF]
+    const int tid = threadIdx.x;
+    const int l = tid & 63, wave = tid >> 6;
+    const int q0 = l & 15, q1 = l >> 4;
+    cf* buf = bufs + wave * R32_BUF;
+    kstamp_begin(ks);
+    tw1[tid] = tw1g[tid];
+    if (tid < 64) tw2[tid] = tw2g[tid];
+    cf pw[5];  // W_N^{tid}, ^2, ^4, ^8, ^16 (forward sign; tw_mul<DIR> conjugates for the inverse)
+    pw[0] = twtg[tid];
+    pw[2] = twtg[1024 + tid];
+    pw[4] = twtg[2048 + tid];
+    pw[1] = cmulf(pw[0], pw[0]);
+    pw[3] = cmulf(pw[2], pw[2]);
+
+    cf pre[32];
+    auto fetch = [&](size_t tix, int half) {  // rows of 8 KiB: one resource, one per-lane offset, the row in the scalar offset
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + tix * 32768u, 32768u * sizeof(cf));
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const bv2u x = __builtin_amdgcn_raw_buffer_load_b64(rs, tid * 8, (16 * half + a) * 8192, 0);
+            pre[16 * half + a] = cf{__uint_as_float(x.x), __uint_as_float(x.y)};
+        }
+    };
+    // one phase: rows k1 = 16 P + j through the wave buffers and out
+    auto store_phase = [&](size_t tix, int phase) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(out + tix * 32768u, 32768u * sizeof(cf));
+        const unsigned j = static_cast<unsigned>(tid) & 15u, kk = static_cast<unsigned>(tid) >> 4;
+        const cf* src = bufs + j * R32_BUF;
+        const unsigned voff = (j + 32u * kk) * 8u;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const unsigned k2 = kk + 64u * u;
+            const cf x = src[k2 + (k2 >> 4)];
+            __builtin_amdgcn_raw_buffer_store_b64(bv2u{__float_as_uint(x.x), __float_as_uint(x.y)}, rs, voff,
+                                                  (16 * phase + 32 * 64 * u) * 8, 0);
+        }
+    };
+    if (blockIdx.x < n_tiles) {
+        fetch(blockIdx.x, 0);
+        fetch(blockIdx.x, 1);
+    }
+    for (size_t tix = blockIdx.x; tix < n_tiles; tix += gridDim.x) {
+        // ---- radix-32 over the rows: u -> even k1, w -> odd k1
+        cf u[16], w[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            u[r] = cadd(pre[r], pre[r + 16]);
+            w[r] = csub(pre[r], pre[r + 16]);
+        }
+#define COMMS_R32_TW(R) w[R] = tw_mul_s<DIR>(w[R], w32<R>());
+        COMMS_R32_TW(1) COMMS_R32_TW(2) COMMS_R32_TW(3) COMMS_R32_TW(4) COMMS_R32_TW(5) COMMS_R32_TW(6) COMMS_R32_TW(7)
+        COMMS_R32_TW(8) COMMS_R32_TW(9) COMMS_R32_TW(10) COMMS_R32_TW(11) COMMS_R32_TW(12) COMMS_R32_TW(13) COMMS_R32_TW(14)
+        COMMS_R32_TW(15)
+#undef COMMS_R32_TW
+        radix16<DIR>(u);
+        radix16<DIR>(w);
+        __syncthreads();  // the previous transform's second store has read the buffers (and the tables are in place)
+        // ---- phase 0: rows k1 = j = 2 q + p, q = 0 ... 7
+#define COMMS_R32_ROW(K, J)                                                        \
+    {                                                                              \
+        cf y = ((K) & 1) ? w[R16_POS((K) >> 1)] : u[R16_POS((K) >> 1)];             \
+        y = tw_mul<DIR>(y, r32_tw<K>(pw));                                         \
+        bufs[(J) * R32_BUF + tid] = y;                                             \
+    }
+        bufs[tid] = u[R16_POS(0)];  // k1 = 0: no twiddle
+        COMMS_R32_ROW(1, 1) COMMS_R32_ROW(2, 2) COMMS_R32_ROW(3, 3) COMMS_R32_ROW(4, 4) COMMS_R32_ROW(5, 5) COMMS_R32_ROW(6, 6)
+        COMMS_R32_ROW(7, 7) COMMS_R32_ROW(8, 8) COMMS_R32_ROW(9, 9) COMMS_R32_ROW(10, 10) COMMS_R32_ROW(11, 11) COMMS_R32_ROW(12, 12)
+        COMMS_R32_ROW(13, 13) COMMS_R32_ROW(14, 14) COMMS_R32_ROW(15, 15)
+        __syncthreads();
+        rx_wave_core<DIR, false, false, 0>(buf, tw1, tw2, l, q0, q1);
+        __syncthreads();
+        store_phase(tix, 0);
+        __syncthreads();
+        // ---- phase 1: rows k1 = 16 + j
+        COMMS_R32_ROW(16, 0) COMMS_R32_ROW(17, 1) COMMS_R32_ROW(18, 2) COMMS_R32_ROW(19, 3) COMMS_R32_ROW(20, 4) COMMS_R32_ROW(21, 5)
+        COMMS_R32_ROW(22, 6) COMMS_R32_ROW(23, 7) COMMS_R32_ROW(24, 8) COMMS_R32_ROW(25, 9) COMMS_R32_ROW(26, 10) COMMS_R32_ROW(27, 11)
+        COMMS_R32_ROW(28, 12) COMMS_R32_ROW(29, 13) COMMS_R32_ROW(30, 14) COMMS_R32_ROW(31, 15)
+#undef COMMS_R32_ROW
+        __syncthreads();
+        // all 64 data registers are free from here on: the next transform's rows are requested in two halves, the first
+        // behind the wave transform (which needs ~60 registers itself), the second behind the store
+        // (unconditional -- the last transform fetches itself again -- so that `pre` is redefined on every path: a
+        // conditional fetch keeps the old values alive through the wave transform, and they spill)
+        const size_t nxt = tix + gridDim.x < n_tiles ? tix + gridDim.x : tix;
+        fetch(nxt, 0);
+        rx_wave_core<DIR, false, false, 0>(buf, tw1, tw2, l, q0, q1);
+        __syncthreads();
+        fetch(nxt, 1);
+        store_phase(tix, 1);
+    }
+    kstamp_end(ks);
+}
+
 // ---------------------------------------------------------------- four-step pass 1 for N = N1 * 1024, N1 = 64 ... 512
 // Column transforms of length N1 (stride 1024) for all 1024 columns, times W_N^{n2*k1}, in place
 // positions.  A 16-wave workgroup owns all N1 rows of C = 16384/N1 adjacent columns (runs of
@@ -1063,6 +1208,7 @@ struct Pow2Plan {
     int rx_rad = 0;           // N = rx_rad * 1024 (2, 4, 8, 16): single-pass fft_rx1024_kernel
     float2* d_rxa = nullptr;  //   W_N^{64*wave*k1} [rad][16]
     float2* d_rxb = nullptr;  //   W_N^{lane*k1}    [rad][64]
+    float2* d_rx32 = nullptr;  // N = 32768 in one pass (fft_rx32k_kernel): W_N^{t}, W_N^{4 t}, W_N^{16 t}, t < 1024
     int col_kind = -1;         // four-step pass 1 on fft_cols_kernel: 0 (N1 = 64), 128, 256, 512; -1: tile kernel
     float2* d_colw1 = nullptr; //   the core's stage table (W256^{b*ka} for the 256-point form, else unused)
     float2* d_colr = nullptr;  //   W_N1^{r}, r < N1/2 (radix-2 front stage of 128 / 512)
@@ -1087,7 +1233,8 @@ struct Pow2Plan {
         if (d_rxb) (void)hipFree(d_rxb);
         if (d_colw1) (void)hipFree(d_colw1);
         if (d_colr) (void)hipFree(d_colr);
-        d_fw1 = d_fw2 = d_rxa = d_rxb = d_colw1 = d_colr = nullptr;
+        if (d_rx32) (void)hipFree(d_rx32);
+        d_fw1 = d_fw2 = d_rxa = d_rxb = d_colw1 = d_colr = d_rx32 = nullptr;
     }
     bool fast(int i) const { return pass[i].L == 1024 && (pass[i].C == 16 || pass[i].C == 8) && d_fw1 != nullptr; }
 };
@@ -1306,7 +1453,9 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
         }
     }
     if (pl.n_pass == 2 && pl.pass[1].L == 1024 && pl.d_fw1 &&
-        (pl.pass[0].L == 32 || pl.pass[0].L == 64 || pl.pass[0].L == 128 || pl.pass[0].L == 256 || pl.pass[0].L == 512)) {
+        (pl.pass[0].L == 64 || pl.pass[0].L == 128 || pl.pass[0].L == 256 || pl.pass[0].L == 512)) {
+        // (N1 = 32, i.e. N = 32768, runs in one pass on fft_rx32k_kernel since round 4; its 16-point column form --
+        // half of its LDS cycles bank conflicts -- is retired, COMMS_FFT_NO_RX32K falls back to the generic tile kernel)
         const int n1 = pl.pass[0].L;
         std::vector<float2> t1(1024, make_float2(1.f, 0.f)), tr(256, make_float2(1.f, 0.f));
         for (int k = 0; k < 16; ++k)
@@ -1323,6 +1472,21 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
         COMMS_HIP_TRY(hipMemcpy(pl.d_colw1, t1.data(), t1.size() * sizeof(float2), hipMemcpyHostToDevice));
         COMMS_HIP_TRY(hipMemcpy(pl.d_colr, tr.data(), tr.size() * sizeof(float2), hipMemcpyHostToDevice));
         pl.col_kind = n1 == 64 ? 0 : n1;
+    }
+    if (N == 32768 && pl.d_fw1) {  // the single-pass form: three twiddle values per thread
+        std::vector<float2> t(3 * 1024);
+        const size_t mult[3] = {1, 4, 16};
+        for (int i = 0; i < 3; ++i)
+            for (size_t n2 = 0; n2 < 1024; ++n2) {
+                const double a = -2.0 * kPiF * static_cast<double>((n2 * mult[i]) % N) / static_cast<double>(N);
+                t[i * 1024 + n2] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
+            }
+        COMMS_HIP_TRY(hipMalloc(&pl.d_rx32, t.size() * sizeof(float2)));
+        COMMS_HIP_TRY(hipMemcpy(pl.d_rx32, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice));
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rx32k_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(R32_LDS)));
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_rx32k_kernel<-1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(R32_LDS)));
     }
     // tiles above 64 KiB need the dynamic-LDS limit raised (160 KiB per CU on gfx950)
     COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_tile_kernel<1>),
@@ -1500,6 +1664,21 @@ static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size
         return v && *v && *v != '0';
     }();
     if (pl.rx_rad && !no_rx) return run_rx(pl, in, out, batch * pl.N, inverse, s);
+    static const bool no_rx32k = [] {
+        const char* v = getenv("COMMS_FFT_NO_RX32K");
+        return v && *v && *v != '0';
+    }();
+    if (pl.d_rx32 && !no_rx32k) {  // N = 32768: one pass, a transform per workgroup and step
+        const unsigned blocks = static_cast<unsigned>(batch < static_cast<size_t>(kNumCU) ? batch : kNumCU);
+        const cf* t1 = reinterpret_cast<const cf*>(pl.d_fw1);
+        const cf* t2 = reinterpret_cast<const cf*>(pl.d_fw2);
+        const cf* tt = reinterpret_cast<const cf*>(pl.d_rx32);
+        if (inverse)
+            fft_rx32k_kernel<1><<<dim3(blocks), dim3(1024), R32_LDS, s>>>(reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), batch, t1, t2, tt, ks);
+        else
+            fft_rx32k_kernel<-1><<<dim3(blocks), dim3(1024), R32_LDS, s>>>(reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), batch, t1, t2, tt, ks);
+        return launch_ok("fft_rx32k_kernel");
+    }
     if (pl.rows) {
         // N = 2^21 ... 2^24 in two passes: N / 1024-point columns gathered in pieces of 64 ... 8 B (small pieces cost far less
         // on the read side than on the write side: scripts/probes/strided_tiles.hip), spectra out in runs of 1 KiB ... 128 B;
@@ -1584,7 +1763,6 @@ static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size
             if (i == 0 && pl.col_kind >= 0 && !no_cols) {
                 switch (pl.col_kind) {
                     case 0: COMMS_TRY(launch_cols<0>(pl, src, dst, batch, inverse, s)); break;
-                    case 32: COMMS_TRY(launch_cols<32>(pl, src, dst, batch, inverse, s)); break;
                     case 128: COMMS_TRY(launch_cols<128>(pl, src, dst, batch, inverse, s)); break;
                     case 256: COMMS_TRY(launch_cols<256>(pl, src, dst, batch, inverse, s)); break;
                     default: COMMS_TRY(launch_cols<512>(pl, src, dst, batch, inverse, s)); break;

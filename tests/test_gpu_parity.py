@@ -943,6 +943,32 @@ def test_fft_single_pass_radix_times_1024(c, n, inverse):
             fft_close(t.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("inverse", [False, True])
+def test_fft_32768_points_in_one_pass(c, inverse):
+    """N = 32768 = 32 x 1024 in ONE pass (fft_rx32k_kernel: radix-32 over the rows in registers, two phases of sixteen
+    rows through the wave buffers): batches below, at and above the 256-workgroup grid, out of place and in place on the
+    device (every bin of a tone batch: test_fft_tones_every_bin at logn 15)."""
+    import torch
+
+    n = 32768
+    s = torch.cuda.current_stream().cuda_stream
+    for batch in (1, 3, 256, 257, 700):
+        x = torch.empty(n * batch, dtype=torch.complex64, device="cuda:0")
+        c.synth_iq_dev(x.data_ptr(), n * batch, 0, 70 + batch)
+        y = torch.empty_like(x)
+        node = c.FFTBatchNode(n, inverse)
+        node.run_dev(x.data_ptr(), n * batch, y.data_ptr(), s)
+        xt = x.to(torch.complex128).reshape(batch, n)
+        want = torch.fft.ifft(xt, dim=1) * n if inverse else torch.fft.fft(xt, dim=1)
+        err = float(torch.linalg.vector_norm(y.to(torch.complex128).reshape(batch, n) - want, dim=1).div(torch.linalg.vector_norm(want, dim=1)).max())
+        assert err <= 1e-5, (batch, err)  # (observed ~3e-7)
+        if batch <= 3:
+            fft_close(y.cpu().numpy()[:n], oracle.fft(c.synth_iq(n, 0, 70 + batch), inverse))  # against the oracle itself
+        node.run_dev(x.data_ptr(), n * batch, x.data_ptr(), s)   # in place
+        torch.cuda.synchronize()
+        assert torch.equal(torch.view_as_real(x), torch.view_as_real(y))
+
+
 @pytest.mark.parametrize("logn", [15, 16, 17, 18, 19])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_fft_four_step_column_pass(c, logn, inverse):
@@ -982,7 +1008,7 @@ def test_fft_above_2p20_columns_rows_transpose(c, logn, batch, inverse):
     assert torch.equal(torch.view_as_real(x), torch.view_as_real(y))
 
 
-@pytest.mark.parametrize("logn,batch", [(6, 4096), (10, 512), (14, 64), (17, 16), (20, 8), (21, 3), (22, 2), (23, 2), (24, 1)])
+@pytest.mark.parametrize("logn,batch", [(6, 4096), (10, 512), (14, 64), (15, 300), (17, 16), (20, 8), (21, 3), (22, 2), (23, 2), (24, 1)])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_fft_tones_every_bin(c, logn, batch, inverse):
     """Every bin of every transform of a batch: transform b holds one complex tone of its own frequency k_b and
