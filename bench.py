@@ -1062,8 +1062,11 @@ def run_config1(ctx):
 
     # `value`: the plain step loop (no timer attached: the pulse node's timer records two events around its launch,
     # a few us that a 10-us step would show); the kernel's duration comes from a second loop of the same launches
-    stamper = c.KernelTimer(max(args.steps + args.warmup, 1), device=ctx.local_rank, stamps=True).attach(fused)
     elapsed = ctx.timed(lambda: fused.run_dev(sym.data_ptr(), nsym, out.data_ptr(), s), args.steps, args.warmup)
+    # in-stream kernel time: the same loop again with the kernel stamping its own begin / end (a 5-us launch notices even
+    # that: `stamped_ms_per_step` beside `ms_per_step`)
+    stamper = c.KernelTimer(max(args.steps + args.warmup, 1), device=ctx.local_rank, stamps=True).attach(fused)
+    stamped_elapsed = ctx.timed(lambda: fused.run_dev(sym.data_ptr(), nsym, out.data_ptr(), s), args.steps, args.warmup)
     sms = stamper.read_stamps_ms()[args.warmup:]
     sms = sms[sms > 0]
     stamper.close()
@@ -1099,7 +1102,8 @@ def run_config1(ctx):
            "roofline": {"bound": "hbm", "kernel": "pulse_poly_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("pulse_poly_kernel", n),
                         "kernel_ms": round(kernel_ms, 5), "launches_timed": int(kms.size), "timer_stride": 1,
-                        **in_stream_fields(sms), "algorithmic_bytes_per_launch": bytes_per_out * n,
+                        **in_stream_fields(sms), "stamped_ms_per_step": round(stamped_elapsed / args.steps * 1e3, 5),
+                        "algorithmic_bytes_per_launch": bytes_per_out * n,
                         "note": "2^20 outputs are 10.5 MB: at this size the launch is latency-bound (the same kernel at "
                                 "2^24 outputs: DESIGN.md section 4); the kernel's own begin / end timestamps, every launch of a second loop"},
            "two_nodes": {"value": round(float(world) * n * args.steps / two_elapsed / 1e6, 1), "unit": "Msamples/s",

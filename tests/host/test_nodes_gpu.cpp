@@ -12,6 +12,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <thread>
 
 #include "../../comms_rs_amd/host/comms/nodes.hpp"
@@ -209,6 +211,158 @@ static void test_fm_node() {
         CHECK(chk.got[0].size() == 1 && chk.got[0][0] == static_cast<float>(M_PI));
         for (size_t i = 1; i < chk.got[1].size(); ++i) CHECK(std::fabs(chk.got[1][i] - 0.25f) < 1e-3f);
     }
+}
+
+// The 63 taps examples/fm_radio.rs:30-52 ships, read from the fixture (tests/golden/reference_kats.json: data the
+// reference holds, transcribed with its citation).
+static std::vector<C> fm_radio_taps() {
+    std::vector<C> taps;
+    for (const char* path : {"tests/golden/reference_kats.json", "../../tests/golden/reference_kats.json"}) {
+        std::FILE* f = std::fopen(path, "rb");
+        if (!f) continue;
+        std::string txt;
+        char buf[4096];
+        size_t got;
+        while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) txt.append(buf, got);
+        std::fclose(f);
+        size_t p = txt.find("\"fm_radio_taps\"");
+        if (p == std::string::npos) break;
+        p = txt.find("\"taps_re\"", p);
+        p = txt.find('[', p);
+        const size_t end = txt.find(']', p);
+        const char* q = txt.c_str() + p + 1;
+        while (q < txt.c_str() + end) {
+            char* e = nullptr;
+            const double v = std::strtod(q, &e);
+            if (e == q) break;
+            taps.push_back(C(static_cast<float>(v), 0.f));
+            q = e;
+            while (q < txt.c_str() + end && (*q == ',' || *q == ' ' || *q == '\n')) ++q;
+        }
+        break;
+    }
+    return taps;
+}
+
+// examples/fm_radio.rs:144-164 as a graph, with the example's own filter: bytes -> ConvertNode -> BatchFirNode<f32>
+// -> DecimateNode<Complex<f32>>(5) -> FMDemodNode -> Convert2Node -> BatchFirNode<f32> -> Convert3Node ->
+// DecimateNode<f32>(5) -> sink.  The three Convert nodes are the example's own (user-defined) nodes.
+struct ConvertU8 : DeriveNode<ConvertU8> {  // fm_radio.rs:62-91
+    NodeReceiver<std::vector<uint8_t>> input;
+    NodeSender<std::vector<C>> output;
+    Result<std::vector<C>> run(const std::vector<uint8_t>& b) {
+        std::vector<C> out(b.size() / 2);
+        for (size_t i = 0; i < out.size(); ++i) out[i] = C((b[2 * i] - 127.5f) / 127.5f, (b[2 * i + 1] - 127.5f) / 127.5f);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+};
+struct Convert2 : DeriveNode<Convert2> {  // fm_radio.rs:93-117
+    NodeReceiver<std::vector<float>> input;
+    NodeSender<std::vector<C>> output;
+    Result<std::vector<C>> run(const std::vector<float>& v) {
+        std::vector<C> out(v.size());
+        for (size_t i = 0; i < v.size(); ++i) out[i] = C(v[i], 0.f);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+};
+struct Convert3 : DeriveNode<Convert3> {  // fm_radio.rs:119-141
+    NodeReceiver<std::vector<C>> input;
+    NodeSender<std::vector<float>> output;
+    Result<std::vector<float>> run(const std::vector<C>& v) {
+        std::vector<float> out(v.size());
+        for (size_t i = 0; i < v.size(); ++i) out[i] = v[i].real();
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+};
+
+static void test_fm_radio_literal_graph() {
+    const std::vector<C> taps = fm_radio_taps();
+    CHECK(taps.size() == 63);
+    if (taps.size() != 63) return;
+    for (size_t k = 0; k < 63; ++k) CHECK(taps[k] == taps[62 - k]);  // the example's filter is symmetric
+    // four radio blocks (RadioRxNode::new(rtlsdr, 0, 262144): 131072 samples each) of an FM tone: 1 kHz-like
+    // modulation on a carrier offset, quantised to the radio's bytes
+    const size_t blk = 131072, nblk = 4;
+    std::vector<std::vector<uint8_t>> blocks(nblk, std::vector<uint8_t>(2 * blk));
+    for (size_t b = 0; b < nblk; ++b)
+        for (size_t i = 0; i < blk; ++i) {
+            const double n = static_cast<double>(b * blk + i);
+            const double ph = 2.0 * M_PI * 0.02 * n + 4.0 * std::cos(2.0 * M_PI * n / 5000.0);
+            blocks[b][2 * i] = static_cast<uint8_t>(std::lround(127.5 + 100.0 * std::cos(ph)));
+            blocks[b][2 * i + 1] = static_cast<uint8_t>(std::lround(127.5 + 100.0 * std::sin(ph)));
+        }
+    // the graph, wired as the example wires it (fm_radio.rs:156-164)
+    Replay<std::vector<uint8_t>> sdr(blocks);
+    ConvertU8 convert;
+    BatchFirNode filt1(taps), filt2(taps);
+    DecimateNode<C> dec1(5);
+    FMDemodNode fm;
+    Convert2 convert2;
+    Convert3 convert3;
+    DecimateNode<float> dec2(5);
+    Collect<std::vector<float>> audio;
+    connect_nodes(sdr.output, convert.input);
+    connect_nodes(convert.output, filt1.input);
+    connect_nodes(filt1.output, dec1.input);
+    connect_nodes(dec1.output, fm.input);
+    connect_nodes(fm.output, convert2.input);
+    connect_nodes(convert2.output, filt2.input);
+    connect_nodes(filt2.output, convert3.input);
+    connect_nodes(convert3.output, dec2.input);
+    connect_nodes(dec2.output, audio.input);
+    start_nodes(std::move(sdr), std::move(convert), std::move(filt1), std::move(dec1), std::move(fm), std::move(convert2),
+                std::move(filt2), std::move(convert3), std::move(dec2));
+    while (audio.call().is_ok()) {
+    }
+    CHECK(audio.got.size() == nblk);
+    // the same blocks through the same node types called directly, state carried across blocks
+    BatchFirNode f1(taps), f2(taps);
+    FMDemodNode fmd;
+    ConvertU8 cv;
+    Convert2 c2;
+    Convert3 c3;
+    double worst = 0.0;
+    for (size_t b = 0; b < nblk && b < audio.got.size(); ++b) {
+        const auto a = fmd.run(DecimateNode<C>(5).run(f1.run(cv.run(blocks[b]).value()).value()).value()).value();
+        const auto want = DecimateNode<float>(5).run(c3.run(f2.run(c2.run(a).value()).value()).value()).value();
+        CHECK(want.size() == audio.got[b].size());
+        for (size_t i = 0; i < want.size() && i < audio.got[b].size(); ++i)
+            worst = std::fmax(worst, std::fabs(static_cast<double>(want[i]) - audio.got[b][i]));
+    }
+    CHECK(worst == 0.0);  // the graph adds nothing: same nodes, same launches, same state
+    // what comes out is the instantaneous frequency: 2 pi 0.02 * 5 per decimated sample, modulated by the tone, low-passed
+    if (!audio.got.empty() && audio.got.back().size() > 1000) {
+        double mean = 0.0;
+        const auto& v = audio.got.back();
+        for (size_t i = 200; i < v.size(); ++i) mean += v[i];
+        mean /= static_cast<double>(v.size() - 200);
+        CHECK(std::fabs(mean - 2.0 * M_PI * 0.02 * 5.0 * 1.0363602) < 0.02);  // x the filter's DC gain (sum of the taps)
+    }
+    // the front half as ONE launch reading the radio's bytes (comms_chain_*, u8 load stage) agrees with the three nodes
+    comms_chain_t* front = nullptr;
+    CHECK(comms_chain_create_ex(0.0, 0.0, c32(taps.data()), taps.size(), 5, COMMS_CHAIN_FM_DEMOD, 0, &front) == COMMS_OK);
+    CHECK(comms_chain_set_input_format(front, COMMS_IQ_U8, 1.0f) == COMMS_OK);
+    BatchFirNode g1(taps);
+    FMDemodNode gfm;
+    const size_t nw = blk / 5 * 5;  // the fused chain takes whole decimation periods
+    std::vector<uint8_t> whole(blocks[0].begin(), blocks[0].begin() + 2 * nw);
+    const auto ref = gfm.run(DecimateNode<C>(5).run(g1.run(cv.run(whole).value()).value()).value()).value();
+    std::vector<float> fused(nw / 5);
+    CHECK(comms_chain_run(front, reinterpret_cast<const comms_c32*>(whole.data()), nw, fused.data()) == COMMS_OK);
+    double wf = 0.0;
+    for (size_t i = 1; i < fused.size() && i < ref.size(); ++i) {
+        double e = std::fabs(static_cast<double>(fused[i]) - ref[i]);
+        if (e > M_PI) e = 2.0 * M_PI - e;
+        wf = std::fmax(wf, e);
+    }
+    CHECK(fused.size() == ref.size() && wf < 2e-3);
+    comms_chain_destroy(front);
 }
 
 static void test_demod_nodes() {
@@ -608,6 +762,7 @@ int main() {
     test_pulse_node();
     test_resample_nodes();
     test_fm_node();
+    test_fm_radio_literal_graph();
     test_demod_nodes();
     test_device_resident_graph();
     test_device_resident_stream_many_messages();

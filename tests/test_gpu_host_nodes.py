@@ -12,6 +12,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_cpp_dsp_nodes_in_graphs():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "comms_rs_amd", "host"), "-s"], timeout=600)
     out = subprocess.run([os.path.join(ROOT, "comms_rs_amd", "lib", "test_nodes_gpu")], capture_output=True,
-                         text=True, timeout=300)
+                         text=True, timeout=300, cwd=ROOT)   # (reads tests/golden/reference_kats.json)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all passed" in out.stdout
