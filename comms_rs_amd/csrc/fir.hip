@@ -925,6 +925,31 @@ __device__ __forceinline__ void x_report(const unsigned long long* aux) {
 #endif
 }
 
+// diagnostic build: phase times of the first X_TRACE_SEGS segments of every wave (scripts/trace_os16k.py), s_memtime at
+// eleven points of a segment, [workgroup][wave][segment][16] -- comms_debug_os16k_trace(buffer) arms it.
+#ifdef COMMS_DIAG
+constexpr unsigned X_TRACE_SEGS = 40;
+__device__ unsigned long long* g_x_trace = nullptr;
+#define X_MARK(i)                                                                  \
+    do {                                                                           \
+        if (xt && done < X_TRACE_SEGS) {                                           \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();            \
+            if (l == 0) xt[done * 16 + (i)] = t_;                                  \
+        }                                                                          \
+    } while (0)
+// (after the vector work that produced `reg`: the clock read is a scalar instruction and would float above it)
+#define X_MARK_AFTER(i, reg)                      \
+    do {                                          \
+        if (xt) {                                 \
+            asm volatile("" : "+v"(reg));         \
+            X_MARK(i);                            \
+        }                                         \
+    } while (0)
+#else
+#define X_MARK(i)
+#define X_MARK_AFTER(i, reg)
+#endif
+
 template <int HR, class In = const float2*>
 __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
                                                             const float2* __restrict__ hist, int hist_len,
@@ -957,7 +982,27 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
         aux[1] = reinterpret_cast<unsigned long long>(err);
         aux[2] = 0;
     }
-    const bool withhold = fault != 0 && blockIdx.x == 0 && wave == 3;
+    const bool withhold = (fault & 1) != 0 && blockIdx.x == 0 && wave == 3;
+    // Diagnostic build, fault bits 1...: issue priority among the four waves of a SIMD (waves w, w + 4, w + 8, w + 12).
+    // The arbiter takes the oldest wave first, so with equal priorities the four finish every phase staggered
+    // (scripts/trace_os16k.py).  Rotating s_setprio by step and wave group does even them out -- and the launch gets
+    // 2 ... 6 % longer (profiles/r04_trace_os16k.txt): the slice phase takes its ~20 k cycles either way.
+#ifdef COMMS_DIAG
+    const int pmode = fault >> 1;
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    auto prio = [&](int step) {
+        if (pmode == 0) return;
+        const int p = pmode == 1 ? ((step + grp) & 3) : pmode == 2 ? grp : pmode == 3 ? 3 - grp : ((step - grp) & 3);
+        switch (p) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    };
+#else
+    auto prio = [](int) {};
+#endif
     if (!accumulate) hist_advance(hist, in, n, new_hist, hist_len);
     tw1[tid] = tb.tw1[tid];
     if (tid < 64) tw2[tid] = tb.tw2[tid];
@@ -1000,13 +1045,26 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
     };
     if (seg_lo < seg_hi) fetch_rows(seg_lo, 0);
     unsigned done = 0;  // segments this workgroup has finished
+#ifdef COMMS_DIAG
+    unsigned long long* xt = g_x_trace;
+    if (xt) xt += (static_cast<size_t>(blockIdx.x) * 16 + wave) * X_TRACE_SEGS * 16;
+#endif
     for (size_t seg = seg_lo; seg < seg_hi; ++seg, ++done) {
         const size_t nb = seg * xv;
+        X_MARK(0);
+        prio(0);
         // ---- stage 1: radix-16 over the rows; value k of thread tid is point tid of slice k.  No wait in front
         // of the writes: word (k, tid) was last read by this very thread (inverse stage 1 of the previous
         // segment), and wave k is past its slice work for that segment or nobody could have read it.
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = rows[a];
+#ifdef COMMS_DIAG
+        if (xt) {  // the rows have arrived (behind them in the queue: the 16 - HR stores of the segment before)
+            if (done == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 - HR) : "memory");
+            X_MARK(1);
+        }
+#endif
 #if COMMS_OS16K_CARRY
         // the next segment's halo = this segment's last hr rows (HBM would see them again otherwise: the XCD streams
         // 7 MiB per segment time through a 4 MiB L2)
@@ -1014,12 +1072,16 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
         for (int a = 0; a < HR; ++a) rows[a] = rows[16 - HR + a];
 #endif
         radix16<-1>(v);
+        X_MARK_AFTER(8, v[R16_POS(15)].x);
 #pragma unroll
         for (int k = 0; k < 16; ++k) bufs[k * X_BUF + tid] = v[R16_POS(k)];
         x_signal(slice_in + (l & 15), l < 16);  // one ds_add, sixteen lanes, sixteen counters
+        X_MARK(2);
         // ---- this wave's slice, once all sixteen waves have delivered their 64 points of it: stage-1 twiddle,
         // 1024-point transform, spectrum multiply, inverse, conjugate twiddle
         x_wait_one(slice_in + wave, 16u * (done + 1), gave_up);
+        X_MARK(3);
+        prio(1);
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = buf[64 * a + l];
         wave_lds_sync();
@@ -1028,7 +1090,7 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
             if (a) v[a] = cmulf_s(v[a], sta[a]);
             v[a] = cmulf(v[a], lane_tw);
         }
-        os1024_core<1024>(v, buf, tw1, tb.hdev, tw2, l, [](int) {}, tid);
+        os1024_core<1024>(v, buf, tw1, tb.hdev, tw2, l, [&](int i) { prio(1 + i); }, tid);
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
             cf y = cmulcf(v[R16_POS(a)], lane_tw);
@@ -1036,14 +1098,25 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
             buf[64 * a + l] = y;
         }
         x_signal(slice_out + wave, l == 0 && !(withhold && done == 0));
+        X_MARK(4);
         // (unconditional -- the last segment fetches itself again -- so that `rows` is redefined on every path
         // and its registers are free during the slice work)
         fetch_rows(seg + 1 < seg_hi ? seg + 1 : seg, R0);
         // ---- inverse stage 1: thread tid gathers point tid of every slice, radix-16 back to the rows
+        X_MARK(5);
         x_wait_all16(slice_out, done + 1, l, gave_up);
+        X_MARK(6);
+        prio(10);
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = bufs[k * X_BUF + tid];
+#ifdef COMMS_DIAG
+        if (xt) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            X_MARK(9);
+        }
+#endif
         radix16<1>(v);
+        X_MARK_AFTER(10, v[R16_POS(15)].x);
         // stores (and the accumulating pass's loads) through a buffer resource that ends at sample n: nothing past it
         const __amdgpu_buffer_rsrc_t ors = make_rsrc(out + nb, nb < n ? (n - nb) * sizeof(float2) : 0);
 #pragma unroll
@@ -1054,6 +1127,7 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
             if (accumulate) y = y + to_cf(BufRows<const float2*>::get_from(ors, tid * 8, row));
             __builtin_amdgcn_raw_buffer_store_b64(bv2u{__float_as_uint(y.x), __float_as_uint(y.y)}, ors, tid * 8, row, 0);
         }
+        X_MARK(7);
     }
     x_report(aux);
 #ifndef COMMS_OS16K_NO_STAMP
@@ -1822,7 +1896,14 @@ static comms_status_t launch_fixed_hr(int hr, int wpb, size_t runs, hipStream_t 
 static std::atomic<int> g_os16k_fault{0};
 static int os16k_fault() { return g_os16k_fault.load(std::memory_order_relaxed); }
 #ifdef COMMS_DIAG
+// bit 0: withhold a signal; bits 1...: wave priority scheme (trial, see the kernel)
 extern "C" void comms_debug_os16k_fault(int on) { g_os16k_fault.store(on, std::memory_order_relaxed); }
+// buf: device memory, [workgroups][16][X_TRACE_SEGS][16] u64 (null: off); returns X_TRACE_SEGS
+extern "C" unsigned comms_debug_os16k_trace(void* buf) {
+    unsigned long long* p = static_cast<unsigned long long*>(buf);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_x_trace), &p, sizeof(p)) != hipSuccess) return 0;
+    return X_TRACE_SEGS;
+}
 #endif
 template <class In>
 static void launch_os16k_hr(int hr, unsigned blocks, size_t lds, hipStream_t s, In in, const float2* hist, int n_eff, float2* o, size_t n,
