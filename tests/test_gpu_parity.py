@@ -120,6 +120,42 @@ def test_fir_state_carries_across_calls_and_matches_reference_state(c, algo):
         assert np.array_equal(node.state(255), st)  # history is moved, never recomputed: exact
 
 
+@pytest.mark.parametrize("n_taps,chunks", [
+    (63, [5, 1000, 1024, 3000, 20000, 200000, 3300000, 7, 70000]),
+    (255, [1, 300, 1023, 2000, 100000, 3300000, 254, 5000]),
+    (300, [5, 1000, 5000, 300000, 3, 40000]),
+    (1600, [1000, 1 << 23, 50000, 3]),
+    (4097, [10, 5000, 200000, 1 << 22, 9]),
+])
+def test_fir_stream_in_chunks_across_kernel_switches(c, n_taps, chunks):
+    """One stream through ONE node (AUTO) in calls of very different sizes: every call picks its kernel by size (direct,
+    1024-point fixed runs / ticketed, 4096-point, 16384-point), the history is what carries over.  Checked against the
+    oracle around every call boundary and in windows inside the long calls."""
+    rng = np.random.default_rng(900 + n_taps)
+    taps = rand_c(rng, n_taps)
+    total = sum(chunks)
+    x = c.synth_iq(total, 0, 77 + n_taps)
+    node = c.BatchFirNode(taps)
+    kernels, parts, edges = [], [], [0]
+    for m in chunks:
+        kernels.append(node.kernel_for(m))
+        parts.append(node.run(x[edges[-1]:edges[-1] + m]))
+        edges.append(edges[-1] + m)
+    assert len(set(kernels)) >= 2 or n_taps > 2049, kernels  # (above 2049 taps there is one kernel: ragged sizes only)
+    got = np.concatenate(parts)
+    windows = [(max(e - 2500, 0), min(e + 2500, total)) for e in edges]
+    for a, b in zip(edges[:-1], edges[1:]):
+        if b - a > 20000:
+            windows += [(int(p), int(p) + 3000) for p in rng.integers(a, b - 3000, 3)]
+    for a, b in windows:
+        lo = max(a - (n_taps - 1), 0)  # the samples the outputs a ... b - 1 see (zeros before the stream)
+        want = oracle.batch_fir(x[lo:b], taps, oracle.default_state(taps), norotate=True)[a - lo:]
+        fir_close(got[a:b], want, taps, x[lo:b])
+    # and the state it leaves is the last samples of the stream, exactly
+    keep = min(n_taps, total)
+    assert np.array_equal(node.state(n_taps)[:keep], x[::-1][:keep])
+
+
 def test_fir_short_and_long_user_state(c):
     # zip(taps, state): a shorter state truncates the taps (fir.rs:53)
     rng = np.random.default_rng(6)
