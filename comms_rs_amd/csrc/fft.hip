@@ -362,6 +362,133 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void fft1024x16_kernel(c
     kstamp_end(p.ks);
 }
 
+// ---------------------------------------------------------------- the same tile, two LDS trips shorter (round 4 trial)
+// fft1024x16_kernel<DIR, 16> with (1) the tile loaded straight into the transform's register layout -- rows: wave w
+// reads transform w, point 64 a + lane into register a (512-B runs); columns: thread (c, t) = (tid & 15, tid >> 4)
+// already holds rows t + 64 u of column c, which IS register u of lane t of column c's transform -- so the first
+// radix-16 runs on the registers the loads land in and the tile's first write-to-LDS / read-back is gone (for columns
+// the exchange that follows is then written across waves: one barrier where the tile-in barrier was; for rows it
+// stays wave-local and the tile needs two barriers instead of three); (2) the last radix-4 across lanes
+// (radix4_lanes: v_permlane32/16_swap) instead of through LDS.  Per thread and tile 32 + 32 LDS accesses instead of
+// 64 + 64, 122-126 VGPRs and no spill (128 and 1-3 there).  Same tables, same buffers, same store stage, same
+// results (all FFT parity tests pass on it).  And no faster: config 4 27.78 against 27.37 ms per step, N = 2^17 ... 2^22
+// 0-2 % slower in two alternating pairs of runs (profiles/r04_fft_tile_direct.txt) -- these passes do not wait for
+// LDS; what they wait for is the memory side.  Kept for that measurement, off by default
+// (COMMS_FFT_TILE_DIRECT=1 selects it).
+template <int DIR, bool TWS = false>
+__global__ __launch_bounds__(1024, 4) void fft1024x16d_kernel(const cf* in, cf* out, FftTileParams p,
+                                                               const cf* __restrict__ tw1g,
+                                                               const cf* __restrict__ tw2g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = 16;
+    cf* tw1 = reinterpret_cast<cf*>(smem);  // [16][64]  W1024^{lane*k0}
+    cf* tw2 = tw1 + 1024;                   // [16][4]   W64^{c*k1}
+    cf* bufs = tw2 + 64;                    // [16][FW_BUF]
+    cf* twu = bufs + NW * FW_BUF;           // [16][16]  W_N^{64 C u} of the tile's columns (four-step store twiddle)
+    const int tid = threadIdx.x;
+    const int l = tid & 63, wave = tid >> 6;
+    const int q0 = l & 15, q1 = l >> 4;
+    cf* buf = bufs + wave * FW_BUF;
+    kstamp_begin(p.ks);
+    tw1[tid] = tw1g[tid];
+    if (tid < 64) tw2[tid] = tw2g[tid];
+    auto tile_src = [&](size_t tix) {
+        const size_t b = tix / p.tiles_per_xform;
+        return in + b * p.N + (tix - b * p.tiles_per_xform) * p.tile_step_in;
+    };
+    const unsigned in_cs = static_cast<unsigned>(p.in_cs), in_ls = static_cast<unsigned>(p.in_ls);
+    const bool cols = p.in_c_fast != 0;
+    // register u <- point 64 u + t of transform c: (c, t) = (tid & 15, tid >> 4) along columns, (wave, lane) along rows
+    const unsigned o0 = cols ? (tid & 15) * in_cs + (tid >> 4) * in_ls : wave * in_cs + l * in_ls;
+    const unsigned ostep = 64u * in_ls;
+    auto fetch = [&](const cf* src, cf (&r)[16]) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) r[u] = src[o0 + u * ostep];
+    };
+    cf pre[16];
+    if (blockIdx.x < p.n_tiles) fetch(tile_src(blockIdx.x), pre);
+    // where this thread's exchange-1 values go: its transform's buffer, column t of the [k][66] image
+    cf* x1 = cols ? bufs + (tid & 15) * FW_BUF + (tid >> 4) : buf + l;
+    const cf* t1 = tw1 + (cols ? (tid >> 4) : l);
+
+    for (size_t tix = blockIdx.x; tix < p.n_tiles; tix += gridDim.x) {
+        const size_t b = tix / p.tiles_per_xform;
+        const size_t tl = tix - b * p.tiles_per_xform;
+        cf* dst = out + b * p.N + tl * p.tile_step_out;
+        cf v[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = pre[a];
+        // (unconditional: the last tile asks for itself again, so that `pre` is redefined on every path)
+        fetch(tile_src(tix + gridDim.x < p.n_tiles ? tix + gridDim.x : tix), pre);
+        __syncthreads();  // previous tile fully stored (and the tables are in place)
+        cf tw_a = cf{1.f, 0.f};
+        if (TWS) {  // four-step twiddle of the store stage, factored (see fft1024x16_kernel)
+            const unsigned col0 = static_cast<unsigned>(tl) * NW;
+            const unsigned ea = (col0 + (tid & 15)) * static_cast<unsigned>(tid >> 4);
+            tw_a = g_mul(p.tw_hi[ea >> 12], p.tw_lo[ea & 4095]);
+            if (tid < 256) {
+                const unsigned eb = (col0 + (tid & 15)) * 64u * static_cast<unsigned>(tid >> 4);
+                twu[tid] = g_mul(p.tw_hi[eb >> 12], p.tw_lo[eb & 4095]);
+            }
+        }
+        radix16<DIR>(v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            cf x = v[R16_POS(k)];
+            if (k) x = tw_mul<DIR>(x, t1[k * 64]);
+            x1[k * FW_S1] = x;
+        }
+        if (cols) __syncthreads();  // written by the threads that loaded them, read by the transform's own wave
+        else fw_wave_sync();
+#pragma unroll
+        for (int bb = 0; bb < 16; ++bb) v[bb] = buf[q0 * FW_S1 + 4 * bb + q1];
+        fw_wave_sync();
+        radix16<DIR>(v);
+        cf r[16], z[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            r[k] = v[R16_POS(k)];
+            if (k) r[k] = tw_mul<DIR>(r[k], tw2[k * 4 + q1]);
+        }
+        radix4_lanes<DIR>(r, z);
+        // z[4 t + m] of lane q0 + 16 g + 32 h is X[k], k = q0 + 16 (2 m + 8 g + h) + 256 t, at position k + (k >> 4)
+        {
+            cf* o = buf + q0 + 17 * (8 * (q1 & 1) + (q1 >> 1));
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) o[34 * m + 272 * t] = z[4 * t + m];
+        }
+        __syncthreads();
+        // ---- coalesced tile store (optionally times the four-step twiddle); 32-bit offsets
+        {
+            const unsigned out_cs = static_cast<unsigned>(p.out_cs), out_ks = static_cast<unsigned>(p.out_ks);
+            const unsigned col0 = static_cast<unsigned>(tl) * NW;
+#pragma unroll 8
+            for (int u = 0; u < 16; ++u) {
+                unsigned c, k;
+                if (p.out_c_fast) {
+                    c = tid & (NW - 1);
+                    k = (tid >> 4) + 64 * u;
+                } else {
+                    const unsigned i = tid + 64 * NW * u;
+                    c = i >> 10;
+                    k = i & 1023;
+                }
+                cf x = bufs[c * FW_BUF + k + (k >> 4)];
+                if (TWS) {
+                    x = tw_apply<DIR>(x, g_mul(tw_a, twu[u * 16 + c]));
+                } else if (p.apply_tw) {
+                    const unsigned e = (col0 + c) * k;  // < N <= 2^24
+                    x = tw_apply<DIR>(x, g_mul(p.tw_hi[e >> 12], p.tw_lo[e & 4095]));
+                }
+                dst[c * out_cs + k * out_ks] = x;
+            }
+        }
+    }
+    kstamp_end(p.ks);
+}
+
 // ---------------------------------------------------------------- N = RAD * 1024 in ONE pass (RAD = 1, 2, 4, 8, 16)
 // n = 1024 n1 + n2, k = k1 + RAD k2:
 //   X[k1 + RAD k2] = sum_{n2} W_1024^{n2 k2} * W_N^{n2 k1} * ( sum_{n1} x[1024 n1 + n2] W_RAD^{n1 k1} )
@@ -1408,6 +1535,14 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
         COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft1024x16_kernel<-1, 16, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft1024x16d_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft1024x16d_kernel<-1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft1024x16d_kernel<1, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft1024x16d_kernel<-1, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
         COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft1024x16_kernel<1, 8>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
         COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft1024x16_kernel<-1, 8>),
@@ -1501,12 +1636,33 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
 // Runs `batch` transforms of length pl.N.  In-place (in == out) is fine: every
 // tile is fully read before it is written and tiles do not overlap; pass 2
 // reads what pass 1 wrote to `out`.
+static bool fft_tile_direct() {  // trial kernel fft1024x16d_kernel (see there): off unless COMMS_FFT_TILE_DIRECT=1
+    static const bool v = [] {
+        const char* e = getenv("COMMS_FFT_TILE_DIRECT");
+        return e && *e && *e != '0';
+    }();
+    return v;
+}
 static comms_status_t launch_fast(Pow2Plan& pl, const float2* src, float2* dst, const FftTileParams& p,
                                   bool inverse, hipStream_t s) {
     const cf* t1 = reinterpret_cast<const cf*>(pl.d_fw1);
     const cf* t2 = reinterpret_cast<const cf*>(pl.d_fw2);
     const cf* a = reinterpret_cast<const cf*>(src);
     cf* d = reinterpret_cast<cf*>(dst);
+    if (p.C == 16 && fft_tile_direct()) {  // trial: register-layout loads, last radix-4 across lanes
+        const size_t lds = (1024 + 64 + 16 * FW_BUF + 256) * sizeof(float2);
+        const unsigned blocks = static_cast<unsigned>(p.n_tiles < static_cast<size_t>(kNumCU) ? p.n_tiles : kNumCU);
+        if (p.apply_tw && p.out_c_fast) {
+            if (inverse)
+                fft1024x16d_kernel<1, true><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, p, t1, t2);
+            else
+                fft1024x16d_kernel<-1, true><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, p, t1, t2);
+        } else if (inverse)
+            fft1024x16d_kernel<1><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, p, t1, t2);
+        else
+            fft1024x16d_kernel<-1><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, p, t1, t2);
+        return launch_ok("fft1024x16d_kernel");
+    }
     if (p.C == 16) {  // one 16-wave workgroup per CU
         const size_t lds = (1024 + 64 + 16 * FW_BUF + 256) * sizeof(float2);
         const unsigned blocks = static_cast<unsigned>(p.n_tiles < static_cast<size_t>(kNumCU) ? p.n_tiles : kNumCU);

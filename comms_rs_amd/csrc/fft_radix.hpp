@@ -115,6 +115,55 @@ __device__ __forceinline__ void radix4_c_rot(cf& a, cf& b, cf& c, cf& d) {
     d = csub_di<DIR>(t1, t3);
 }
 
+// v_permlane32_swap / v_permlane16_swap on a complex register pair: (a, b) -> a keeps its lanes 0-31 and takes
+// b's lanes 0-31 into 32-63, b takes a's lanes 32-63 into 0-31 and keeps its own 32-63 (32); the same with the
+// four 16-lane rows, odd rows of a <-> even rows of b (16).  The builtins (not raw asm) so that the compiler
+// knows the instruction; the packed butterflies next to them are plain vector adds for the same reason -- the
+// hazard recogniser cannot see into an asm block -- and an asm operand produced right before a swap is fenced.
+__device__ __forceinline__ void lane_swap_fence(cf& a, cf& b) { asm volatile("s_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void lane_swap32(cf& a, cf& b) {
+    lane_swap_fence(a, b);
+    const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+    const auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+    a = cf{__uint_as_float(x[0]), __uint_as_float(y[0])};
+    b = cf{__uint_as_float(x[1]), __uint_as_float(y[1])};
+}
+__device__ __forceinline__ void lane_swap16(cf& a, cf& b) {
+    lane_swap_fence(a, b);
+    const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+    const auto y = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+    a = cf{__uint_as_float(x[0]), __uint_as_float(y[0])};
+    b = cf{__uint_as_float(x[1]), __uint_as_float(y[1])};
+}
+
+// 4-point DFTs ACROSS lanes: lane (q0, c) = (lane & 15, lane >> 4) holds r[k1], k1 = 0 ... 15, and the transform runs over
+// c.  v_permlane32_swap pairs registers so that the two halves of the wave (c's upper bit) meet in one lane,
+// v_permlane16_swap does the same for the 16-lane rows (c's lower bit); the W4 twiddle of the odd outputs is folded
+// into the second butterfly.  Result: z[4 t + m] of lane q0 + 16 g + 32 h is output t of the transform whose other
+// indices are (q0, k1 = 2 m + 8 g + h).  No LDS; 32 swaps + 32 packed adds.
+template <int DIR>
+__device__ __forceinline__ void radix4_lanes(const cf (&r)[16], cf (&z)[16]) {
+    cf sd[16];  // [0..7] sums, [8..15] differences of the upper-bit halves
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        cf p = r[2 * m], q = r[2 * m + 1];
+        lane_swap32(p, q);
+        sd[m] = p + q;
+        sd[8 + m] = p - q;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        cf a = sd[m], b = sd[m + 4];
+        lane_swap16(a, b);
+        z[m] = a + b;      // t = 0
+        z[8 + m] = a - b;  // t = 2
+        cf c = sd[8 + m], d = sd[12 + m];
+        lane_swap16(c, d);
+        z[4 + m] = cadd_di<DIR>(c, d);   // t = 1
+        z[12 + m] = csub_di<DIR>(c, d);  // t = 3
+    }
+}
+
 // forward W16^m = (cos(2 pi m/16), -sin(2 pi m/16)); the inverse uses the conjugate
 template <int M>
 __device__ __forceinline__ cf w16() {

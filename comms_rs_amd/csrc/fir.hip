@@ -383,27 +383,6 @@ __device__ __forceinline__ void load_rows(In in, size_t nb, int l, size_t n,
     }
 }
 
-// v_permlane32_swap / v_permlane16_swap on a complex register pair: (a, b) -> a keeps its lanes 0-31 and takes
-// b's lanes 0-31 into 32-63, b takes a's lanes 32-63 into 0-31 and keeps its own 32-63 (32); the same with the
-// four 16-lane rows, odd rows of a <-> even rows of b (16).  The builtins (not raw asm) so that the compiler
-// knows the instruction; the packed butterflies next to them are plain vector adds for the same reason -- the
-// hazard recogniser cannot see into an asm block -- and an asm operand produced right before a swap is fenced.
-__device__ __forceinline__ void lane_swap_fence(cf& a, cf& b) { asm volatile("s_nop 1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void lane_swap32(cf& a, cf& b) {
-    lane_swap_fence(a, b);
-    const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
-    const auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
-    a = cf{__uint_as_float(x[0]), __uint_as_float(y[0])};
-    b = cf{__uint_as_float(x[1]), __uint_as_float(y[1])};
-}
-__device__ __forceinline__ void lane_swap16(cf& a, cf& b) {
-    lane_swap_fence(a, b);
-    const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
-    const auto y = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
-    a = cf{__uint_as_float(x[0]), __uint_as_float(y[0])};
-    b = cf{__uint_as_float(x[1]), __uint_as_float(y[1])};
-}
-
 // One segment through the filter: the 16 rows v[a] (samples 64a + lane of the 1024-point segment)
 // -> forward transform, spectrum multiply, inverse transform -> v[R16_POS(a)] = filtered row a.
 // `lds` is the calling wave's private exchange buffer; stamp(i) marks the diagnostic phases.

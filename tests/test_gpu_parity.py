@@ -1101,6 +1101,35 @@ print("ok")
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
 
+def test_fft_trial_tile_kernel_gives_the_same_transforms():
+    """COMMS_FFT_TILE_DIRECT=1: fft1024x16d_kernel (register-layout loads, last radix-4 across lanes) in place of
+    fft1024x16_kernel on every pass that uses it -- 1024-point batches, pass 2 of 2^16 ... 2^19, both passes of 2^20,
+    the column pass of 2^21 -- forward and inverse, against numpy's f64 FFT.  Read once per process: own process."""
+    import subprocess
+    import sys
+
+    code = r'''
+import sys; sys.path.insert(0, %r)
+import numpy as np, torch, comms_rs_amd as c
+for logn, batch, inverse in ((10, 64, False), (10, 48, True), (16, 4, False), (17, 2, True), (19, 2, False), (20, 3, False), (20, 2, True), (21, 1, False)):
+    n = 1 << logn
+    x = torch.empty(n * batch, dtype=torch.complex64, device="cuda:0")
+    c.synth_iq_dev(x.data_ptr(), n * batch, 0, 190 + logn)
+    y = torch.empty_like(x)
+    c.FFTBatchNode(n, inverse).run_dev(x.data_ptr(), n * batch, y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    xs = c.synth_iq(n * batch, 0, 190 + logn).astype(np.complex128).reshape(batch, n)
+    want = np.fft.ifft(xs, axis=1) * n if inverse else np.fft.fft(xs, axis=1)
+    got = y.cpu().numpy().astype(np.complex128).reshape(batch, n)
+    d = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert d <= %r, (logn, d)
+print("ok")
+''' % (ROOT, TOL)
+    env = dict(os.environ, COMMS_FFT_TILE_DIRECT="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_fft_bluestein_on_a_padded_length_above_2p20(c):
     """A non-power-of-two length whose chirp-z padding (2^21) runs on the columns / rows / transpose path,
     forward and inverse, against numpy's f64 FFT."""
