@@ -869,6 +869,12 @@ __device__ __forceinline__ void x_signal(unsigned* cnt, bool lane_on) {
 // wait the kernel ran 6 % slower (614 against 579 us at 2^27 samples, scripts/ab_libs.py on five builds), and the kernel
 // sits at the scalar-register limit.)
 constexpr int X_SPINS = 1 << 22;  // x ~100 cycles per poll: a few tenths of a second
+#ifndef COMMS_OS16K_SLEEP_IN
+#define COMMS_OS16K_SLEEP_IN 1  // s_sleep argument (x 64 cycles) between two polls of the first / second wait
+#endif
+#ifndef COMMS_OS16K_SLEEP_OUT
+#define COMMS_OS16K_SLEEP_OUT 4  // (1 / 2 / 4 / 8 here: 591 / 589 / 585 / 588 us at 2^27 samples, seven builds in one process; IN: no difference)
+#endif
 __device__ __forceinline__ void x_wait_one(const unsigned* cnt, unsigned target, unsigned* gave_up) {
     bool ok = false;
     for (int spin = 0; spin < X_SPINS; ++spin) {
@@ -877,7 +883,7 @@ __device__ __forceinline__ void x_wait_one(const unsigned* cnt, unsigned target,
             ok = true;
             break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(COMMS_OS16K_SLEEP_IN);
     }
     if (!ok) __hip_atomic_fetch_or(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -890,7 +896,7 @@ __device__ __forceinline__ void x_wait_all16(const unsigned* cnt, unsigned targe
             ok = true;
             break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(COMMS_OS16K_SLEEP_OUT);
     }
     if (!ok) __hip_atomic_fetch_or(gave_up, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
