@@ -118,7 +118,7 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
     // every rate (2^24 samples, 127 taps: /2 85.8 against 95.9 us, /3 68 against 83, /8 60 against 82 -- the fused
     // form needs `rate` more halo samples per segment and an atan2 per output in a kernel short of issue slots) and
     // has no limit on taps + rate; COMMS_CHAIN_FM_SEPARATE=0 brings the in-kernel form back for comparison.
-    static const int fm_sep = [] { const char* v = getenv("COMMS_CHAIN_FM_SEPARATE"); return v && *v ? atoi(v) : 1; }();
+    static const int fm_sep = diag_knob("COMMS_CHAIN_FM_SEPARATE", 1);
     const bool can_fuse = can_fuse_nofm && (!h->fm_demod || (!fm_sep && rate <= 64 && n_taps + rate <= 257));
     const bool can_hybrid = h->fm_demod && can_fuse_nofm && !can_fuse;
     // the time-domain kernel against what would run otherwise: an overlap-save fusion, or the four kernels in
@@ -134,7 +134,7 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
     // taps 60 us at rate 17, 53 at 20, 39 at 32, 30 at 100, 11 at 1000; 127 taps 49 at 17; 63 taps 45 at 17
     // (profiles/r03_bench_chain_rates.txt) -- so from rate 17; taps up to 512, where the alternative is four kernels in
     // series.  COMMS_CHAIN_TIME_DOMAIN forces it wherever it can run.
-    static const int any_min_rate = [] { const char* v = getenv("COMMS_ANY_MIN_RATE"); return v && *v ? atoi(v) : 17; }();
+    static const int any_min_rate = diag_knob("COMMS_ANY_MIN_RATE", 17);
     const size_t any_from = static_cast<size_t>(any_min_rate);
     const bool can_any = st == COMMS_OK && !can_decim && !(flags & (COMMS_CHAIN_UNFUSED | COMMS_CHAIN_FREQ_DOMAIN)) &&
                          comms_fir_decim_any_supported(h->fir, static_cast<uint32_t>(rate)) &&

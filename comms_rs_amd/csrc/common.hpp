@@ -44,6 +44,21 @@ extern "C" COMMS_INTERNAL comms_status_t comms_fir_run_decim_any_dev(comms_fir_t
 
 namespace comms {
 
+// ---- tuning knobs ------------------------------------------------------------
+// Kernel selectors and sweep parameters (COMMS_OS1024_*, COMMS_DECIM_*, COMMS_FFT_*, ...) exist in the DIAGNOSTIC build
+// only (`make diag`, -DCOMMS_DIAG: scripts/ load it through scripts/with_lib.py), where they are read once from the
+// environment.  In the product build every knob is its default at compile time: no getenv on any launch path, nothing
+// in the environment changes which kernel runs or what it computes.  (The two documented runtime limits,
+// COMMS_ZERO_COPY_BYTES and COMMS_BUF_POOL_MB in runtime.hip, are resources, not kernel selectors.)
+#ifdef COMMS_DIAG
+inline int diag_knob(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+#else
+constexpr int diag_knob(const char*, int dflt) { return dflt; }
+#endif
+
 // ---- thread-local last error -------------------------------------------------
 inline char* err_buf() {
     static thread_local char buf[512] = {0};

@@ -130,6 +130,153 @@ __global__ __launch_bounds__(1024) void probe_fft_tile_kernel(const float2* __re
     }
 }
 
+
+// ---- read-only probes (round 5): what the decimating chain's INPUT side can reach without its arithmetic.
+// Grid-stride reads (V = float2 / float4), summed; the sum leaves only if it hits a value it never has.
+template <typename V>
+__global__ __launch_bounds__(256) void probe_read_kernel(const V* __restrict__ in, float* __restrict__ sink, size_t n) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    float acc = 0.f;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) acc += in[i].x;
+    if (acc == 12345.678f) sink[0] = acc;
+}
+// fir_decim_kernel<8, 2>'s tile traffic: a 256-lane workgroup reads tiles of 16 rows x 256 samples (+ half a halo row)
+// dealt round-robin over a persistent grid.  FLAGS bit 0: the next tile is requested before this one is consumed;
+// bit 1: the tile goes through LDS as 16 phase arrays with the kernel's two barriers; bit 2: nontemporal loads;
+// bit 3: 16 bytes per lane (8 rows of 4 KiB); bit 4: one 4-byte output per two lanes' worth of tile is stored
+// (the FM chain's 1/16 of the input bytes).
+template <int FLAGS>
+__global__ __launch_bounds__(256, 4) void probe_read_tile_kernel(const float2* __restrict__ in, float* __restrict__ sink,
+                                                                 float* __restrict__ out, size_t n_tiles) {
+    constexpr bool PF = FLAGS & 1, LDSST = (FLAGS & 2) != 0, NT = (FLAGS & 4) != 0, WIDE = (FLAGS & 8) != 0, ST = (FLAGS & 16) != 0;
+    constexpr int S = 273;
+    __shared__ float2 sh[LDSST ? 16 * S : 1];
+    const int tid = threadIdx.x;
+    float acc = 0.f;
+    constexpr int NR = WIDE ? 8 : 16;
+    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+    float4 xa[WIDE ? NR : 1], xb[WIDE ? NR : 1];
+    float2 ya[WIDE ? 1 : NR + 1], yb[WIDE ? 1 : NR + 1];
+    auto fetch = [&](size_t t, auto& xv, auto& yv) {
+        const float2* base = in + t * 4096;
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                if (NT) {
+                    const nt_f4 q = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(base) + tid + 256 * m);
+                    xv[m] = make_float4(q.x, q.y, q.z, q.w);
+                } else
+                    xv[m] = reinterpret_cast<const float4*>(base)[tid + 256 * m];
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                if (NT) {
+                    const nt_f2 q = __builtin_nontemporal_load(reinterpret_cast<const nt_f2*>(base) + tid + 256 * m);
+                    yv[m] = make_float2(q.x, q.y);
+                } else
+                    yv[m] = base[tid + 256 * m];
+            }
+            yv[NR] = (t > 0 && tid < 128) ? base[tid - 128] : make_float2(0.f, 0.f);  // halo: the last 128 samples of the tile before
+        }
+    };
+    auto consume = [&](size_t t, auto& xv, auto& yv) {
+        if constexpr (LDSST && !WIDE) {
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                const unsigned s = static_cast<unsigned>(tid + 256 * m);
+                sh[(s & 15) * S + 8 + (s >> 4)] = yv[m];
+            }
+            if (tid < 128) sh[(tid & 15) * S + (tid >> 4)] = yv[NR];
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            acc += sh[(tid & 15) * S + 8 + (tid >> 4)].x;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else if constexpr (WIDE) {
+#pragma unroll
+            for (int m = 0; m < NR; ++m) acc += xv[m].x + xv[m].z;
+        } else {
+#pragma unroll
+            for (int m = 0; m <= NR; ++m) acc += yv[m].x;
+        }
+        if (ST) {
+            out[t * 512 + tid] = acc;
+            out[t * 512 + 256 + tid] = acc + 1.f;
+        }
+    };
+    size_t t = blockIdx.x;
+    if (PF) {
+        if (t < n_tiles) fetch(t, xa, ya);
+        for (; t < n_tiles; t += 2 * static_cast<size_t>(gridDim.x)) {
+            const size_t t2 = t + gridDim.x, t3 = t2 + gridDim.x;
+            if (t2 < n_tiles) fetch(t2, xb, yb);
+            consume(t, xa, ya);
+            if (t3 < n_tiles) fetch(t3, xa, ya);
+            if (t2 < n_tiles) consume(t2, xb, yb);
+        }
+    } else {
+        for (; t < n_tiles; t += gridDim.x) {
+            fetch(t, xa, ya);
+            consume(t, xa, ya);
+        }
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
+
+// Wave-private streaming (the shape of a barrier-free decimating chain): a wave reads tiles of 16 rows x 64 samples
+// (512 B per instruction, 8 KiB per tile), `nt_chunk` consecutive tiles per chunk, chunks dealt round-robin over
+// all the waves of a persistent grid; the next tile is requested before this one is consumed.  FLAGS bit 0:
+// nontemporal loads; bit 1: 512 B stored per wave and tile (an FM chain's output at rate 8); bit 2: 16 B per lane.
+template <int FLAGS>
+__global__ __launch_bounds__(256, 4) void probe_read_wave_kernel(const float2* __restrict__ in, float* __restrict__ sink,
+                                                                 float2* __restrict__ out, size_t n_tiles, int nt_chunk) {
+    constexpr bool NT = FLAGS & 1, ST = (FLAGS & 2) != 0, WIDE = (FLAGS & 4) != 0;
+    const int l = threadIdx.x & 63;
+    const size_t wave = static_cast<size_t>(blockIdx.x) * 4 + (threadIdx.x >> 6), n_waves = static_cast<size_t>(gridDim.x) * 4;
+    const size_t n_chunks = (n_tiles + nt_chunk - 1) / nt_chunk;
+    float acc = 0.f;
+    float2 xa[16], xb[16];
+    auto fetch = [&](size_t t, float2 (&x)[16]) __attribute__((always_inline)) {
+        const float2* base = in + t * 1024;
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                nt_f4 q;
+                if (NT) q = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(base) + l + 64 * m);
+                else { const float4 v = reinterpret_cast<const float4*>(base)[l + 64 * m]; q = nt_f4{v.x, v.y, v.z, v.w}; }
+                x[2 * m] = make_float2(q.x, q.y);
+                x[2 * m + 1] = make_float2(q.z, q.w);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                if (NT) {
+                    const nt_f2 q = __builtin_nontemporal_load(reinterpret_cast<const nt_f2*>(base) + l + 64 * m);
+                    x[m] = make_float2(q.x, q.y);
+                } else
+                    x[m] = base[l + 64 * m];
+            }
+        }
+    };
+    auto consume = [&](size_t t, const float2 (&x)[16]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) acc += x[m].x;
+        if (ST) out[t * 64 + l] = make_float2(acc, acc + 1.f);
+    };
+    for (size_t c = wave; c < n_chunks; c += n_waves) {
+        const size_t t0 = c * nt_chunk, t1 = t0 + nt_chunk < n_tiles ? t0 + nt_chunk : n_tiles;
+        fetch(t0, xa);
+        for (size_t t = t0; t < t1; t += 2) {
+            if (t + 1 < t1) fetch(t + 1, xb);
+            consume(t, xa);
+            if (t + 2 < t1) fetch(t + 2, xa);
+            if (t + 1 < t1) consume(t + 1, xb);
+        }
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
 }  // namespace comms
 
 using namespace comms;
@@ -182,6 +329,44 @@ extern "C" comms_status_t comms_debug_copy(const void* d_in, void* d_out, size_t
         probe_tile4_kernel<<<dim3((runs + 3) / 4), dim3(256), 0, s>>>(static_cast<const float4*>(d_in), static_cast<float4*>(d_out), ntiles, runs);
     }
     return launch_ok("probe kernel");
+}
+
+
+// read-only probes: mode 0 / 1 grid-stride float4 / float2; 100 + FLAGS the decimating chain's tile pattern
+// (probe_read_tile_kernel), wgs_per_cu persistent workgroups per CU
+extern "C" comms_status_t comms_debug_read(const void* d_in, size_t n_c32, int mode, int wgs_per_cu, float* d_sink,
+                                           float* d_out, void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (mode == 0)
+        probe_read_kernel<float4><<<dim3(8 * kNumCU), dim3(256), 0, s>>>(static_cast<const float4*>(d_in), d_sink, n_c32 / 2);
+    else if (mode == 1)
+        probe_read_kernel<float2><<<dim3(8 * kNumCU), dim3(256), 0, s>>>(static_cast<const float2*>(d_in), d_sink, n_c32);
+    else if (mode >= 100 && mode < 132) {
+        const size_t n_tiles = n_c32 / 4096;
+        const dim3 g(static_cast<unsigned>(wgs_per_cu) * kNumCU), b(256);
+        const float2* in = static_cast<const float2*>(d_in);
+        switch (mode - 100) {
+#define COMMS_RT(F) case F: probe_read_tile_kernel<F><<<g, b, 0, s>>>(in, d_sink, d_out, n_tiles); break;
+            COMMS_RT(0) COMMS_RT(1) COMMS_RT(2) COMMS_RT(3) COMMS_RT(4) COMMS_RT(5) COMMS_RT(6) COMMS_RT(7)
+            COMMS_RT(8) COMMS_RT(9) COMMS_RT(12) COMMS_RT(13) COMMS_RT(16) COMMS_RT(17) COMMS_RT(18) COMMS_RT(19) COMMS_RT(20) COMMS_RT(21) COMMS_RT(22) COMMS_RT(23)
+#undef COMMS_RT
+            default: return COMMS_ERR_ARG;
+        }
+    } else if (mode >= 200 && mode < 208) {
+        // wave-private streaming: wgs_per_cu = nt_chunk * 16 + workgroups per CU (4 waves each)
+        const size_t n_tiles = n_c32 / 1024;
+        const int wg = wgs_per_cu & 15, ntc = wgs_per_cu >> 4;
+        const dim3 g(static_cast<unsigned>(wg) * kNumCU), b(256);
+        const float2* in = static_cast<const float2*>(d_in);
+        float2* o2 = reinterpret_cast<float2*>(d_out);
+        switch (mode - 200) {
+#define COMMS_RW(F) case F: probe_read_wave_kernel<F><<<g, b, 0, s>>>(in, d_sink, o2, n_tiles, ntc); break;
+            COMMS_RW(0) COMMS_RW(1) COMMS_RW(2) COMMS_RW(3) COMMS_RW(4) COMMS_RW(5) COMMS_RW(6) COMMS_RW(7)
+#undef COMMS_RW
+        }
+    } else
+        return COMMS_ERR_ARG;
+    return launch_ok("probe read kernel");
 }
 
 // ---- VALU issue-rate probe: ITER x 16 independent ops per lane

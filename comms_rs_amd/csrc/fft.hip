@@ -362,6 +362,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void fft1024x16_kernel(c
     kstamp_end(p.ks);
 }
 
+#ifdef COMMS_DIAG  // (diagnostic build only: a measured-no-faster trial, kept for the comparison it records)
 // ---------------------------------------------------------------- the same tile, two LDS trips shorter (round 4 trial)
 // fft1024x16_kernel<DIR, 16> with (1) the tile loaded straight into the transform's register layout -- rows: wave w
 // reads transform w, point 64 a + lane into register a (512-B runs); columns: thread (c, t) = (tid & 15, tid >> 4)
@@ -488,6 +489,7 @@ __global__ __launch_bounds__(1024, 4) void fft1024x16d_kernel(const cf* in, cf* 
     }
     kstamp_end(p.ks);
 }
+#endif  // COMMS_DIAG
 
 // ---------------------------------------------------------------- N = RAD * 1024 in ONE pass (RAD = 1, 2, 4, 8, 16)
 // n = 1024 n1 + n2, k = k1 + RAD k2:
@@ -1401,7 +1403,7 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
         // 258 vs 226 Gpoints/s); four-step passes keep 16 columns = 128-B row pieces
         // short transforms: full 16384-point tiles (1024 lanes, 128 KiB of LDS) -- with 16 transforms
         // per tile a 64-point batch ran one wave per workgroup (74 -> 173 Gpoints/s)
-        static const size_t tile_pts = [] { const char* v = getenv("COMMS_FFT_TILE_PTS"); return static_cast<size_t>(v && *v ? atoi(v) : 16384); }();
+        static const size_t tile_pts = static_cast<size_t>(diag_knob("COMMS_FFT_TILE_PTS", 16384));
         tile_geometry(p, static_cast<int>(N), N == 1024 ? 8 : (N < 1024 ? tile_pts / N : 16));
         // rows mode: tile = C consecutive transforms; the "transform" seen by the
         // kernel is the tile itself (distance C*N), one tile per transform
@@ -1535,6 +1537,7 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
         COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft1024x16_kernel<-1, 16, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
+#ifdef COMMS_DIAG
         COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft1024x16d_kernel<1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
         COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft1024x16d_kernel<-1>),
@@ -1543,6 +1546,7 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
         COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft1024x16d_kernel<-1, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
+#endif
         COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft1024x16_kernel<1, 8>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, fw_lds));
         COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fft1024x16_kernel<-1, 8>),
@@ -1636,19 +1640,19 @@ static comms_status_t pow2_plan_build(Pow2Plan& pl, size_t N) {
 // Runs `batch` transforms of length pl.N.  In-place (in == out) is fine: every
 // tile is fully read before it is written and tiles do not overlap; pass 2
 // reads what pass 1 wrote to `out`.
+#ifdef COMMS_DIAG
 static bool fft_tile_direct() {  // trial kernel fft1024x16d_kernel (see there): off unless COMMS_FFT_TILE_DIRECT=1
-    static const bool v = [] {
-        const char* e = getenv("COMMS_FFT_TILE_DIRECT");
-        return e && *e && *e != '0';
-    }();
+    static const bool v = diag_knob("COMMS_FFT_TILE_DIRECT", 0) != 0;
     return v;
 }
+#endif
 static comms_status_t launch_fast(Pow2Plan& pl, const float2* src, float2* dst, const FftTileParams& p,
                                   bool inverse, hipStream_t s) {
     const cf* t1 = reinterpret_cast<const cf*>(pl.d_fw1);
     const cf* t2 = reinterpret_cast<const cf*>(pl.d_fw2);
     const cf* a = reinterpret_cast<const cf*>(src);
     cf* d = reinterpret_cast<cf*>(dst);
+#ifdef COMMS_DIAG
     if (p.C == 16 && fft_tile_direct()) {  // trial: register-layout loads, last radix-4 across lanes
         const size_t lds = (1024 + 64 + 16 * FW_BUF + 256) * sizeof(float2);
         const unsigned blocks = static_cast<unsigned>(p.n_tiles < static_cast<size_t>(kNumCU) ? p.n_tiles : kNumCU);
@@ -1663,6 +1667,7 @@ static comms_status_t launch_fast(Pow2Plan& pl, const float2* src, float2* dst, 
             fft1024x16d_kernel<-1><<<dim3(blocks), dim3(1024), lds, s>>>(a, d, p, t1, t2);
         return launch_ok("fft1024x16d_kernel");
     }
+#endif
     if (p.C == 16) {  // one 16-wave workgroup per CU
         const size_t lds = (1024 + 64 + 16 * FW_BUF + 256) * sizeof(float2);
         const unsigned blocks = static_cast<unsigned>(p.n_tiles < static_cast<size_t>(kNumCU) ? p.n_tiles : kNumCU);
@@ -1815,15 +1820,9 @@ static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size
     // only the four-step passes of N = 2^15 ... 2^20 stamp (both of them: the call from its first workgroup in to its last
     // wave out); the column pass of the larger lengths does not, so those stay unstamped altogether
     pl.pass[0].ks = pl.pass[1].ks = pl.rows ? KStamp{nullptr, nullptr} : ks;
-    static const bool no_rx = [] {
-        const char* v = getenv("COMMS_FFT_NO_RX");
-        return v && *v && *v != '0';
-    }();
+    static const bool no_rx = diag_knob("COMMS_FFT_NO_RX", 0) != 0;
     if (pl.rx_rad && !no_rx) return run_rx(pl, in, out, batch * pl.N, inverse, s);
-    static const bool no_rx32k = [] {
-        const char* v = getenv("COMMS_FFT_NO_RX32K");
-        return v && *v && *v != '0';
-    }();
+    static const bool no_rx32k = diag_knob("COMMS_FFT_NO_RX32K", 0) != 0;
     if (pl.d_rx32 && !no_rx32k) {  // N = 32768: one pass, a transform per workgroup and step
         const unsigned blocks = static_cast<unsigned>(batch < static_cast<size_t>(kNumCU) ? batch : kNumCU);
         const cf* t1 = reinterpret_cast<const cf*>(pl.d_fw1);
@@ -1839,7 +1838,7 @@ static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size
         // N = 2^21 ... 2^24 in two passes: N / 1024-point columns gathered in pieces of 64 ... 8 B (small pieces cost far less
         // on the read side than on the write side: scripts/probes/strided_tiles.hip), spectra out in runs of 1 KiB ... 128 B;
         // then 1024-point rows, sixteen adjacent ones per tile, stored transposed in 128-byte pieces.
-        static const int gather_max = [] { const char* v = getenv("COMMS_FFT_LARGE_GATHER"); return v && *v ? atoi(v) : 23; }();
+        static const int gather_max = diag_knob("COMMS_FFT_LARGE_GATHER", 23);
         if (ilog2(pl.N) <= gather_max && pl.rows->rx_rad >= 2) {
             const cf* lo = pl.pass[0].tw_lo;
             const cf* hi = pl.pass[0].tw_hi;
@@ -1878,7 +1877,7 @@ static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size
             if (full && pl.fast(i)) {
                 COMMS_TRY(launch_fast(pl, src, dst, p, inverse, s));
             } else if (full) {
-                static const unsigned wgs = [] { const char* v = getenv("COMMS_FFT_TILE_WGS"); return static_cast<unsigned>(v && *v ? atoi(v) : 4); }();
+                static const unsigned wgs = static_cast<unsigned>(diag_knob("COMMS_FFT_TILE_WGS", 4));
                 unsigned blocks = static_cast<unsigned>(full < wgs * kNumCU ? full : wgs * kNumCU);
                 if (inverse)
                     fft_tile_kernel<1><<<dim3(blocks), dim3(pl.threads[i]), pl.lds[i], s>>>(reinterpret_cast<const cf*>(src), reinterpret_cast<cf*>(dst), p);
@@ -1912,10 +1911,7 @@ static comms_status_t pow2_run(Pow2Plan& pl, const float2* in, float2* out, size
                 src = scratch;
             }
             p.n_tiles = batch * p.tiles_per_xform;
-            static const bool no_cols = [] {
-                const char* v = getenv("COMMS_FFT_NO_COLS");
-                return v && *v && *v != '0';
-            }();
+            static const bool no_cols = diag_knob("COMMS_FFT_NO_COLS", 0) != 0;
             if (i == 0 && pl.col_kind >= 0 && !no_cols) {
                 switch (pl.col_kind) {
                     case 0: COMMS_TRY(launch_cols<0>(pl, src, dst, batch, inverse, s)); break;
@@ -1974,10 +1970,7 @@ static comms_status_t fft_setup(comms_fft* h) {
     }
     // short odd lengths: the exact-index O(N^2) DFT (f64 accumulation); above that Bluestein on the
     // power-of-two kernels is faster by far (N = 1000: 2.3 -> 20 Gpoints/s) -- measured crossover ~64
-    static const size_t direct_max = [] {
-        const char* v = getenv("COMMS_FFT_DIRECT_MAX");
-        return static_cast<size_t>(v && *v ? atol(v) : 64);
-    }();
+    static const size_t direct_max = static_cast<size_t>(diag_knob("COMMS_FFT_DIRECT_MAX", 64));
     if (N <= direct_max && N <= 4096) {
         h->kind = 1;
         return upload_tw(N, N, 1, &h->d_twN);
@@ -2079,10 +2072,7 @@ comms_status_t comms_fft_run_dev(comms_fft_t* h, const comms_c32* d_in, size_t n
         // four-step: pass 1 -> scratch -> pass 2, in groups that bound the scratch buffer.
         // (Small groups, sized so the intermediate stays in the 256 MiB Infinity Cache, were
         // measured and lose: 2^20 x 64 runs 0.56 ms ungrouped, 0.66 ms at 64 MiB, 2.3 ms at 8 MiB.)
-        static const size_t group_bytes = [] {
-            const char* v = getenv("COMMS_FFT_GROUP_MB");
-            return static_cast<size_t>(v && *v ? atoi(v) : 2048) << 20;
-        }();
+        static const size_t group_bytes = static_cast<size_t>(diag_knob("COMMS_FFT_GROUP_MB", 2048)) << 20;
         size_t group = group_bytes / (h->N * sizeof(float2));
         if (group < 1) group = 1;
         if (group > batch) group = batch;
@@ -2126,10 +2116,7 @@ comms_status_t comms_fft_run_dev(comms_fft_t* h, const comms_c32* d_in, size_t n
     if (h->plan.n_pass == 2) COMMS_TRY(h->work2.reserve(chunk * M * sizeof(float2)));
     float2* a = static_cast<float2*>(h->work.p);
     float2* sc = static_cast<float2*>(h->work2.p);
-    static const bool no_fuse = [] {
-        const char* v = getenv("COMMS_FFT_BLU_UNFUSED");
-        return v && *v && *v != '0';
-    }();
+    static const bool no_fuse = diag_knob("COMMS_FFT_BLU_UNFUSED", 0) != 0;
     const bool fuse = h->plan.rx_rad != 0 && !no_fuse;  // padded length on the single-pass kernel (M <= 16384)
     unsigned logM = 0;
     while ((static_cast<size_t>(1) << logM) < M) ++logM;

@@ -1469,11 +1469,8 @@ static float2 unit_root_os(long long e, int denom) {
     return make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
 }
 
-// Tuning knobs read once from the environment (scripts/bench_fir.py sweeps them).
-static int tune_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
+// Tuning knobs (scripts/bench_fir.py sweeps them in the diagnostic build; compile-time defaults in the product: common.hpp)
+static int tune_int(const char* name, int dflt) { return diag_knob(name, dflt); }
 
 // Filter spectrum + twiddle tables for the 4096-point overlap-save kernel (f64 on
 // the host, rounded once to f32).
@@ -2251,10 +2248,7 @@ static bool pulse_poly_try(comms_pulse* h, const float2* sym, size_t n_sym, floa
     return true;
 }
 static bool pulse_poly_launch(comms_pulse* h, const float2* sym, size_t n_sym, float2* out, hipStream_t s) {
-    static const bool off = [] {
-        const char* v = getenv("COMMS_PULSE_GENERIC");
-        return v && *v && *v != '0';
-    }();
+    static const bool off = diag_knob("COMMS_PULSE_GENERIC", 0) != 0;
     if (off) return false;
     switch (h->sps) {
         case 2: return pulse_poly_try<2>(h, sym, n_sym, out, s);

@@ -28,6 +28,16 @@
 #include "fir_handle.hpp"
 #include "sgpr_mac.hpp"
 
+#ifndef COMMS_DECIM_PREFETCH
+#define COMMS_DECIM_PREFETCH 0
+#endif
+#ifndef COMMS_DECIM_TILE_DEFAULT
+#define COMMS_DECIM_TILE_DEFAULT 0
+#endif
+#ifndef COMMS_DECIM_NOMAC_DEFAULT
+#define COMMS_DECIM_NOMAC_DEFAULT 0
+#endif
+
 namespace comms {
 
 constexpr int DC_TILE = 512;        // outputs per tile (DcGeom<.., TILE>: 1024 in the diagnostic build's wide variant)
@@ -117,6 +127,21 @@ __device__ __forceinline__ float fm_step_fast(float2 x, float2 p) {
     return fast_atan2f(x.x * pci + x.y * pcr, x.x * pcr - x.y * pci);
 }
 
+// A sample of the input stream, read once by this launch (the tile's halo a second time).  COMMS_DECIM_NT=1 (trial
+// build): Complex<f32> rows as nontemporal loads.
+#ifndef COMMS_DECIM_NT
+#define COMMS_DECIM_NT 0
+#endif
+template <class In>
+__device__ __forceinline__ float2 ld_once(In in, size_t i) { return in[i]; }
+#if COMMS_DECIM_NT
+__device__ __forceinline__ float2 ld_once(const float2* in, size_t i) {
+    typedef float nt_f2 __attribute__((ext_vector_type(2)));
+    const nt_f2 q = __builtin_nontemporal_load(reinterpret_cast<const nt_f2*>(in) + i);
+    return make_float2(q.x, q.y);
+}
+#endif
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would
 // stall on the next tile's global loads that are deliberately left in flight across it.
 __device__ __forceinline__ void lds_barrier() {  // (kept light: nothing global is shared between waves here)
@@ -159,8 +184,12 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
     // outputs after the filter -- the filter is linear), and a part that never changes,
     // lrow[m] = e^{i (tid + WG m) dphi} (f32, set up once): one multiply per staged sample.
     //   mixer after the FIR: ro = rot(R (jb + OPL tid)) is this lane's first output's rotor.
-    constexpr int NROW = PRE ? PR : 1;
-    cf lrow[NROW], lhalo[HROWS];
+    // (prefetching build: the row rotors are re-made from the lane's l0 / h0 and the wave-uniform steps for every tile --
+    // two packed operations per staged row -- instead of living in 2 (PR + HROWS) registers through the filter loop,
+    // where the next tile's rows now wait; the products are the same f32 operations either way)
+    constexpr bool kRowRotorsPerTile = COMMS_DECIM_PREFETCH != 0;
+    constexpr int NROW = PRE && !kRowRotorsPerTile ? PR : 1;
+    cf lrow[NROW], lhalo[kRowRotorsPerTile ? 1 : HROWS];
     double tt_c = 1.0, tt_s = 0.0, ro_c = 1.0, ro_s = 0.0;
     {
         const long long jb0 = static_cast<long long>(t0) * ts - ovl;
@@ -173,7 +202,7 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
 #pragma unroll
             for (int m = 0; m < NROW; ++m) lrow[m] = m ? cmulf(l0, to_cf(a.step[m])) : l0;
 #pragma unroll
-            for (int m = 0; m < HROWS; ++m) lhalo[m] = m ? cmulf(h0, to_cf(a.step[m])) : h0;
+            for (int m = 0; m < (kRowRotorsPerTile ? 1 : HROWS); ++m) lhalo[m] = m ? cmulf(h0, to_cf(a.step[m])) : h0;
             rotor_at(a.turns0 + static_cast<uint64_t>(R * jb0) * a.frac, tt_c, tt_s);
         }
         if (post) rotor_at(a.turns0 + static_cast<uint64_t>(R * (jb0 + OPL * tid)) * a.frac, ro_c, ro_s);
@@ -199,14 +228,14 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
     // tile's rows before this tile's filter loop was measured, twice, and does not pay: 47.5 -> 48.5 us on the
     // metric chain, 147 -> 152 us on config 3 -- the workgroups of a CU already cover each other's loads.)
     cf x[PR], xh[HROWS];
-    auto load_tile_from = [&](auto in, size_t t) {
+    auto load_tile_from = [&](auto in, size_t t) __attribute__((always_inline)) {
         const long long ib = R * (static_cast<long long>(t) * ts - ovl);
         if (ib - hl >= 0 && static_cast<size_t>(ib) + static_cast<size_t>(WG) * PR <= a.n) {  // interior tile: no edge handling
             const size_t base = static_cast<size_t>(ib) + static_cast<unsigned>(tid);
 #pragma unroll
-            for (int m = 0; m < PR; ++m) x[m] = to_cf(in[base + WG * m]);
+            for (int m = 0; m < PR; ++m) x[m] = to_cf(ld_once(in, base + WG * m));
 #pragma unroll
-            for (int m = 0; m < HROWS; ++m) xh[m] = slot_h[m] >= 0 ? to_cf(in[base - hl + WG * m]) : cf{0.f, 0.f};
+            for (int m = 0; m < HROWS; ++m) xh[m] = slot_h[m] >= 0 ? to_cf(ld_once(in, base - hl + WG * m)) : cf{0.f, 0.f};
         } else {
 #pragma unroll
             for (int m = 0; m < PR; ++m) x[m] = to_cf(stream_at(in, a.hist, a.hist_len, ib + tid + WG * m, a.n));
@@ -216,7 +245,7 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
                                        : cf{0.f, 0.f};
         }
     };
-    auto load_tile = [&](size_t t) {
+    auto load_tile = [&](size_t t) __attribute__((always_inline)) {
         switch (a.fmt) {   // wave-uniform: one scalar branch per tile
             case COMMS_IQ_I16: load_tile_from(InI16{static_cast<const short2*>(a.in), a.in_scale}, t); break;
             case COMMS_IQ_U8: load_tile_from(InU8{static_cast<const uchar2*>(a.in)}, t); break;
@@ -236,16 +265,30 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
     }
     if (a.stamps) st_prev = __builtin_amdgcn_s_memtime();
 
+#if COMMS_DECIM_PREFETCH
+    load_tile(t0);
+#endif
     for (size_t t = t0; t < t1; t += tstep) {
         const long long jb = static_cast<long long>(t) * ts - ovl;  // first output computed by this tile
         // ---- stage the tile: PR rows of new samples, then the halo
+#if !COMMS_DECIM_PREFETCH
         load_tile(t);
+#endif
         DC_STAMP(0)  // global loads landed
         if (pre) {
+            if constexpr (kRowRotorsPerTile) {
+                cf l0 = lrow[0], h0 = lhalo[0];
+                asm volatile("" : "+v"(l0), "+v"(h0));  // (opaque per tile: keeps the row rotors from being hoisted back out of the loop)
 #pragma unroll
-            for (int m = 0; m < PR; ++m) x[m] = cmulf(x[m], lrow[m < NROW ? m : 0]);
+                for (int m = 0; m < PR; ++m) x[m] = cmulf(x[m], m ? cmulf(l0, to_cf(a.step[m])) : l0);
 #pragma unroll
-            for (int m = 0; m < HROWS; ++m) xh[m] = cmulf(xh[m], lhalo[m]);
+                for (int m = 0; m < HROWS; ++m) xh[m] = cmulf(xh[m], m ? cmulf(h0, to_cf(a.step[m])) : h0);
+            } else {
+#pragma unroll
+                for (int m = 0; m < PR; ++m) x[m] = cmulf(x[m], lrow[m < NROW ? m : 0]);
+#pragma unroll
+                for (int m = 0; m < HROWS; ++m) xh[m] = cmulf(xh[m], lhalo[m < (kRowRotorsPerTile ? 1 : HROWS) ? m : 0]);
+            }
         }
 #pragma unroll
         for (int m = 0; m < PR; ++m) sh[kLinearSlots ? slot[0] + (WG / PR) * m : slot[m < NSLOT ? m : 0]] = x[m];
@@ -255,6 +298,9 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
         DC_STAMP(1)  // mixer + LDS writes
         lds_barrier();
         DC_STAMP(2)
+#if COMMS_DECIM_PREFETCH
+        if (t + tstep < t1) load_tile(t + tstep);  // the next tile's rows travel while this tile's taps run
+#endif
 
         // ---- outputs j = jb + OPL tid + c:  y_c = sum_k h[k] u[R j - k]
         // tile sample index of u[R j - k] is PR (tid + hlq) + (R c - k) = PR (tid + hlq - d) + p with
@@ -396,7 +442,13 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
         }
         const long long j0 = jb + OPL * tid;
         if (fm) {
-            if (j0 < 0) y[0] = a.fm_prev[0];  // FM.prev of the previous call stands in for y[-1]
+            if (j0 < 0) {  // FM.prev of the previous call stands in for y[-1]
+                // (a scalar load: as a vector load into y[0] it made every later use of y[0] wait for vmcnt(0), i.e. for the
+                // next tile's rows as well; another launch wrote the word, this one never does)
+                typedef const __attribute__((address_space(4))) float* cfp;
+                const cfp pp = (cfp)(a.fm_prev);
+                y[0] = make_float2(pp[0], pp[1]);
+            }
             if (l == 63) sh_y[w] = y[OPL - 1];
         }
         lds_barrier();  // sh_y visible; every lane is done reading the staged tile
@@ -465,10 +517,7 @@ static comms_status_t launch_decim_v(const DecimArgs& a, hipStream_t s) {
 static int decim_opl(bool real, int macs_per_input) {
     (void)macs_per_input;
 #ifdef COMMS_DIAG
-    static const int forced = [] {
-        const char* v = getenv("COMMS_DECIM_OPL");
-        return v && *v ? atoi(v) : 0;
-    }();
+    static const int forced = diag_knob("COMMS_DECIM_OPL", 0);
     if (real && forced == 4) return 4;
 #else
     (void)real;
@@ -480,11 +529,8 @@ static int decim_opl(bool real, int macs_per_input) {
 // SIMD holds are in the same phase more often)
 static int decim_tile(bool real, int R, int opl) {
 #ifdef COMMS_DIAG
-    static const int forced = [] {
-        const char* v = getenv("COMMS_DECIM_TILE");
-        return v && *v ? atoi(v) : 0;
-    }();
-    if (real && opl == 2 && R == 8 && forced == 1024) return 1024;
+    static const int forced = diag_knob("COMMS_DECIM_TILE", COMMS_DECIM_TILE_DEFAULT);
+    if (real && opl == 2 && R == 8 && (forced == 1024 || forced == 256)) return forced;
 #else
     (void)real; (void)R; (void)opl;
 #endif
@@ -496,9 +542,10 @@ static comms_status_t launch_decim(const DecimArgs& a, bool real, int opl, int t
     const bool pre = (a.mode & COMMS_CHAIN_PRE) != 0;
 #ifdef COMMS_DIAG
     if constexpr (R == 8) {
-        static const int chx = [] { const char* v = getenv("COMMS_DECIM_CH"); return v && *v ? atoi(v) : 0; }();
+        static const int chx = diag_knob("COMMS_DECIM_CH", 0);
         if (chx == 16 && real && opl == 2 && !pre && tile == DC_TILE) return launch_decim_v<R, 2, true, false, DC_TILE, 16>(a, s);
         if (tile == 1024) return pre ? launch_decim_v<R, 2, true, true, 1024>(a, s) : launch_decim_v<R, 2, true, false, 1024>(a, s);
+        if (tile == 256) return pre ? launch_decim_v<R, 2, true, true, 256>(a, s) : launch_decim_v<R, 2, true, false, 256>(a, s);
     }
 #else
     (void)tile;
@@ -556,10 +603,7 @@ static int32_t decim_macs(const comms_fir_t* h, uint32_t rate) {
 int32_t comms_fir_decim_supported_for(const comms_fir_t* h, uint32_t rate, int32_t fm_demod, int32_t can_fuse) {
     const int macs = decim_macs(h, rate);
     if (macs < 0) return 0;
-    static const int max_macs = [] {
-        const char* v = getenv("COMMS_DECIM_MAX_MACS");
-        return v && *v ? atoi(v) : 0;
-    }();
+    static const int max_macs = diag_knob("COMMS_DECIM_MAX_MACS", 0);
     const int limit = max_macs > 0 ? max_macs : !can_fuse ? 96 : fm_demod ? 48 : 44;
     return macs <= limit ? 2 : 1;
 }
@@ -610,10 +654,13 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
     a.turns0 = turns0;
     a.frac = frac;
     a.stamps = g_decim_stamps;
-    if (getenv("COMMS_DECIM_DEBUG_NOMAC")) a.nd = 0;  // diagnostic: staging + epilogue only
+#ifdef COMMS_DIAG
+    static const int nomac = diag_knob("COMMS_DECIM_DEBUG_NOMAC", COMMS_DECIM_NOMAC_DEFAULT);
+    if (nomac) a.nd = 0;  // diagnostic build only: staging + epilogue without the filter loop (wrong results; timing)
+#endif
     // tile order: interleaved over the workgroups by default (config 3 at 2^26: 145 -> 142 us per step, neutral
     // at 2^24); COMMS_DECIM_INTERLEAVE=0 gives every workgroup a contiguous run again
-    static const int interleave = [] { const char* v = getenv("COMMS_DECIM_INTERLEAVE"); return v && *v ? atoi(v) : 1; }();
+    static const int interleave = diag_knob("COMMS_DECIM_INTERLEAVE", 1);
     a.interleave = interleave;
     mix_host_rotor(static_cast<uint64_t>(R) * ts * frac, a.tile_c, a.tile_s);
     double c, sn;

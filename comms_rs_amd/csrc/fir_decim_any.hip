@@ -334,7 +334,7 @@ comms_status_t comms_fir_run_decim_any_dev(comms_fir_t* h, const void* d_in, siz
     // STAGED while neighbouring windows share most of their samples: below rate max(48, 0.4 taps) (255 taps: staged 33 us
     // against 42 direct at rate 64, a tie at 100; 127 and 63 taps: direct ahead from rate 64, a tie at 48 --
     // scripts/bench_chain_any.py, profiles/r03_bench_chain_rates.txt); COMMS_ANY_STAGED=0/1 forces one form
-    static const int forced = [] { const char* v = getenv("COMMS_ANY_STAGED"); return v && *v ? atoi(v) : -1; }();
+    static const int forced = diag_knob("COMMS_ANY_STAGED", -1);
     const int staged_below = 2 * N / 5 > 48 ? 2 * N / 5 : 48;
     bool staged = forced >= 0 ? forced != 0 : R < staged_below;
     AnyArgs a{};

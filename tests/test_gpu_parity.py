@@ -17,6 +17,7 @@ import pytest
 import oracle
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIAG_LIB = os.path.join(ROOT, "comms_rs_amd", "lib", "libcomms_hip_diag.so")  # build()'s diagnostic build: the only one with kernel selectors
 
 pytestmark = pytest.mark.gpu
 
@@ -1096,7 +1097,7 @@ for logn, inverse in ((21, False), (22, True), (23, False), (24, True)):
     assert d <= %r, (logn, d)
 print("ok")
 ''' % (ROOT, TOL)
-    env = dict(os.environ, COMMS_FFT_LARGE_GATHER=str(gather_max))
+    env = dict(os.environ, COMMS_FFT_LARGE_GATHER=str(gather_max), COMMS_HIP_LIB=DIAG_LIB)  # kernel selectors exist in the diagnostic build only
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
@@ -1125,7 +1126,7 @@ for logn, batch, inverse in ((10, 64, False), (10, 48, True), (16, 4, False), (1
     assert d <= %r, (logn, d)
 print("ok")
 ''' % (ROOT, TOL)
-    env = dict(os.environ, COMMS_FFT_TILE_DIRECT="1")
+    env = dict(os.environ, COMMS_FFT_TILE_DIRECT="1", COMMS_HIP_LIB=DIAG_LIB)  # kernel selectors exist in the diagnostic build only
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
@@ -1482,7 +1483,7 @@ for a, b in ((0, 768 * rate), (768 * rate, n)):
     assert d[ok].max() <= 1e-4, d[ok].max()
 print("ok")
 ''' % ROOT
-    env = dict(os.environ, COMMS_CHAIN_FM_SEPARATE="0")
+    env = dict(os.environ, COMMS_CHAIN_FM_SEPARATE="0", COMMS_HIP_LIB=DIAG_LIB)  # kernel selectors exist in the diagnostic build only
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
