@@ -318,9 +318,11 @@ comms_status_t comms_chain_run(comms_chain_t* h, const comms_c32* in, size_t n, 
     if (!n) return COMMS_OK;
     const size_t out_bytes = (n / h->rate) * (h->fm_demod ? sizeof(float) : sizeof(comms_c32));
     const size_t in_elem = h->in_fmt == COMMS_IQ_I16 ? 4 : h->in_fmt == COMMS_IQ_U8 ? 2 : 8;
-    return h->run_host(in, n * in_elem, out, out_bytes, [&](void* d_in, void* d_out) {
+    COMMS_TRY(h->run_host(in, n * in_elem, out, out_bytes, [&](void* d_in, void* d_out) {
         return comms_chain_run_dev(h, static_cast<const comms_c32*>(d_in), n, d_out, COMMS_STREAM_HANDLE);
-    });
+    }));
+    // (a long filter runs the 16384-point FIR kernel inside the series of launches: its failure is this call's)
+    return h->fir ? fir_check_sticky(h->fir) : COMMS_OK;
 }
 
 // d_in of the run entries then points to raw IQ samples of that format; the conversion (iqformat.hip's

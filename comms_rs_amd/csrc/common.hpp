@@ -364,9 +364,24 @@ struct Handle {
 
 // Handle-less host-pointer entry points (resampling, IQ formats, estimators) borrow a per-thread,
 // per-device handle (stream + staging), created on first use and kept for the thread's life:
-// no hipMalloc / hipFree -- which also synchronise the device -- per call.
+// no hipMalloc / hipFree -- which also synchronise the device -- per call.  The handles END with their thread
+// (comms-rs starts one thread per node, src/node/mod.rs:276-284: a graph that is torn down and rebuilt must not leave
+// a pooled stream, device scratch and pinned staging behind per retired node thread).
+struct ThreadHandles {
+    Handle* h[64] = {};
+    ~ThreadHandles() {
+        for (Handle*& p : h) {
+            if (!p) continue;
+            (void)use_device(p->device);
+            p->fini();  // scratch and staging freed, the stream back to the device's pool
+            delete p;
+            p = nullptr;
+        }
+    }
+};
 inline comms_status_t thread_handle(int32_t device, Handle** out) {
-    static thread_local Handle* tl[64] = {};
+    static thread_local ThreadHandles th;
+    Handle** tl = th.h;
     COMMS_ARG(device >= 0 && device < 64, "device index out of range");
     if (!tl[device]) {
         Handle* nh = new (std::nothrow) Handle;

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 4) void probe_read_tile_kernel(const float2* _
 // nontemporal loads; bit 1: 512 B stored per wave and tile (an FM chain's output at rate 8); bit 2: 16 B per lane.
 template <int FLAGS>
 __global__ __launch_bounds__(256, 4) void probe_read_wave_kernel(const float2* __restrict__ in, float* __restrict__ sink,
-                                                                 float2* __restrict__ out, size_t n_tiles, int nt_chunk) {
+                                                                 float2* __restrict__ out, size_t n_tiles, int nt_chunk, int st_mode) {
     constexpr bool NT = FLAGS & 1, ST = (FLAGS & 2) != 0, WIDE = (FLAGS & 4) != 0;
     const int l = threadIdx.x & 63;
     const size_t wave = static_cast<size_t>(blockIdx.x) * 4 + (threadIdx.x >> 6), n_waves = static_cast<size_t>(gridDim.x) * 4;
@@ -262,7 +262,19 @@ __global__ __launch_bounds__(256, 4) void probe_read_wave_kernel(const float2* _
     auto consume = [&](size_t t, const float2 (&x)[16]) __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < 16; ++m) acc += x[m].x;
-        if (ST) out[t * 64 + l] = make_float2(acc, acc + 1.f);
+        if (ST) {
+            const float2 v = make_float2(acc, acc + 1.f);
+            float2* q = out + t * 64 + l;
+            if (st_mode == 0) *q = v;
+            else if (st_mode == 1) {
+                nt_f2 w; w.x = v.x; w.y = v.y;
+                __builtin_nontemporal_store(w, reinterpret_cast<nt_f2*>(q));
+            } else if (st_mode == 2) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(q), "v"(v) : "memory");
+            else if (st_mode == 3) asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(q), "v"(v) : "memory");
+            else if (st_mode == 4) asm volatile("global_store_dwordx2 %0, %1, off sc0" : : "v"(q), "v"(v) : "memory");
+            else if (st_mode == 5) out[(t & 1023) * 64 + l] = v;   // a 512-KiB window: what the store path costs without HBM writes
+            else if (st_mode == 6) { if ((t & 7) == 7) { for (int i = 0; i < 8; ++i) out[(t - 7 + i) * 64 + l] = v; } }  // eight tiles' outputs in one burst
+        }
     };
     for (size_t c = wave; c < n_chunks; c += n_waves) {
         const size_t t0 = c * nt_chunk, t1 = t0 + nt_chunk < n_tiles ? t0 + nt_chunk : n_tiles;
@@ -355,12 +367,12 @@ extern "C" comms_status_t comms_debug_read(const void* d_in, size_t n_c32, int m
     } else if (mode >= 200 && mode < 208) {
         // wave-private streaming: wgs_per_cu = nt_chunk * 16 + workgroups per CU (4 waves each)
         const size_t n_tiles = n_c32 / 1024;
-        const int wg = wgs_per_cu & 15, ntc = wgs_per_cu >> 4;
+        const int wg = wgs_per_cu & 15, ntc = (wgs_per_cu >> 4) & 255, stm = wgs_per_cu >> 12;
         const dim3 g(static_cast<unsigned>(wg) * kNumCU), b(256);
         const float2* in = static_cast<const float2*>(d_in);
         float2* o2 = reinterpret_cast<float2*>(d_out);
         switch (mode - 200) {
-#define COMMS_RW(F) case F: probe_read_wave_kernel<F><<<g, b, 0, s>>>(in, d_sink, o2, n_tiles, ntc); break;
+#define COMMS_RW(F) case F: probe_read_wave_kernel<F><<<g, b, 0, s>>>(in, d_sink, o2, n_tiles, ntc, stm); break;
             COMMS_RW(0) COMMS_RW(1) COMMS_RW(2) COMMS_RW(3) COMMS_RW(4) COMMS_RW(5) COMMS_RW(6) COMMS_RW(7)
 #undef COMMS_RW
         }

@@ -875,7 +875,12 @@ constexpr int X_SPINS = 1 << 22;  // x ~100 cycles per poll: a few tenths of a s
 #ifndef COMMS_OS16K_SLEEP_OUT
 #define COMMS_OS16K_SLEEP_OUT 4  // (1 / 2 / 4 / 8 here: 591 / 589 / 585 / 588 us at 2^27 samples, seven builds in one process; IN: no difference)
 #endif
-__device__ __forceinline__ void x_wait_one(const unsigned* cnt, unsigned target, unsigned* gave_up) {
+// Both waits return false when they ran out: the wave then LEAVES its segment loop (the counters are cumulative: once a
+// signal is missing, every later wait on that counter would run out as well, X_SPINS polls each -- a launch with
+// hundreds of segments per workgroup would take minutes to report what it knew after the first).  Its own signals stop
+// with it, so the other waves of the workgroup run out at their next wait and leave too: a failed launch costs a few
+// timeouts, whatever its length.  The exit hangs off the cold path only.
+__device__ __forceinline__ bool x_wait_one(const unsigned* cnt, unsigned target, unsigned* gave_up) {
     bool ok = false;
     for (int spin = 0; spin < X_SPINS; ++spin) {
         const unsigned c = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -887,8 +892,9 @@ __device__ __forceinline__ void x_wait_one(const unsigned* cnt, unsigned target,
     }
     if (!ok) __hip_atomic_fetch_or(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return ok;
 }
-__device__ __forceinline__ void x_wait_all16(const unsigned* cnt, unsigned target, int l, unsigned* gave_up) {
+__device__ __forceinline__ bool x_wait_all16(const unsigned* cnt, unsigned target, int l, unsigned* gave_up) {
     bool ok = false;
     for (int spin = 0; spin < X_SPINS; ++spin) {
         const unsigned c = __hip_atomic_load(cnt + (l & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -900,6 +906,7 @@ __device__ __forceinline__ void x_wait_all16(const unsigned* cnt, unsigned targe
     }
     if (!ok) __hip_atomic_fetch_or(gave_up, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return ok;
 }
 // at a wave's end: report what any wait of the workgroup gave up on
 __device__ __forceinline__ void x_report(const unsigned long long* aux) {
@@ -1064,7 +1071,7 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
         X_MARK(2);
         // ---- this wave's slice, once all sixteen waves have delivered their 64 points of it: stage-1 twiddle,
         // 1024-point transform, spectrum multiply, inverse, conjugate twiddle
-        x_wait_one(slice_in + wave, 16u * (done + 1), gave_up);
+        if (!x_wait_one(slice_in + wave, 16u * (done + 1), gave_up)) break;
         X_MARK(3);
         prio(1);
 #pragma unroll
@@ -1089,7 +1096,7 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
         fetch_rows(seg + 1 < seg_hi ? seg + 1 : seg, R0);
         // ---- inverse stage 1: thread tid gathers point tid of every slice, radix-16 back to the rows
         X_MARK(5);
-        x_wait_all16(slice_out, done + 1, l, gave_up);
+        if (!x_wait_all16(slice_out, done + 1, l, gave_up)) break;
         X_MARK(6);
         prio(10);
 #pragma unroll
@@ -1708,14 +1715,6 @@ static int fir_pick(const comms_fir* h, size_t n) {
     return algo;
 }
 
-// A launch of the 16384-point kernel whose LDS waits ran out has raised the handle's error word (fir_os16k_kernel):
-// its outputs are wrong, and so is everything the handle would compute from the state it left.
-static comms_status_t fir_check_sticky(const comms_fir* h) {
-    if (h->err_host && __atomic_load_n(h->err_host, __ATOMIC_RELAXED) != 0)
-        return fail(COMMS_ERR_DEVICE, "fir_os16k_kernel: a workgroup's LDS wait ran out (code %u): the outputs of that call "
-                                      "are invalid and the handle is unusable", *h->err_host);
-    return COMMS_OK;
-}
 
 static comms_status_t fir_upload_state(comms_fir* h, const comms_c32* state, size_t n_state) {
     // reference layout: state[0] newest ... -> device ring is time-ordered (oldest first)
@@ -2048,9 +2047,12 @@ comms_status_t comms_fir_run(comms_fir_t* h, const comms_c32* in, size_t n, comm
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
     const size_t in_elem = h->in_fmt == COMMS_IQ_I16 ? 4 : h->in_fmt == COMMS_IQ_U8 ? 2 : 8;
-    return h->run_host(in, n * in_elem, out, n * sizeof(comms_c32), [&](void* d_in, void* d_out) {
+    COMMS_TRY(h->run_host(in, n * in_elem, out, n * sizeof(comms_c32), [&](void* d_in, void* d_out) {
         return comms_fir_run_dev(h, static_cast<const comms_c32*>(d_in), n, static_cast<comms_c32*>(d_out), COMMS_STREAM_HANDLE);
-    });
+    }));
+    // run_host has waited for this call's launches: a wait of the 16384-point kernel that ran out in THIS call is
+    // reported by this call (its samples are in `out`, and they are wrong)
+    return fir_check_sticky(h);
 }
 
 comms_status_t comms_fir_get_state(comms_fir_t* h, comms_c32* state, size_t n_state) {
@@ -2073,6 +2075,7 @@ comms_status_t comms_fir_set_state(comms_fir_t* h, const comms_c32* state, size_
     COMMS_ARG(n_state == static_cast<size_t>(h->n_eff), "state must hold exactly the %d effective taps", h->n_eff);
     COMMS_TRY(use_device(h->device));
     COMMS_TRY(h->quiesce());  // no pending launch may still read the buffer that is overwritten
+    COMMS_TRY(fir_check_sticky(h));
     return fir_upload_state(h, state, n_state);
 }
 
@@ -2101,6 +2104,7 @@ comms_status_t comms_fir_run_fused_dev(comms_fir_t* h, const comms_c32* d_in, si
     COMMS_ARG(rate >= 1 && n % rate == 0, "n must be a multiple of the decimation rate");
     COMMS_ARG(!(mode & CH_FM) || (rate <= 64 && h->n_eff + static_cast<int>(rate) <= 257),
               "fused FM demod needs rate <= 64 and taps + rate <= 257");
+    COMMS_TRY(fir_check_sticky(h));
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
     COMMS_ARG(!ranges_overlap(d_in, n * 8, d_out, (n / rate) * ((mode & CH_FM) ? 4 : 8)), "the fused chain cannot run in place");

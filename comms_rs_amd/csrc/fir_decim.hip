@@ -37,6 +37,12 @@
 #ifndef COMMS_DECIM_NOMAC_DEFAULT
 #define COMMS_DECIM_NOMAC_DEFAULT 0
 #endif
+#ifndef COMMS_DECIM_WAVE_DEFAULT
+#define COMMS_DECIM_WAVE_DEFAULT 0
+#endif
+#ifndef COMMS_DECIM_WAVE_NT_DEFAULT
+#define COMMS_DECIM_WAVE_NT_DEFAULT 0
+#endif
 
 namespace comms {
 
@@ -86,6 +92,10 @@ struct DecimArgs {
     int interleave;                // tile t of workgroup b: b + i gridDim.x instead of a contiguous run (kept behind the tap
                                    // arrays: their offsets decide how many scalar-cache lines a 64-byte tap load touches)
     KStamp ks;                     // in-kernel begin / end stamps of a stamps timer, or null
+    // wave-private form (fir_decim_wave_kernel): a wave's run of tiles, the row rotors of its halo rows
+    int nt_chunk;                  // tiles of 128 outputs per run
+    long long n_chunks;            // runs
+    float2 step_h[4];              // e^{i * 64 (i - HR) * dphi}, halo row i
 };
 
 constexpr double kTwoPiD = 2.0 * 3.14159265358979323846264338327950288;
@@ -478,10 +488,290 @@ __global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::
 #undef DC_STAMP
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same chain, WAVE-PRIVATE (round 5): no workgroup barrier, no halo staged twice.
+//
+// What bounds fir_decim_kernel (profiles/r05_ab_chain_prefetch.txt, r05_pmc_config3.txt): nothing is saturated -- the
+// vector ALU is busy 55-65 % of the time (at the 1.65 GHz the chip holds under this kernel), LDS 45 %, HBM 70 % of what a
+// read stream of this shape reaches -- but its four waves meet at two barriers per tile, every tile stages its halo
+// again, and a wave that waits for its rows has nothing else to do.  Requesting the next tile's rows early did not
+// help there (the time moved from the load wait into the filter loop and the second barrier).
+//
+// Here a wave owns a RUN of consecutive tiles of 128 outputs (two per lane) and a private LDS image of PR = 2R phase
+// arrays.  The 128 R new samples of a tile arrive as 2R rows of 64 (512-B loads); the halo -- the last 64 HR samples
+// of the tile before -- is already in LDS: the wave kept those rows (raw) in registers and writes them, mixed for the
+// new tile, into the halo slots once the filter loop has read the old ones.  A wave's LDS operations execute in order, so
+// nothing but the data dependencies orders them: no barrier, no fence.  The next tile's rows are requested before the
+// filter loop (the registers are free: the row rotors are re-made per tile from the lane's one rotor and the
+// wave-uniform steps).  FM demod takes y[j-1] of a lane's first output from the lane below (DPP wave shift), lane 0
+// from the tile before; the output before a run's first is made once per run by the whole wave from global memory
+// (two taps per lane, summed across the lanes), so that every run is whole tiles and all waves end together.
+// Same arithmetic per output as fir_decim_kernel (taps ascending, the same rotor products), except that run-start
+// value, whose sum runs in another order (|d| ~ 1e-7 relative, one FM output per run).
+//
+// Built for PR | 64 (rates 4, 8, 16), Complex<f32> input; HR = 2 halo rows (taps <= 129) or 4 (<= 257).
+template <int R, int HR>
+struct DwGeom {
+    static constexpr int PR = 2 * R;
+    static constexpr int RPE = 64 / PR;        // phase-array elements per row of 64 samples
+    static constexpr int SCAP = HR * RPE;      // halo elements in front of the 64 new ones of a phase array
+    static constexpr int S = (64 + SCAP) | 1;  // phase-array stride (odd: the staging writes spread over the banks)
+    static constexpr int WAVE_CF = PR * S;
+    static constexpr size_t LDS_WAVE = static_cast<size_t>(WAVE_CF) * sizeof(float2);
+    static_assert(64 % PR == 0, "a row of 64 samples must be whole phase-array columns");
+};
+
+// lane l takes lane l - 1's value, lane 0 keeps `first` (DPP wave_shr:1)
+__device__ __forceinline__ float wave_shr1(float v, float first) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+
+template <int R, bool REAL, bool PRE, int HR, int WPB, int AUX>
+__global__ __launch_bounds__(64 * WPB, 4) void fir_decim_wave_kernel(const DecimArgs a) {
+    using G = DwGeom<R, HR>;
+    constexpr int PR = G::PR, S = G::S, RPE = G::RPE, SCAP = G::SCAP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int l = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));  // (wave-uniform, and the compiler must know: run, window and row offsets then live in SGPRs)
+    cf* sh = reinterpret_cast<cf*>(smem) + w * G::WAVE_CF;
+    const float2* in = static_cast<const float2*>(a.in);
+    hist_advance(a.hist, in, a.n, a.new_hist, a.hist_len);
+    kstamp_begin(a.ks);
+    const bool post = !PRE && (a.mode & COMMS_CHAIN_POST) != 0;
+    const bool fm = (a.mode & COMMS_CHAIN_FM) != 0;
+    const long long n_out = static_cast<long long>(a.n_out);
+    const long long C = 128LL * a.nt_chunk;  // outputs per run
+    const long long wave0 = static_cast<long long>(blockIdx.x) * WPB + w, n_waves = static_cast<long long>(gridDim.x) * WPB;
+
+    // lane constants: LDS slot of the lane's sample of row 0 (row m: + RPE m; halo row i: - SCAP + RPE i), its rotor
+    const int wslot = (l % PR) * S + SCAP + l / PR;
+    cf l0 = cf{1.f, 0.f};
+    if (PRE) {
+        double c, sn;
+        rotor_at(static_cast<uint64_t>(l) * a.frac, c, sn);
+        l0 = cf{static_cast<float>(c), static_cast<float>(sn)};
+    }
+    const cf* up = sh + l + SCAP;
+    const unsigned voff = static_cast<unsigned>(l) * 8u;
+
+    for (long long k = wave0; k < a.n_chunks; k += n_waves) {
+        const long long Jc = k * C;           // the run's first output
+        const long long Bc = R * Jc;          // ... and its first new sample
+        double tt_c = 1.0, tt_s = 0.0, ro_c = 1.0, ro_s = 0.0;
+        if (PRE) rotor_at(a.turns0 + static_cast<uint64_t>(Bc) * a.frac, tt_c, tt_s);
+        if (post) rotor_at(a.turns0 + static_cast<uint64_t>(R * (Jc + 2 * l)) * a.frac, ro_c, ro_s);
+        // the run's window of the input as a buffer resource: reads past the stream's end return zero
+        const long long w0 = Bc - 64 * HR;    // first halo sample (negative for the first run: history)
+        const long long base_s = w0 < 0 ? 0 : w0;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + base_s, (a.n - static_cast<size_t>(base_s)) * sizeof(float2));
+        unsigned off = static_cast<unsigned>(Bc - base_s) * 8u;  // byte offset of the tile's row 0 in the window (wave-uniform)
+        cf x[PR], xh[HR];
+        if (w0 >= 0) {
+#pragma unroll
+            for (int i = 0; i < HR; ++i) xh[i] = to_cf(BufRows<const float2*>::get_from(rs, voff, 512u * i));
+#pragma unroll
+            for (int m = 0; m < PR; ++m) {
+                const bv2u q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, off + 512u * m, AUX);
+                x[m] = cf{__uint_as_float(q.x), __uint_as_float(q.y)};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < HR; ++i) xh[i] = to_cf(stream_at(in, a.hist, a.hist_len, w0 + 64 * i + l, a.n));
+#pragma unroll
+            for (int m = 0; m < PR; ++m) x[m] = to_cf(stream_at(in, a.hist, a.hist_len, Bc + 64 * m + l, a.n));
+        }
+#pragma unroll
+        for (int i = 0; i < HR; ++i) sh[wslot - SCAP + RPE * i] = PRE ? cmulf(xh[i], cmulf_s(l0, to_cf(a.step_h[i]))) : xh[i];
+
+        // FM: y[Jc - 1].  The first run: FM.prev of the call before; the others: the whole wave makes that one output
+        // from global memory (lane l: taps l, l + 64, ...), mixed and rotated as the tile path does it
+        cf carry = cf{0.f, 0.f};
+        if (fm) {
+            if (Jc == 0) {
+                typedef const __attribute__((address_space(4))) float* cfp;
+                const cfp pp = (cfp)(a.fm_prev);
+                carry = cf{pp[0], pp[1]};
+            } else {
+                const long long P = Bc - R;  // newest sample of output Jc - 1
+                cf part = cf{0.f, 0.f};
+                for (int kk = l; kk < a.hist_len; kk += 64) {
+                    cf xv = to_cf(in[P - kk]);
+                    if (PRE) {
+                        double c, sn;
+                        rotor_at(a.turns0 + static_cast<uint64_t>(P - kk) * a.frac, c, sn);
+                        xv = cmulf(xv, cf{static_cast<float>(c), static_cast<float>(sn)});
+                    }
+                    const float tr = a.are[kk + PR - 1];
+                    part.x = __builtin_fmaf(tr, xv.x, part.x);
+                    part.y = __builtin_fmaf(tr, xv.y, part.y);
+                    if (!REAL) {
+                        const float ti = a.aim[kk + PR - 1];
+                        part.x = __builtin_fmaf(-ti, xv.y, part.x);
+                        part.y = __builtin_fmaf(ti, xv.x, part.y);
+                    }
+                }
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) {
+                    part.x += __shfl_xor(part.x, sft);
+                    part.y += __shfl_xor(part.y, sft);
+                }
+                if (post) {
+                    double c, sn;
+                    rotor_at(a.turns0 + static_cast<uint64_t>(R * (Jc - 1)) * a.frac, c, sn);
+                    part = cmulf(part, cf{static_cast<float>(c), static_cast<float>(sn)});
+                }
+                carry = part;
+            }
+        }
+
+        for (int i = 0; i < a.nt_chunk; ++i) {
+            const long long J0 = Jc + 128LL * i;
+            if (J0 >= n_out) break;
+            // ---- stage the tile's rows (mixed on the way in); the last HR rows stay behind, raw, for the next tile's halo
+#pragma unroll
+            for (int m = 0; m < PR; ++m)
+                sh[wslot + RPE * m] = PRE ? cmulf(x[m], m ? cmulf_s(l0, to_cf(a.step[m])) : l0) : x[m];
+            cf keep[HR];
+#pragma unroll
+            for (int h = 0; h < HR; ++h) keep[h] = x[PR - HR + h];
+            // ---- the next tile's rows travel while this tile's taps run
+            off += 512u * PR;
+            if (i + 1 < a.nt_chunk && J0 + 128 < n_out) {
+#pragma unroll
+                for (int m = 0; m < PR; ++m) {
+                    const bv2u q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, off + 512u * m, AUX);
+                    x[m] = cf{__uint_as_float(q.x), __uint_as_float(q.y)};
+                }
+            }
+            // ---- outputs j = J0 + 2 l + c (as fir_decim_kernel's two-output loop: taps ascending, SGPR pairs, chunks of CH)
+            cf acc[2] = {cf{0.f, 0.f}, cf{0.f, 0.f}};
+            {
+                constexpr int OPL = 2;
+                constexpr int CH = (R <= 10 || R % 2) ? R : R / 2;
+                constexpr int NCH = PR / CH;
+                static_assert(PR % CH == 0 && NCH % 2 == 0, "chunks must pair up inside a block");
+                constexpr int NP = ((CH & 1) + CH + (OPL - 1) * R + 1) / 2;
+                cf ua[CH], ub[CH];
+                v2f ra[NP], rb[NP], ia[NP], ib_[NP];
+                auto fetch = [&](int d, int g, cf (&u)[CH], v2f (&tr)[NP], v2f (&ti)[NP]) __attribute__((always_inline)) {
+                    const int m0 = PR * d + ((g * CH) & ~1);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        tr[q] = v2f{a.are[m0 + 2 * q], a.are[m0 + 2 * q + 1]};
+                        if (!REAL) ti[q] = v2f{a.aim[m0 + 2 * q], a.aim[m0 + 2 * q + 1]};
+                    }
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) u[q] = up[(PR - 1 - (g * CH + q)) * S - d];
+                };
+                auto landed = [&](cf (&u)[CH], v2f (&tr)[NP], v2f (&ti)[NP]) __attribute__((always_inline)) {
+                    asm volatile("" ::"v"(u[CH - 1]), "s"(tr[NP - 1]));
+                    if (!REAL) asm volatile("" ::"s"(ti[NP - 1]));
+                };
+                auto macs = [&](int g, const cf (&u)[CH], const v2f (&tr)[NP], const v2f (&ti)[NP]) __attribute__((always_inline)) {
+                    const int o = (g * CH) & 1;
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) {
+#pragma unroll
+                        for (int c = 0; c < OPL; ++c) {
+                            const int e = o + q + R * c;
+                            mac_tap<REAL>(acc[c], u[q], tr[e >> 1], ti[e >> 1], (e & 1) != 0);
+                        }
+                    }
+                };
+                fetch(0, 0, ua, ra, ia);
+                for (int d = 0; d < a.nd; ++d) {
+#pragma unroll
+                    for (int g = 0; g < NCH; g += 2) {
+                        landed(ua, ra, ia);
+                        fetch(d, g + 1, ub, rb, ib_);
+                        macs(g, ua, ra, ia);
+                        landed(ub, rb, ib_);
+                        if (g + 2 < NCH)
+                            fetch(d, g + 2, ua, ra, ia);
+                        else if (d + 1 < a.nd)
+                            fetch(d + 1, 0, ua, ra, ia);
+                        macs(g + 1, ub, rb, ib_);
+                    }
+                }
+            }
+            // ---- the next tile's halo: this tile's last rows, mixed for the NEW tile (the filter loop's reads of the old
+            // halo were issued before these writes: a wave's LDS operations execute in order)
+#pragma unroll
+            for (int h = 0; h < HR; ++h) sh[wslot - SCAP + RPE * h] = PRE ? cmulf(keep[h], cmulf_s(l0, to_cf(a.step_h[h]))) : keep[h];
+            // ---- epilogue: mixer after the FIR, FM demod, stores
+            cf y0 = acc[0], y1 = acc[1];
+            if (PRE) {
+                const cf tt = cf{static_cast<float>(tt_c), static_cast<float>(tt_s)};
+                y0 = cmulf(acc[0], tt);
+                y1 = cmulf(acc[1], tt);
+                rotor_step(tt_c, tt_s, a.tile_c, a.tile_s);
+            }
+            if (post) {
+                const cf ro = cf{static_cast<float>(ro_c), static_cast<float>(ro_s)};
+                y0 = cmulf(acc[0], ro);
+                y1 = cmulf(acc[1], cmulf(ro, to_cf(a.step_r[1])));
+                rotor_step(ro_c, ro_s, a.tile_c, a.tile_s);
+            }
+            const long long j0 = J0 + 2 * l;
+            const bool whole = J0 + 128 <= n_out;  // (wave-uniform)
+            if (fm) {
+                const cf p0 = cf{wave_shr1(y1.x, carry.x), wave_shr1(y1.y, carry.y)};
+                // (two __builtin_amdgcn_readlane of y1.x / y1.y came out of this compiler as ONE v_readlane of y1.x used
+                // for both halves -- seen in the ISA, and as wrong angles at every tile's first output; asm keeps them apart)
+                int cx, cy;
+                asm volatile("s_nop 1\n\tv_readlane_b32 %0, %2, 63\n\tv_readlane_b32 %1, %3, 63" : "=s"(cx), "=s"(cy) : "v"(y1.x), "v"(y1.y));
+                carry = cf{__builtin_bit_cast(float, cx), __builtin_bit_cast(float, cy)};
+                const float o0 = fm_step_fast(to_f2(y0), to_f2(p0)), o1 = fm_step_fast(to_f2(y1), to_f2(y0));
+                float* o = static_cast<float*>(a.out);
+                if (whole)  // (j0 is even and the host checked the buffer's alignment; a plain store, so that the compiler's
+                            // vmcnt arithmetic sees it: behind an asm store it waited for the store's completion as well)
+                    *reinterpret_cast<float2*>(o + j0) = make_float2(o0, o1);
+                else {
+                    if (j0 < n_out) o[j0] = o0;
+                    if (j0 + 1 < n_out) o[j0 + 1] = o1;
+                }
+                if (j0 == n_out - 1) a.fm_prev_new[0] = to_f2(y0);
+                if (j0 + 1 == n_out - 1) a.fm_prev_new[0] = to_f2(y1);
+            } else {
+                float2* o = static_cast<float2*>(a.out);
+                if (whole)
+                    *reinterpret_cast<float4*>(o + j0) = make_float4(y0.x, y0.y, y1.x, y1.y);
+                else {
+                    if (j0 < n_out) o[j0] = to_f2(y0);
+                    if (j0 + 1 < n_out) o[j0 + 1] = to_f2(y1);
+                }
+            }
+        }
+    }
+    kstamp_end(a.ks);
+}
+
+
 // Event pair of an attached kernel timer for the launch about to be made (set by comms_fir_run_decim_dev, taken by
 // launch_decim_v): the kernel's own begin / end timestamps, as the FIR kernels' timed launches -- events recorded
 // around the launch would include the dispatch gap in front of it whenever the launch before it carried no events.
 static thread_local hipEvent_t g_decim_ev_start = nullptr, g_decim_ev_stop = nullptr;
+
+template <int R, bool REAL, bool PRE, int HR, int WPB, int AUX>
+static comms_status_t launch_decim_wave_v(const DecimArgs& a, hipStream_t s) {
+    using G = DwGeom<R, HR>;
+    constexpr size_t lds = G::LDS_WAVE * WPB;
+    const size_t want = (static_cast<size_t>(a.n_chunks) + WPB - 1) / WPB;
+    const size_t slots = (160u * 1024u / lds) * kNumCU;
+    const unsigned blocks = static_cast<unsigned>(want < slots ? want : slots);
+    static DeviceOnce attr_once;
+    if (attr_once.need())
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_decim_wave_kernel<R, REAL, PRE, HR, WPB, AUX>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipEvent_t ea = g_decim_ev_start, eb = g_decim_ev_stop;
+    g_decim_ev_start = g_decim_ev_stop = nullptr;
+    if (ea)
+        hipExtLaunchKernelGGL((fir_decim_wave_kernel<R, REAL, PRE, HR, WPB, AUX>), dim3(blocks), dim3(64 * WPB), static_cast<uint32_t>(lds), s, ea, eb, 0u, a);
+    else
+        fir_decim_wave_kernel<R, REAL, PRE, HR, WPB, AUX><<<dim3(blocks), dim3(64 * WPB), lds, s>>>(a);
+    return launch_ok("fir_decim_wave_kernel");
+}
 
 template <int R, int OPL, bool REAL, bool PRE, int TILE = DC_TILE, int CHX = 0>
 static comms_status_t launch_decim_v(const DecimArgs& a, hipStream_t s) {
@@ -620,6 +910,7 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
               "the decimating chain kernel supports <= 257 taps and rates 2 ... 16 (11, 13, 15: real taps)");
     COMMS_ARG(n % rate == 0, "n must be a multiple of the decimation rate");
     COMMS_ARG((mode & COMMS_CHAIN_DEC) && !((mode & COMMS_CHAIN_PRE) && (mode & COMMS_CHAIN_POST)), "bad chain mode");
+    COMMS_TRY(fir_check_sticky(h));
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
     const size_t in_elem = h->in_fmt == COMMS_IQ_I16 ? 4 : h->in_fmt == COMMS_IQ_U8 ? 2 : 8;
@@ -707,6 +998,43 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
     (void)h->take_events(g_decim_ev_start, g_decim_ev_stop);
     a.ks = h->next_stamp();
     comms_status_t st;
+    // The wave-private form (fir_decim_wave_kernel): rate 8, Complex<f32> input, and a batch whose tiles of 128 outputs
+    // spread evenly over the waves of the chip (every wave runs ONE contiguous run: the launch lasts as long as its
+    // longest run, so a batch of 4.3 tiles per wave would pay for 5)
+    static const int wave_knob = diag_knob("COMMS_DECIM_WAVE", COMMS_DECIM_WAVE_DEFAULT);
+    if (wave_knob && R == 8 && h->in_fmt == COMMS_IQ_C32 && opl == 2 && tile == DC_TILE &&
+        (reinterpret_cast<uintptr_t>(d_out) & 15) == 0) {  // (its stores are 8 / 16 bytes per lane)
+        const int HR = a.hlq * PR <= 128 ? 2 : 4;
+        const long long tiles = static_cast<long long>((a.n_out + 127) / 128);
+        const long long waves = (HR == 2 ? 16 : 12) * static_cast<long long>(kNumCU);
+        const long long nt = (tiles + waves - 1) / waves;
+        const bool balanced = tiles >= waves && nt * waves * 100 <= tiles * 104;
+        if (balanced || wave_knob == 2) {
+            a.nt_chunk = static_cast<int>(nt < 1 ? 1 : nt);
+            a.n_chunks = (tiles + a.nt_chunk - 1) / a.nt_chunk;
+            a.interleave = 0;
+            mix_host_rotor(static_cast<uint64_t>(R) * 128u * frac, a.tile_c, a.tile_s);
+            for (int m = 0; m < PR; ++m) {
+                mix_host_rotor(static_cast<uint64_t>(64 * m) * frac, c, sn);
+                a.step[m] = make_float2(static_cast<float>(c), static_cast<float>(sn));
+            }
+            for (int i = 0; i < HR; ++i) {
+                mix_host_rotor(static_cast<uint64_t>(static_cast<long long>(64 * (i - HR))) * frac, c, sn);
+                a.step_h[i] = make_float2(static_cast<float>(c), static_cast<float>(sn));
+            }
+            const bool pre = (mode & COMMS_CHAIN_PRE) != 0;
+            static const int nt_loads = diag_knob("COMMS_DECIM_WAVE_NT", COMMS_DECIM_WAVE_NT_DEFAULT);
+#define COMMS_DW(REAL_, PRE_, HR_) (nt_loads ? launch_decim_wave_v<8, REAL_, PRE_, HR_, 4, 2>(a, s) : launch_decim_wave_v<8, REAL_, PRE_, HR_, 4, 0>(a, s))
+            if (HR == 2)
+                st = real ? (pre ? COMMS_DW(true, true, 2) : COMMS_DW(true, false, 2)) : (pre ? COMMS_DW(false, true, 2) : COMMS_DW(false, false, 2));
+            else
+                st = real ? (pre ? COMMS_DW(true, true, 4) : COMMS_DW(true, false, 4)) : (pre ? COMMS_DW(false, true, 4) : COMMS_DW(false, false, 4));
+#undef COMMS_DW
+            COMMS_TRY(st);
+            h->cur ^= 1;
+            return COMMS_OK;
+        }
+    }
     switch (R) {
         case 2: st = launch_decim<2>(a, real, opl, tile, s); break;
         case 3: st = launch_decim<3>(a, real, opl, tile, s); break;

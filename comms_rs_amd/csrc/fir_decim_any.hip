@@ -307,6 +307,7 @@ comms_status_t comms_fir_run_decim_any_dev(comms_fir_t* h, const void* d_in, siz
     COMMS_ARG(comms_fir_decim_any_supported(h, rate), "the any-rate chain kernel takes up to 512 taps and rates 2 ... 2^20");
     COMMS_ARG(n % rate == 0, "n must be a multiple of the decimation rate");
     COMMS_ARG((mode & COMMS_CHAIN_DEC) && !(mode & COMMS_CHAIN_PRE), "the any-rate kernel knows the mixer behind the FIR only");
+    COMMS_TRY(fir_check_sticky(h));
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
     const size_t in_elem = h->in_fmt == COMMS_IQ_I16 ? 4 : h->in_fmt == COMMS_IQ_U8 ? 2 : 8;

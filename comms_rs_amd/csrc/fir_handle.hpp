@@ -194,3 +194,16 @@ struct comms_fir : comms::Handle {
     std::vector<comms_c32> taps;  // effective taps (host copy)
 };
 
+namespace comms {
+// A launch of the 16384-point kernel whose LDS waits ran out has raised the handle's error word (fir_os16k_kernel):
+// its outputs are wrong, and so is everything the handle would compute from the state it left.  Checked on entry to
+// every run / state entry of the handle (all of them, round 5) and, by the host-pointer entries, once more AFTER the
+// call's own launches have been waited for: the synchronous caller of the failing call gets COMMS_ERR_DEVICE, not the
+// invalid samples with COMMS_OK.
+inline comms_status_t fir_check_sticky(const comms_fir* h) {
+    if (h->err_host && __atomic_load_n(h->err_host, __ATOMIC_RELAXED) != 0)
+        return fail(COMMS_ERR_DEVICE, "fir_os16k_kernel: a workgroup's LDS wait ran out (code %u): the outputs of that call "
+                                      "are invalid and the handle is unusable", *h->err_host);
+    return COMMS_OK;
+}
+}  // namespace comms

@@ -55,6 +55,7 @@ __global__ void synth_iq_kernel(float2* out, size_t n, uint64_t first, uint64_t 
 static std::mutex g_stream_m;
 static std::vector<hipStream_t> g_free_streams[64];
 
+static std::atomic<long> g_streams_created[64];  // (what the pool has ever created: the diagnostic build reports it)
 comms_status_t stream_acquire(int32_t device, hipStream_t* out) {
     COMMS_ARG(device >= 0 && device < 64, "device index out of range");
     COMMS_TRY(use_device(device));
@@ -68,6 +69,7 @@ comms_status_t stream_acquire(int32_t device, hipStream_t* out) {
         }
     }
     COMMS_HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    g_streams_created[device].fetch_add(1);
     return COMMS_OK;
 }
 
@@ -83,9 +85,17 @@ void stream_release(int32_t device, hipStream_t s) {
     g_free_streams[device].push_back(s);
 }
 
+long streams_created(int32_t device) { return device >= 0 && device < 64 ? g_streams_created[device].load() : -1; }
+
 }  // namespace comms
 
 using namespace comms;
+
+#ifdef COMMS_DIAG
+// diagnostic build: streams the pool of `device` has created so far (tests/test_gpu_host_threads.py: node threads that
+// come and go must reuse them)
+extern "C" long comms_debug_streams_created(int32_t device) { return comms::streams_created(device); }
+#endif
 
 // Device-resident message.  Besides the allocation it carries what lets node threads hand it
 // from stream to stream without ever synchronising the device:

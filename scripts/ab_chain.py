@@ -48,7 +48,15 @@ for name in os.environ.get("CASES", "c3,c2").split(","):
     torch.cuda.synchronize()
     for i in range(1, len(libs)):
         a, b = outs[0], outs[i]
-        d = (a - b).abs().max().item()
+        d = (a - b).abs()
+        if fm:
+            d = torch.minimum(d, 2 * np.pi - d)  # angles: compare on the circle
+        if os.environ.get("AB_WHERE"):  # where two builds disagree (a new kernel's first runs)
+            bad = torch.nonzero(d > float(os.environ["AB_WHERE"])).flatten()
+            print("   %d of %d outputs differ by more than %s; first: %s; mod 128: %s; mod %d (a run of 16 tiles): %s" % (
+                bad.numel(), d.numel(), os.environ["AB_WHERE"], bad[:12].tolist(), sorted(set((bad[:2000] % 128).tolist()))[:20],
+                2048, sorted(set((bad[:2000] % 2048).tolist()))[:20]))
+        d = d.max().item()
         print("%s: %s vs first: max|d| = %.3e (max|y| %.3e)" % (name, os.path.basename(paths[i]), d, a.abs().max().item()))
     for _ in range(10):
         for i in range(len(libs)):
@@ -62,18 +70,19 @@ for name in os.environ.get("CASES", "c3,c2").split(","):
     for i, p in enumerate(paths):
         v = np.array([a.elapsed_time(b) for a, b in ev[i]]) * 1e3
         print("%-4s %-36s median %.2f us  mean %.2f  p10 %.2f  p90 %.2f" % (name, os.path.basename(p), np.median(v), v.mean(), *np.percentile(v, [10, 90])), flush=True)
-    # back to back: bursts of 20 launches of one lib
-    for i, p in enumerate(paths):
-        ts = []
-        for _ in range(5):
+    # back to back: bursts of 20 launches of one lib, the libs taking turns burst by burst (clock drift hits all alike)
+    ts = [[] for _ in libs]
+    for _ in range(8):
+        for i in range(len(libs)):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for _ in range(20):
                 run(i)
             b.record()
             torch.cuda.synchronize()
-            ts.append(a.elapsed_time(b) * 1e3 / 20)
-        print("%-4s %-36s back to back %.2f us per launch (min of 5 bursts of 20; median %.2f)" % (name, os.path.basename(p), min(ts), np.median(ts)), flush=True)
+            ts[i].append(a.elapsed_time(b) * 1e3 / 20)
+    for i, p in enumerate(paths):
+        print("%-4s %-36s back to back %.2f us per launch (median of 8 interleaved bursts of 20; min %.2f)" % (name, os.path.basename(p), np.median(ts[i]), min(ts[i])), flush=True)
     for l, h in zip(libs, hs):
         l.comms_chain_destroy.argtypes = [C.c_void_p]
         l.comms_chain_destroy(h)
