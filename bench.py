@@ -92,8 +92,11 @@ def pmc_traffic(kernel, n):
             d = json.load(f)
         if d.get("kernel") == kernel and d.get("n_samples") == n:
             return d.get("hbm_bytes_per_launch")
+        leg = None
+        if ":" in kernel:
+            kernel, leg = kernel.split(":", 1)
         for e in d.get("others", []):   # configs 3, 4, 5: the dominant kernel at the config's own size
-            if kernel.startswith(e["kernel"]) and n in (e.get("n_samples"), e.get("n_points")):
+            if kernel.startswith(e["kernel"]) and n in (e.get("n_samples"), e.get("n_points")) and e.get("leg") == leg:
                 return e["hbm_bytes_per_launch"]
     except Exception:
         pass
@@ -677,6 +680,72 @@ def fir_chain_pass(ctx, n, first_index, steps, warmup, algo="auto", stride=TIMER
     return res
 
 
+def host_vec_leg(ctx, n):
+    """The drop-in path of an unchanged comms-rs graph (reported separately, never `value`): host memory in,
+    host memory out -- run(&[Complex<f32>]) -> Vec<Complex<f32>> (src/filter/fir_node.rs:215-220).  The metric's chain over
+    2^24 samples through the host-pointer entries, node by node (comms_fir_run -> comms_mixer_run -> comms_decimate_run)
+    and as one comms_chain_run; PCIe both ways is inside the time.  Two forms of the caller: `fresh_out` allocates the
+    output array in every call, as run() returning a fresh Vec does (a fresh 128-MiB allocation is page-faulted in while
+    the copy lands in it); `reused_out` hands the same, touched, buffers to every call.  Long calls are pipelined in
+    chunks by the library (csrc/common.hpp, Handle::run_host_units)."""
+    import ctypes as C
+
+    import comms_rs_amd as c
+    from comms_rs_amd._lib import check
+
+    taps = c.rrc_taps(N_TAPS, 8.0, 0.35)
+    x = c.synth_iq(n, 0, SEED)
+    lib = c.lib()
+    res = {"samples": n, "unit": "Msamples/s"}
+
+    def best(fn, reps=4):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return min(ts)
+
+    fir = c.BatchFirNode(taps, device=ctx.local_rank)
+    mixer = c.MixerNode(MIX_DPHASE, 0.0, device=ctx.local_rank)
+    dec = c.DecimateNode(DEC_RATE, device=ctx.local_rank)
+    chain = c.ChainNode(MIX_DPHASE, 0.0, taps, DEC_RATE, False, device=ctx.local_rank, mixer_after_fir=True)
+    # fresh output per call (the wrappers' run(): np.empty per call, like a Vec returned by value)
+    t_nodes_fresh = best(lambda: dec.run(mixer.run(fir.run(x))))
+    t_chain_fresh = best(lambda: chain.run(x))
+    # the same entries with caller-owned buffers reused over the calls
+    y = np.empty(n, np.complex64)
+    z = np.empty(n // DEC_RATE, np.complex64)
+    y.fill(0)
+    z.fill(0)
+    m = C.c_size_t()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def nodes_reused():
+        check(lib.comms_fir_run(fir._h, vp(x), n, vp(y)))
+        check(lib.comms_mixer_run(mixer._h, vp(y), n, vp(y)))
+        check(lib.comms_decimate_run(vp(y), n, 8, DEC_RATE, vp(z), C.byref(m), ctx.local_rank))
+
+    t_nodes = best(nodes_reused)
+    t_chain = best(lambda: check(lib.comms_chain_run(chain._h, vp(x), n, vp(z))))
+    t_fir = best(lambda: check(lib.comms_fir_run(fir._h, vp(x), n, vp(y))))
+    res.update({
+        "node_by_node": {"value": round(n / t_nodes / 1e6, 1), "ms": round(t_nodes * 1e3, 3),
+                         "fresh_out_value": round(n / t_nodes_fresh / 1e6, 1),
+                         "pcie_bytes_per_sample": "8 + 8 (FIR) + 8 + 8 (mixer) + 8 + 1 (decimate): every node takes host memory"},
+        "fused_chain": {"value": round(n / t_chain / 1e6, 1), "ms": round(t_chain * 1e3, 3),
+                        "fresh_out_value": round(n / t_chain_fresh / 1e6, 1), "GBps_in": round(8.0 * n / t_chain / 1e9, 1),
+                        "pcie_bytes_per_sample": "8 in + 1 out"},
+        "fir_alone": {"value": round(n / t_fir / 1e6, 1), "ms": round(t_fir * 1e3, 3),
+                      "GBps_each_way": round(8.0 * n / t_fir / 1e9, 1)},
+        "pcie_note": "pageable host memory both ways; hipMemcpy on this box moves 56 GB/s one way and 46-48 GB/s each way "
+                     "with both directions busy (profiles/r05_host_path.txt): the FIR node's 8 B in + 8 B out per sample "
+                     "cannot pass ~5.9 Gsamples/s, the fused chain's 9 B ~6.2 Gsamples/s",
+        "pipelined": "calls of 64 MiB and more whose input and output both carry bytes, in 16-MiB chunks: copy in + launch on the node's stream, copy out on a second "
+                     "stream from a helper thread (csrc/common.hpp: Handle::run_host_units)"})
+    return res
+
+
 def run_config2(ctx):
     args, world = ctx.args, ctx.world
     n = 1 << args.n_log2 if args.n_log2 else N_SAMPLES
@@ -737,12 +806,21 @@ def run_config2(ctx):
         "ranks": head["ranks"],
         "box": box_info(ctx.torch, ctx.local_rank),
     }
+    fused_ms = head["fused_elapsed"] / args.steps * 1e3
+    fused_bytes = 9.0 * n   # 8 B read + 8/8 B written per input sample
     out["fused_chain"] = {"value": round(total / head["fused_elapsed"] / 1e6, 1), "unit": "Msamples/s",
-                          "ms_per_step": round(head["fused_elapsed"] / args.steps * 1e3, 4), "fused": head["fused"],
+                          "ms_per_step": round(fused_ms, 4), "fused": head["fused"],
                           "kernel": {"time": "fir_decim_kernel", "freq": "fir_os1024_kernel<.., MODE>",
                                      "unfused": "four kernels"}[head["fused_kernel"]],
+                          "roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": fused_bytes,
+                                       "achieved": round(fused_bytes / (fused_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(fused_bytes / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "traffic": pmc_traffic("fir_decim_kernel:fused_chain", n),
+                                       "clock": "step period of the timed loop (one launch per step, back to back)"},
                           "note": "same FIR->mixer->decimate chain as one comms_chain_* launch "
                                   "(8 B read + 1 B written per input sample); not the headline value"}
+    if ctx.rank == 0 and not args.no_host_vec:
+        out["host_vec"] = host_vec_leg(ctx, min(n, N_SAMPLES))
     if stream is not None:
         st = stream
         ach = FIR_BYTES_PER_SAMPLE * st["per"] / (st["kernel_ms"] * 1e-3) / 1e9
@@ -1200,6 +1278,7 @@ def main():
                     help="config 2: log2 of the whole stream of the strong-scaling extra (0 = skip it)")
     ap.add_argument("--n-log2", type=int, default=0, help="rehearsal: override log2 of the per-GPU size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-vec", action="store_true", help="skip the host-pointer (Vec in, Vec out) leg of the default config")
     ap.add_argument("--head-first", action="store_true",
                     help="config 2: time the headline chain before the 2^30-sample stream leg (default: after it)")
     ap.add_argument("--algo", choices=["auto", "direct", "os1024", "os4096"], default="auto")

@@ -318,8 +318,11 @@ comms_status_t comms_chain_run(comms_chain_t* h, const comms_c32* in, size_t n, 
     if (!n) return COMMS_OK;
     const size_t out_bytes = (n / h->rate) * (h->fm_demod ? sizeof(float) : sizeof(comms_c32));
     const size_t in_elem = h->in_fmt == COMMS_IQ_I16 ? 4 : h->in_fmt == COMMS_IQ_U8 ? 2 : 8;
-    COMMS_TRY(h->run_host(in, n * in_elem, out, out_bytes, [&](void* d_in, void* d_out) {
-        return comms_chain_run_dev(h, static_cast<const comms_c32*>(d_in), n, d_out, COMMS_STREAM_HANDLE);
+    // (chunks of whole groups of `rate` samples: DecimateNode restarts its index with every batch, src/util/resample_node.rs:53-65,
+    // and a chunk that starts on a multiple of the rate keeps the batch's indexing)
+    const size_t out_elem = h->fm_demod ? sizeof(float) : sizeof(comms_c32);
+    COMMS_TRY(h->run_host_units(in, n * in_elem, h->rate * in_elem, out, out_bytes, out_elem, [&](void* d_in, void* d_out, size_t ib, size_t) {
+        return comms_chain_run_dev(h, static_cast<const comms_c32*>(d_in), ib / in_elem, d_out, COMMS_STREAM_HANDLE);
     }));
     // (a long filter runs the 16384-point FIR kernel inside the series of launches: its failure is this call's)
     return h->fir ? fir_check_sticky(h->fir) : COMMS_OK;

@@ -9,7 +9,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <thread>
+#include <vector>
 
 #include "../../include/comms_hip.h"
 
@@ -236,6 +240,10 @@ COMMS_INTERNAL void stream_release(int32_t device, hipStream_t s);
 // follow their own stream).  A handle remembers the last stream it launched on, possibly a pooled one that its owner
 // has since released: comms_stream_pool_trim must not destroy streams while such a handle exists.
 COMMS_INTERNAL void handle_count(int32_t device, int delta);
+// in + out bytes from which a host-pointer call is pipelined in chunks (COMMS_HOST_PIPE_BYTES, a documented runtime limit
+// like COMMS_ZERO_COPY_BYTES; 0 = never)
+COMMS_INTERNAL size_t host_pipe_bytes();
+COMMS_INTERNAL size_t host_chunk_bytes();  // COMMS_HOST_CHUNK_BYTES: bytes of the larger side per chunk (default 8 MiB)
 
 struct Handle {
     int32_t device = 0;
@@ -350,7 +358,117 @@ struct Handle {
         return COMMS_OK;
     }
 
+    // ---- long host-pointer calls, pipelined (round 5) ----------------------------------------------------------------
+    // The drop-in path of a comms-rs graph is `run(&[Complex<T>]) -> Vec<Complex<T>>` (src/filter/fir_node.rs:215-220):
+    // host memory in, host memory out.  Until round 4 that was one copy in, the launch, one copy out, one direction of
+    // the PCIe link at a time.  Above kHostPipeBytes (and where both directions carry bytes) the batch is now cut into chunks of whole UNITS (a unit = in_u input
+    // bytes that yield out_u output bytes: a sample, `rate` samples of a decimator, one transform): the calling thread
+    // feeds chunk after chunk -- copy in, launch(es), an event -- and a helper thread copies each chunk's outputs back
+    // on a second stream as soon as its event has fired, so that the two directions of the link run together.  Stateful
+    // nodes stream across the chunks exactly as they stream across calls (same launches, same order, one stream), so the
+    // samples are bit-identical to the single-shot path (tests/test_gpu_host_pipeline.py).
+    hipStream_t out_stream = nullptr;
+    std::vector<hipEvent_t> pipe_events;
+    static constexpr size_t kHostPipeBytes = 64u << 20;   // in + out bytes from which a call is pipelined
+    static constexpr size_t kHostChunkBytes = 16u << 20;  // of the larger side, per chunk
+    template <class F>
+    comms_status_t run_host_units(const void* in, size_t in_bytes, size_t in_u, void* out, size_t out_bytes, size_t out_u, F&& launch) {
+        const size_t big_u = in_u > out_u ? in_u : out_u;
+        size_t per = big_u ? host_chunk_bytes() / big_u : 0;
+        if (per < 1) per = 1;
+        const size_t n_units = in_u ? (in_bytes + in_u - 1) / in_u : 1;
+        const size_t n_chunks = (n_units + per - 1) / per;
+        // Only where BOTH directions carry a real share of the bytes: what the pipeline buys is the two directions of the
+        // link at once (2^24 samples through the FIR node: 4.84 -> 3.26 ms); a decimating chain's output is an eighth of
+        // its input, and its one big copy in is faster whole than in chunks (2.74 against 2.82 - 3.20 ms) --
+        // scripts/bench_host_path.py, profiles/r05_host_pipeline.txt
+        const bool both_ways = out_bytes * 4 >= in_bytes && in_bytes * 4 >= out_bytes;
+        if (in_bytes + out_bytes < host_pipe_bytes() || n_chunks < 2 || !in_u || !out_u || !both_ways)
+            return run_host(in, in_bytes, out, out_bytes, [&](void* d_in, void* d_out) { return launch(d_in, d_out, in_bytes, out_bytes); });
+        COMMS_TRY(in_scratch.reserve(in_bytes));
+        COMMS_TRY(out_scratch.reserve(out_bytes));
+        if (!out_stream) COMMS_TRY(stream_acquire(device, &out_stream));
+        while (pipe_events.size() < n_chunks) {
+            hipEvent_t e = nullptr;
+            COMMS_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            pipe_events.push_back(e);
+        }
+        struct Shared {
+            std::mutex m;
+            std::condition_variable cv;
+            size_t recorded = 0;   // chunks whose event has been recorded
+            bool abort = false;
+            hipError_t err = hipSuccess;
+        } sh;
+        const char* cin = static_cast<const char*>(in);
+        char* cout_ = static_cast<char*>(out);
+        char* din = static_cast<char*>(in_scratch.p);
+        char* dout = static_cast<char*>(out_scratch.p);
+        auto out_range = [&](size_t k, size_t& o0, size_t& o1) {
+            o0 = k * per * out_u;
+            o1 = (k + 1) * per * out_u;
+            if (o0 > out_bytes) o0 = out_bytes;
+            if (o1 > out_bytes || k + 1 == n_chunks) o1 = out_bytes;
+        };
+        std::thread back([&] {
+            if (hipSetDevice(device) != hipSuccess) {
+                std::lock_guard<std::mutex> lk(sh.m);
+                sh.err = hipErrorInvalidDevice;
+                return;
+            }
+            for (size_t k = 0; k < n_chunks; ++k) {
+                {
+                    std::unique_lock<std::mutex> lk(sh.m);
+                    sh.cv.wait(lk, [&] { return sh.recorded > k || sh.abort; });
+                    if (sh.abort) return;
+                }
+                size_t o0, o1;
+                out_range(k, o0, o1);
+                hipError_t e = hipStreamWaitEvent(out_stream, pipe_events[k], 0);
+                if (e == hipSuccess && o1 > o0) e = hipMemcpyAsync(cout_ + o0, dout + o0, o1 - o0, hipMemcpyDeviceToHost, out_stream);
+                if (e != hipSuccess) {
+                    std::lock_guard<std::mutex> lk(sh.m);
+                    sh.err = e;
+                    return;
+                }
+            }
+            hipError_t e = hipStreamSynchronize(out_stream);
+            if (e != hipSuccess) {
+                std::lock_guard<std::mutex> lk(sh.m);
+                sh.err = e;
+            }
+        });
+        comms_status_t st = COMMS_OK;
+        for (size_t k = 0; k < n_chunks && st == COMMS_OK; ++k) {
+            size_t i0 = k * per * in_u, i1 = (k + 1) * per * in_u;
+            if (i1 > in_bytes || k + 1 == n_chunks) i1 = in_bytes;
+            size_t o0, o1;
+            out_range(k, o0, o1);
+            hipError_t e = hipMemcpyAsync(din + i0, cin + i0, i1 - i0, hipMemcpyHostToDevice, stream);
+            if (e != hipSuccess) st = fail(COMMS_ERR_DEVICE, "host pipeline: copy in failed: %s", hipGetErrorString(e));
+            if (st == COMMS_OK) st = launch(din + i0, dout + o0, i1 - i0, o1 - o0);
+            if (st == COMMS_OK && (e = hipEventRecord(pipe_events[k], stream)) != hipSuccess)
+                st = fail(COMMS_ERR_DEVICE, "host pipeline: event record failed: %s", hipGetErrorString(e));
+            std::lock_guard<std::mutex> lk(sh.m);
+            if (st == COMMS_OK) sh.recorded = k + 1;
+            else sh.abort = true;
+            sh.cv.notify_all();
+        }
+        back.join();
+        if (st != COMMS_OK) {
+            (void)hipStreamSynchronize(stream);  // nothing of this call stays in flight behind an error
+            return st;
+        }
+        if (sh.err != hipSuccess) return fail(COMMS_ERR_DEVICE, "host pipeline: copy out failed: %s", hipGetErrorString(sh.err));
+        COMMS_HIP_TRY(hipStreamSynchronize(stream));
+        return COMMS_OK;
+    }
+
     void fini() {
+        for (hipEvent_t e : pipe_events) (void)hipEventDestroy(e);
+        pipe_events.clear();
+        if (out_stream) stream_release(device, out_stream);
+        out_stream = nullptr;
         in_scratch.release();
         out_scratch.release();
         pin_in.release();

@@ -276,6 +276,22 @@ __global__ __launch_bounds__(256, 4) void probe_read_wave_kernel(const float2* _
             else if (st_mode == 6) { if ((t & 7) == 7) { for (int i = 0; i < 8; ++i) out[(t - 7 + i) * 64 + l] = v; } }  // eight tiles' outputs in one burst
         }
     };
+    if (st_mode >= 16) {  // staggered: the wave walks its chunk from tile (wave * mul) % nt_chunk on and wraps (no two waves' phases alike)
+        const int mul = st_mode >> 4;
+        st_mode &= 15;
+        for (size_t c = wave; c < n_chunks; c += n_waves) {
+            const size_t t0 = c * nt_chunk;
+            const size_t s0 = (wave * mul) % nt_chunk;
+            fetch(t0 + s0, xa);
+            for (int i = 0; i < nt_chunk; i += 2) {
+                const size_t ta = t0 + (s0 + i) % nt_chunk, tb = t0 + (s0 + i + 1) % nt_chunk, tc = t0 + (s0 + i + 2) % nt_chunk;
+                if (i + 1 < nt_chunk) fetch(tb, xb);
+                consume(ta, xa);
+                if (i + 2 < nt_chunk) fetch(tc, xa);
+                if (i + 1 < nt_chunk) consume(tb, xb);
+            }
+        }
+    } else
     for (size_t c = wave; c < n_chunks; c += n_waves) {
         const size_t t0 = c * nt_chunk, t1 = t0 + nt_chunk < n_tiles ? t0 + nt_chunk : n_tiles;
         fetch(t0, xa);

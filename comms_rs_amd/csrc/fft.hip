@@ -2156,8 +2156,9 @@ comms_status_t comms_fft_run(comms_fft_t* h, const comms_c32* in, size_t n, comm
               "input length %zu is not a multiple of fft_size %zu (the reference panics)", n, h->N);
     COMMS_ARG(in && out, "NULL host pointer");
     COMMS_TRY(use_device(h->device));
-    return h->run_host(in, n * sizeof(comms_c32), out, n * sizeof(comms_c32), [&](void* d_in, void* d_out) {
-        return comms_fft_run_dev(h, static_cast<const comms_c32*>(d_in), n, static_cast<comms_c32*>(d_out), COMMS_STREAM_HANDLE);
+    const size_t xform = h->N * sizeof(comms_c32);  // (chunks of whole transforms)
+    return h->run_host_units(in, n * sizeof(comms_c32), xform, out, n * sizeof(comms_c32), xform, [&](void* d_in, void* d_out, size_t ib, size_t) {
+        return comms_fft_run_dev(h, static_cast<const comms_c32*>(d_in), ib / sizeof(comms_c32), static_cast<comms_c32*>(d_out), COMMS_STREAM_HANDLE);
     });
 }
 

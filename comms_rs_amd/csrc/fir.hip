@@ -2047,8 +2047,9 @@ comms_status_t comms_fir_run(comms_fir_t* h, const comms_c32* in, size_t n, comm
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
     const size_t in_elem = h->in_fmt == COMMS_IQ_I16 ? 4 : h->in_fmt == COMMS_IQ_U8 ? 2 : 8;
-    COMMS_TRY(h->run_host(in, n * in_elem, out, n * sizeof(comms_c32), [&](void* d_in, void* d_out) {
-        return comms_fir_run_dev(h, static_cast<const comms_c32*>(d_in), n, static_cast<comms_c32*>(d_out), COMMS_STREAM_HANDLE);
+    // (long batches go through the chunked host pipeline, common.hpp: the history streams across the chunks as across calls)
+    COMMS_TRY(h->run_host_units(in, n * in_elem, in_elem, out, n * sizeof(comms_c32), sizeof(comms_c32), [&](void* d_in, void* d_out, size_t ib, size_t) {
+        return comms_fir_run_dev(h, static_cast<const comms_c32*>(d_in), ib / in_elem, static_cast<comms_c32*>(d_out), COMMS_STREAM_HANDLE);
     }));
     // run_host has waited for this call's launches: a wait of the 16384-point kernel that ran out in THIS call is
     // reported by this call (its samples are in `out`, and they are wrong)
@@ -2389,8 +2390,9 @@ comms_status_t comms_pulse_run(comms_pulse_t* h, const comms_c32* sym, size_t n_
     COMMS_ARG((sym && out) || !n_sym, "NULL host pointer");
     COMMS_TRY(use_device(h->device));
     if (!n_sym) return COMMS_OK;
-    return h->run_host(sym, n_sym * sizeof(comms_c32), out, n_sym * h->sps * (h->out_i16 ? 4 : sizeof(comms_c32)), [&](void* d_in, void* d_out) {
-        return comms_pulse_run_dev(h, static_cast<const comms_c32*>(d_in), n_sym, static_cast<comms_c32*>(d_out), COMMS_STREAM_HANDLE);
+    const size_t out_sym = static_cast<size_t>(h->sps) * (h->out_i16 ? 4 : sizeof(comms_c32));  // output bytes per symbol
+    return h->run_host_units(sym, n_sym * sizeof(comms_c32), sizeof(comms_c32), out, n_sym * out_sym, out_sym, [&](void* d_in, void* d_out, size_t ib, size_t) {
+        return comms_pulse_run_dev(h, static_cast<const comms_c32*>(d_in), ib / sizeof(comms_c32), static_cast<comms_c32*>(d_out), COMMS_STREAM_HANDLE);
     });
 }
 

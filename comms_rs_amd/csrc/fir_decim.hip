@@ -38,10 +38,16 @@
 #define COMMS_DECIM_NOMAC_DEFAULT 0
 #endif
 #ifndef COMMS_DECIM_WAVE_DEFAULT
-#define COMMS_DECIM_WAVE_DEFAULT 0
+#define COMMS_DECIM_WAVE_DEFAULT 1
 #endif
 #ifndef COMMS_DECIM_WAVE_NT_DEFAULT
-#define COMMS_DECIM_WAVE_NT_DEFAULT 0
+#define COMMS_DECIM_WAVE_NT_DEFAULT -1
+#endif
+#ifndef COMMS_DECIM_WAVE_SPLIT_DEFAULT
+#define COMMS_DECIM_WAVE_SPLIT_DEFAULT 1
+#endif
+#ifndef COMMS_DECIM_WAVE_WPB_DEFAULT
+#define COMMS_DECIM_WAVE_WPB_DEFAULT 1
 #endif
 
 namespace comms {
@@ -542,6 +548,9 @@ __global__ __launch_bounds__(64 * WPB, 4) void fir_decim_wave_kernel(const Decim
     const bool fm = (a.mode & COMMS_CHAIN_FM) != 0;
     const long long n_out = static_cast<long long>(a.n_out);
     const long long C = 128LL * a.nt_chunk;  // outputs per run
+    // (run k belongs to workgroup k: the sixteen waves that share a CU then work 32 MiB apart.  Giving them sixteen
+    // ADJACENT runs instead -- b -> (b % 256) * 16 + b / 256, 2 MiB of the stream per CU -- was measured and is slower,
+    // 130.6 against 124.6 us on config 3, as are four-wave workgroups with four adjacent runs: NOTES.md, round 5)
     const long long wave0 = static_cast<long long>(blockIdx.x) * WPB + w, n_waves = static_cast<long long>(gridDim.x) * WPB;
 
     // lane constants: LDS slot of the lane's sample of row 0 (row m: + RPE m; halo row i: - SCAP + RPE i), its rotor
@@ -572,7 +581,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void fir_decim_wave_kernel(const Decim
             for (int i = 0; i < HR; ++i) xh[i] = to_cf(BufRows<const float2*>::get_from(rs, voff, 512u * i));
 #pragma unroll
             for (int m = 0; m < PR; ++m) {
-                const bv2u q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, off + 512u * m, AUX);
+                const bv2u q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, off + 512u * m, AUX & 2);
                 x[m] = cf{__uint_as_float(q.x), __uint_as_float(q.y)};
             }
         } else {
@@ -640,7 +649,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void fir_decim_wave_kernel(const Decim
             if (i + 1 < a.nt_chunk && J0 + 128 < n_out) {
 #pragma unroll
                 for (int m = 0; m < PR; ++m) {
-                    const bv2u q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, off + 512u * m, AUX);
+                    const bv2u q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, off + 512u * m, AUX & 2);
                     x[m] = cf{__uint_as_float(q.x), __uint_as_float(q.y)};
                 }
             }
@@ -724,10 +733,14 @@ __global__ __launch_bounds__(64 * WPB, 4) void fir_decim_wave_kernel(const Decim
                 carry = cf{__builtin_bit_cast(float, cx), __builtin_bit_cast(float, cy)};
                 const float o0 = fm_step_fast(to_f2(y0), to_f2(p0)), o1 = fm_step_fast(to_f2(y1), to_f2(y0));
                 float* o = static_cast<float*>(a.out);
-                if (whole)  // (j0 is even and the host checked the buffer's alignment; a plain store, so that the compiler's
-                            // vmcnt arithmetic sees it: behind an asm store it waited for the store's completion as well)
-                    *reinterpret_cast<float2*>(o + j0) = make_float2(o0, o1);
-                else {
+                if (whole) {  // (j0 is even and the host checked the buffer's alignment; a plain store, so that the compiler's
+                              // vmcnt arithmetic sees it: behind an asm store it waited for the store's completion as well)
+                    if (AUX & 4) {
+                        typedef float nt_f2 __attribute__((ext_vector_type(2)));
+                        __builtin_nontemporal_store(nt_f2{o0, o1}, reinterpret_cast<nt_f2*>(o + j0));
+                    } else
+                        *reinterpret_cast<float2*>(o + j0) = make_float2(o0, o1);
+                } else {
                     if (j0 < n_out) o[j0] = o0;
                     if (j0 + 1 < n_out) o[j0 + 1] = o1;
                 }
@@ -756,7 +769,9 @@ static thread_local hipEvent_t g_decim_ev_start = nullptr, g_decim_ev_stop = nul
 template <int R, bool REAL, bool PRE, int HR, int WPB, int AUX>
 static comms_status_t launch_decim_wave_v(const DecimArgs& a, hipStream_t s) {
     using G = DwGeom<R, HR>;
-    constexpr size_t lds = G::LDS_WAVE * WPB;
+    // (single-wave workgroups ask for a sixteenth of the CU's LDS: seventeen would fit at HR = 2, and the dispatcher
+    // would then fill some CUs with 17 waves and leave others 15)
+    constexpr size_t lds = WPB == 1 && G::LDS_WAVE < 10240 ? 10240 : G::LDS_WAVE * WPB;
     const size_t want = (static_cast<size_t>(a.n_chunks) + WPB - 1) / WPB;
     const size_t slots = (160u * 1024u / lds) * kNumCU;
     const unsigned blocks = static_cast<unsigned>(want < slots ? want : slots);
@@ -1006,11 +1021,13 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
         (reinterpret_cast<uintptr_t>(d_out) & 15) == 0) {  // (its stores are 8 / 16 bytes per lane)
         const int HR = a.hlq * PR <= 128 ? 2 : 4;
         const long long tiles = static_cast<long long>((a.n_out + 127) / 128);
-        const long long waves = (HR == 2 ? 16 : 12) * static_cast<long long>(kNumCU);
+        const long long waves = (HR == 2 ? 16 : 15) * static_cast<long long>(kNumCU);  // single-wave workgroups: 10240 / 10368 B of LDS each
         const long long nt = (tiles + waves - 1) / waves;
         const bool balanced = tiles >= waves && nt * waves * 100 <= tiles * 104;
         if (balanced || wave_knob == 2) {
             a.nt_chunk = static_cast<int>(nt < 1 ? 1 : nt);
+            static const int ntc_div = diag_knob("COMMS_DECIM_WAVE_SPLIT", COMMS_DECIM_WAVE_SPLIT_DEFAULT);  // runs per wave (trial)
+            if (ntc_div > 1 && a.nt_chunk % ntc_div == 0) a.nt_chunk /= ntc_div;
             a.n_chunks = (tiles + a.nt_chunk - 1) / a.nt_chunk;
             a.interleave = 0;
             mix_host_rotor(static_cast<uint64_t>(R) * 128u * frac, a.tile_c, a.tile_s);
@@ -1023,8 +1040,17 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
                 a.step_h[i] = make_float2(static_cast<float>(c), static_cast<float>(sn));
             }
             const bool pre = (mode & COMMS_CHAIN_PRE) != 0;
-            static const int nt_loads = diag_knob("COMMS_DECIM_WAVE_NT", COMMS_DECIM_WAVE_NT_DEFAULT);
-#define COMMS_DW(REAL_, PRE_, HR_) (nt_loads ? launch_decim_wave_v<8, REAL_, PRE_, HR_, 4, 2>(a, s) : launch_decim_wave_v<8, REAL_, PRE_, HR_, 4, 0>(a, s))
+            // nontemporal loads and stores once the batch is past what the 256 MiB Infinity Cache can hold for the next kernel
+            // (config 3 at 2^26 samples: 128.3 -> 120.3 us; at 2^24 the re-read input of a benchmark loop would lose its
+            // cache hits); the diagnostic build's COMMS_DECIM_WAVE_NT = 0 / 2 (loads) / 4 (stores) / 6 forces a form
+            static const int nt_knob = diag_knob("COMMS_DECIM_WAVE_NT", COMMS_DECIM_WAVE_NT_DEFAULT);
+            const int nt_loads = nt_knob >= 0 ? nt_knob : (n * sizeof(float2) > (192u << 20) ? 6 : 0);
+#ifdef COMMS_DIAG
+            static const int wpb4 = diag_knob("COMMS_DECIM_WAVE_WPB", COMMS_DECIM_WAVE_WPB_DEFAULT) == 4;
+#define COMMS_DW(REAL_, PRE_, HR_) (wpb4 ? launch_decim_wave_v<8, REAL_, PRE_, HR_, 4, 0>(a, s) : nt_loads == 2 ? launch_decim_wave_v<8, REAL_, PRE_, HR_, 1, 2>(a, s) : nt_loads == 4 ? launch_decim_wave_v<8, REAL_, PRE_, HR_, 1, 4>(a, s) : nt_loads == 6 ? launch_decim_wave_v<8, REAL_, PRE_, HR_, 1, 6>(a, s) : launch_decim_wave_v<8, REAL_, PRE_, HR_, 1, 0>(a, s))
+#else
+#define COMMS_DW(REAL_, PRE_, HR_) (nt_loads ? launch_decim_wave_v<8, REAL_, PRE_, HR_, 1, 6>(a, s) : launch_decim_wave_v<8, REAL_, PRE_, HR_, 1, 0>(a, s))
+#endif
             if (HR == 2)
                 st = real ? (pre ? COMMS_DW(true, true, 2) : COMMS_DW(true, false, 2)) : (pre ? COMMS_DW(false, true, 2) : COMMS_DW(false, false, 2));
             else

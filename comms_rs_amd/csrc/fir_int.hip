@@ -147,8 +147,8 @@ static comms_status_t run_int_host(comms_fir_i16* h, const comms_c16* in, size_t
     COMMS_ARG((in && out) || !n, "NULL host pointer");
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
-    return h->run_host(in, n * 4, out, n * h->sps * 4, [&](void* d_in, void* d_out) {
-        return run_int_dev(h, static_cast<const comms_c16*>(d_in), n, static_cast<comms_c16*>(d_out), COMMS_STREAM_HANDLE);
+    return h->run_host_units(in, n * 4, 4, out, n * h->sps * 4, static_cast<size_t>(h->sps) * 4, [&](void* d_in, void* d_out, size_t ib, size_t) {
+        return run_int_dev(h, static_cast<const comms_c16*>(d_in), ib / 4, static_cast<comms_c16*>(d_out), COMMS_STREAM_HANDLE);
     });
 }
 

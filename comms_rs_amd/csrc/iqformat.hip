@@ -65,13 +65,15 @@ static unsigned conv_grid(size_t n) {
     return static_cast<unsigned>(b ? b : 1);
 }
 
-// run(d_in, d_out, stream): the device form on the borrowed handle's stream
+// run(d_in, d_out, samples, stream): the device form on the borrowed handle's stream; in_e / out_e bytes per sample (long
+// captures go through the chunked host pipeline, common.hpp)
 template <typename F>
-static comms_status_t via_device(const void* in, size_t in_bytes, void* out, size_t out_bytes, int32_t device, F run) {
+static comms_status_t via_device(const void* in, size_t n, size_t in_e, void* out, size_t out_e, int32_t device, F run) {
     COMMS_TRY(use_device(device));
     Handle* h = nullptr;
     COMMS_TRY(thread_handle(device, &h));
-    return h->run_host(in, in_bytes, out, out_bytes, [&](void* d_in, void* d_out) { return run(d_in, d_out, h->stream); });
+    return h->run_host_units(in, n * in_e, in_e, out, n * out_e, out_e,
+                             [&](void* d_in, void* d_out, size_t ib, size_t) { return run(d_in, d_out, ib / in_e, h->stream); });
 }
 
 }  // namespace comms
@@ -139,22 +141,22 @@ comms_status_t comms_iq_c32_re_dev(const comms_c32* d_in, size_t n, float* d_out
 comms_status_t comms_iq_i16_to_c32(const int16_t* in, size_t n, float scale, comms_c32* out, int32_t device) {
     COMMS_ARG((in && out) || !n, "NULL host pointer");
     if (!n) return use_device(device);
-    return via_device(in, n * 4, out, n * 8, device, [&](void* a, void* b, void* st) {
-        return comms_iq_i16_to_c32_dev(static_cast<const int16_t*>(a), n, scale, static_cast<comms_c32*>(b), device, st);
+    return via_device(in, n, 4, out, 8, device, [&](void* a, void* b, size_t m, void* st) {
+        return comms_iq_i16_to_c32_dev(static_cast<const int16_t*>(a), m, scale, static_cast<comms_c32*>(b), device, st);
     });
 }
 comms_status_t comms_iq_c32_to_i16(const comms_c32* in, size_t n, float scale, int16_t* out, int32_t device) {
     COMMS_ARG((in && out) || !n, "NULL host pointer");
     if (!n) return use_device(device);
-    return via_device(in, n * 8, out, n * 4, device, [&](void* a, void* b, void* st) {
-        return comms_iq_c32_to_i16_dev(static_cast<const comms_c32*>(a), n, scale, static_cast<int16_t*>(b), device, st);
+    return via_device(in, n, 8, out, 4, device, [&](void* a, void* b, size_t m, void* st) {
+        return comms_iq_c32_to_i16_dev(static_cast<const comms_c32*>(a), m, scale, static_cast<int16_t*>(b), device, st);
     });
 }
 comms_status_t comms_iq_u8_to_c32(const uint8_t* in, size_t n, comms_c32* out, int32_t device) {
     COMMS_ARG((in && out) || !n, "NULL host pointer");
     if (!n) return use_device(device);
-    return via_device(in, n * 2, out, n * 8, device, [&](void* a, void* b, void* st) {
-        return comms_iq_u8_to_c32_dev(static_cast<const uint8_t*>(a), n, static_cast<comms_c32*>(b), device, st);
+    return via_device(in, n, 2, out, 8, device, [&](void* a, void* b, size_t m, void* st) {
+        return comms_iq_u8_to_c32_dev(static_cast<const uint8_t*>(a), m, static_cast<comms_c32*>(b), device, st);
     });
 }
 

@@ -387,8 +387,8 @@ comms_status_t comms_mixer_run(comms_mixer_t* h, const comms_c32* in, size_t n, 
     COMMS_ARG((in && out) || !n, "NULL host pointer");
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
-    return h->run_host(in, n * sizeof(comms_c32), out, n * sizeof(comms_c32), [&](void* d_in, void* d_out) {
-        return comms_mixer_run_dev(h, static_cast<const comms_c32*>(d_in), n, static_cast<comms_c32*>(d_out), COMMS_STREAM_HANDLE);
+    return h->run_host_units(in, n * sizeof(comms_c32), sizeof(comms_c32), out, n * sizeof(comms_c32), sizeof(comms_c32), [&](void* d_in, void* d_out, size_t ib, size_t) {
+        return comms_mixer_run_dev(h, static_cast<const comms_c32*>(d_in), ib / sizeof(comms_c32), static_cast<comms_c32*>(d_out), COMMS_STREAM_HANDLE);
     });
 }
 
@@ -418,8 +418,8 @@ comms_status_t comms_mixer_run_f64(comms_mixer_t* h, const comms_c64* in, size_t
     COMMS_ARG((in && out) || !n, "NULL host pointer");
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
-    return h->run_host(in, n * sizeof(comms_c64), out, n * sizeof(comms_c64), [&](void* d_in, void* d_out) {
-        return comms_mixer_run_f64_dev(h, static_cast<const comms_c64*>(d_in), n, static_cast<comms_c64*>(d_out), COMMS_STREAM_HANDLE);
+    return h->run_host_units(in, n * sizeof(comms_c64), sizeof(comms_c64), out, n * sizeof(comms_c64), sizeof(comms_c64), [&](void* d_in, void* d_out, size_t ib, size_t) {
+        return comms_mixer_run_f64_dev(h, static_cast<const comms_c64*>(d_in), ib / sizeof(comms_c64), static_cast<comms_c64*>(d_out), COMMS_STREAM_HANDLE);
     });
 }
 
@@ -546,9 +546,12 @@ static comms_status_t resample_host(bool up, const void* in, size_t n, size_t el
     if (!n_out) return COMMS_OK;
     Handle* h = nullptr;  // these two nodes have no handle in the C ABI
     COMMS_TRY(thread_handle(device, &h));
-    return h->run_host(in, n * elem, out, n_out * elem, [&](void* d_in, void* d_out) {
-        return up ? comms_upsample_run_dev(d_in, n, elem, rate, d_out, nullptr, device, h->stream)
-                  : comms_decimate_run_dev(d_in, n, elem, rate, d_out, nullptr, device, h->stream);
+    // (units: one element in, `rate` out -- or `rate` in, one out: a chunk of whole units keeps the batch's indexing,
+    // src/util/resample_node.rs:53-65,120-131; the ragged tail of a decimated batch is the last chunk's)
+    const size_t r = rate < 1 ? 1 : rate;
+    return h->run_host_units(in, n * elem, up ? elem : r * elem, out, n_out * elem, up ? r * elem : elem, [&](void* d_in, void* d_out, size_t ib, size_t) {
+        return up ? comms_upsample_run_dev(d_in, ib / elem, elem, rate, d_out, nullptr, device, h->stream)
+                  : comms_decimate_run_dev(d_in, ib / elem, elem, rate, d_out, nullptr, device, h->stream);
     });
 }
 
@@ -620,8 +623,8 @@ comms_status_t comms_fmdemod_run(comms_fmdemod_t* h, const comms_c32* in, size_t
     COMMS_ARG((in && out) || !n, "NULL host pointer");
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
-    return h->run_host(in, n * sizeof(comms_c32), out, n * sizeof(float), [&](void* d_in, void* d_out) {
-        return comms_fmdemod_run_dev(h, static_cast<const comms_c32*>(d_in), n, static_cast<float*>(d_out), COMMS_STREAM_HANDLE);
+    return h->run_host_units(in, n * sizeof(comms_c32), sizeof(comms_c32), out, n * sizeof(float), sizeof(float), [&](void* d_in, void* d_out, size_t ib, size_t) {
+        return comms_fmdemod_run_dev(h, static_cast<const comms_c32*>(d_in), ib / sizeof(comms_c32), static_cast<float*>(d_out), COMMS_STREAM_HANDLE);
     });
 }
 

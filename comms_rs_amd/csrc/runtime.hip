@@ -17,6 +17,24 @@ size_t zero_copy_limit() {
 }
 
 
+size_t host_pipe_bytes() {
+    static const size_t lim = [] {
+        const char* v = getenv("COMMS_HOST_PIPE_BYTES");
+        const long long x = v && *v ? atoll(v) : static_cast<long long>(Handle::kHostPipeBytes);
+        return x <= 0 ? ~static_cast<size_t>(0) : static_cast<size_t>(x);
+    }();
+    return lim;
+}
+
+size_t host_chunk_bytes() {
+    static const size_t b = [] {
+        const char* v = getenv("COMMS_HOST_CHUNK_BYTES");
+        const long long x = v && *v ? atoll(v) : static_cast<long long>(Handle::kHostChunkBytes);
+        return x < 4096 ? static_cast<size_t>(4096) : static_cast<size_t>(x);
+    }();
+    return b;
+}
+
 comms_status_t use_device(int32_t device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

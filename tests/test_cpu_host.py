@@ -397,3 +397,38 @@ def test_shard_helpers_of_the_c_abi_match_their_definition():
         r = max(rate, 1)
         need = (taps - 1) + (r if fm else 0)
         assert sh.chain_prefix_len(taps, rate, fm) == -(-need // r) * r
+
+
+def test_no_environment_switch_reaches_a_product_launch_path():
+    """Kernel selectors and sweep knobs exist in the diagnostic build only (csrc/common.hpp: diag_knob is a getenv under
+    COMMS_DIAG and a compile-time default otherwise).  Every other getenv in csrc/ must be on this allow-list of documented
+    runtime LIMITS (resources, not kernel choices or results): a new one fails this test until it is listed here and in
+    DESIGN.md section 1."""
+    import re
+
+    allowed = {("runtime.hip", "COMMS_ZERO_COPY_BYTES"), ("runtime.hip", "COMMS_BUF_POOL_MB"),
+               ("runtime.hip", "COMMS_HOST_PIPE_BYTES"), ("runtime.hip", "COMMS_HOST_CHUNK_BYTES")}
+    csrc = os.path.join(ROOT, "comms_rs_amd", "csrc")
+    found = set()
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".hpp", ".cpp", ".h")):
+            continue
+        text = open(os.path.join(csrc, name)).read()
+        # strip what only the diagnostic build compiles
+        depth, keep, stack = 0, [], []
+        for line in text.split("\n"):
+            st = line.strip()
+            if st.startswith("#if"):
+                stack.append(st.startswith("#ifdef COMMS_DIAG") or st.startswith("#if defined(COMMS_DIAG)"))
+            elif st.startswith("#else") and stack:
+                stack[-1] = False if stack[-1] else stack[-1]
+            elif st.startswith("#endif") and stack:
+                stack.pop()
+            if not any(stack):
+                keep.append(line)
+        for m in re.finditer(r'getenv\(\s*("([A-Z0-9_]+)"|[a-z_]+)\s*\)', "\n".join(l for l in keep if not l.strip().startswith("//"))):
+            found.add((name, m.group(2) or m.group(1)))
+    assert found <= allowed, "getenv outside COMMS_DIAG: %s" % sorted(found - allowed)
+    assert allowed <= found, "allow-list entries that no longer exist: %s" % sorted(allowed - found)
+    # and the results-changing debug switch of round 4 is gone from every build's launch path
+    assert 'getenv("COMMS_DECIM_DEBUG_NOMAC")' not in open(os.path.join(csrc, "fir_decim.hip")).read()

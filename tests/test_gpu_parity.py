@@ -1884,3 +1884,21 @@ def test_nodes_run_concurrently_on_their_own_threads(c):
     for a, b in zip(serial, parallel):
         for u, v in zip(a, b):
             assert np.array_equal(u, v)
+
+
+def test_wave_private_chain_kernel_at_every_size_the_other_chain_tests_use():
+    """fir_decim_wave_kernel (round 5) takes rate-8 Complex<f32> chains whose tiles spread evenly over the chip's waves --
+    config 3 at 2^26 samples, and the full-size tests above reach it that way.  The diagnostic build's COMMS_DECIM_WAVE=2
+    sends EVERY rate-8 chain to it, whatever the batch: single-tile runs, ragged last tiles, one-output batches, state
+    carried over calls, shards -- the chain tests of this file and the shard tests, run once more in that mode (own
+    process: the switch is read once)."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, COMMS_HIP_LIB=DIAG_LIB, COMMS_DECIM_WAVE="2")
+    sel = ("time_domain_decimating_chain_kernel or config3_mixer_fir_decimate_fm_chain or metric_chain_fir_mixer_decimate_fused "
+           "or chain_kernels_agree_on_random or chain_shard_continues or fused_fm_chain_rates or chain_full_size_impulse_comb "
+           "or fm_chain_full_size_tone")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x", "-k", sel,
+                          "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
