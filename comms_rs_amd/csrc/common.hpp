@@ -240,6 +240,11 @@ COMMS_INTERNAL void stream_release(int32_t device, hipStream_t s);
 // follow their own stream).  A handle remembers the last stream it launched on, possibly a pooled one that its owner
 // has since released: comms_stream_pool_trim must not destroy streams while such a handle exists.
 COMMS_INTERNAL void handle_count(int32_t device, int delta);
+// Handles that currently FOLLOW a stream of the device's pool other than their own (a node thread's stream, handed to
+// run_dev): comms_stream_pool_trim refuses while there is one -- its owner may have released that stream to the pool,
+// and the handle's next drain would synchronise a destroyed stream.  pool_owns: did the pool create `s`?
+COMMS_INTERNAL void follower_count(int32_t device, int delta);
+COMMS_INTERNAL bool pool_owns(int32_t device, hipStream_t s);
 // in + out bytes from which a host-pointer call is pipelined in chunks (COMMS_HOST_PIPE_BYTES, a documented runtime limit
 // like COMMS_ZERO_COPY_BYTES; 0 = never)
 COMMS_INTERNAL size_t host_pipe_bytes();
@@ -311,9 +316,16 @@ struct Handle {
     // the state getters / setters call before touching the state from the host.
     hipStream_t last_stream = nullptr;
     bool launched = false;
+    bool follows_pooled = false;  // last_stream is a pooled stream that is not this handle's own
+    void set_following(hipStream_t s) {
+        const bool f = s != nullptr && s != stream && pool_owns(device, s);  // (looked up on a CHANGE of stream only)
+        if (f != follows_pooled) follower_count(device, f ? +1 : -1);
+        follows_pooled = f;
+    }
     comms_status_t enter(void* s_arg, hipStream_t* out) {
         hipStream_t s = pick(s_arg);
         if (launched && s != last_stream) COMMS_TRY(drain());
+        if (s != last_stream) set_following(s);
         last_stream = s;
         launched = true;
         *out = s;
@@ -331,6 +343,7 @@ struct Handle {
         launched = false;
         last_stream = nullptr;
         hipError_t e = hipStreamSynchronize(s);
+        set_following(nullptr);
         if (e != hipSuccess)
             return fail(COMMS_ERR_DEVICE, "draining the handle's previous stream: %s", hipGetErrorString(e));
         return COMMS_OK;
@@ -465,6 +478,7 @@ struct Handle {
     }
 
     void fini() {
+        set_following(nullptr);
         for (hipEvent_t e : pipe_events) (void)hipEventDestroy(e);
         pipe_events.clear();
         if (out_stream) stream_release(device, out_stream);

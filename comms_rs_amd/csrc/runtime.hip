@@ -74,6 +74,7 @@ static std::mutex g_stream_m;
 static std::vector<hipStream_t> g_free_streams[64];
 
 static std::atomic<long> g_streams_created[64];  // (what the pool has ever created: the diagnostic build reports it)
+static std::vector<hipStream_t> g_pool_streams[64];  // every stream the pool created and has not destroyed (under g_stream_m)
 comms_status_t stream_acquire(int32_t device, hipStream_t* out) {
     COMMS_ARG(device >= 0 && device < 64, "device index out of range");
     COMMS_TRY(use_device(device));
@@ -88,10 +89,25 @@ comms_status_t stream_acquire(int32_t device, hipStream_t* out) {
     }
     COMMS_HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
     g_streams_created[device].fetch_add(1);
+    {
+        std::lock_guard<std::mutex> lk(g_stream_m);
+        g_pool_streams[device].push_back(*out);
+    }
     return COMMS_OK;
 }
 
 static std::atomic<long> g_live_handles[64];
+static std::atomic<long> g_followers[64];
+void follower_count(int32_t device, int delta) {
+    if (device >= 0 && device < 64) g_followers[device].fetch_add(delta);
+}
+bool pool_owns(int32_t device, hipStream_t s) {
+    if (device < 0 || device >= 64) return false;
+    std::lock_guard<std::mutex> lk(g_stream_m);
+    for (hipStream_t q : g_pool_streams[device])
+        if (q == s) return true;
+    return false;
+}
 void handle_count(int32_t device, int delta) {
     if (device >= 0 && device < 64) g_live_handles[device].fetch_add(delta);
 }
@@ -420,13 +436,33 @@ comms_status_t comms_stream_pool_trim(int32_t device) {
         std::lock_guard<std::mutex> lp(p.m);
         COMMS_ARG(p.live_bufs.load() == 0, "%ld comms_buf objects are alive on device %d: release them first",
                   p.live_bufs.load(), device);
-        COMMS_ARG(comms::g_live_handles[device].load() == 0,
-                  "%ld node handles are alive on device %d (a handle may still follow a pooled stream): destroy them first",
-                  comms::g_live_handles[device].load(), device);
+        // (round 5: not "any live handle" -- a long-running host that retired node threads could then never trim without
+        // tearing its graph down -- but handles that FOLLOW a pooled stream other than their own: only those can be left
+        // holding a stream this call destroys.  A state getter / setter, or the handle's next launch on another stream,
+        // detaches it.)
+        COMMS_ARG(comms::g_followers[device].load() == 0,
+                  "%ld node handles on device %d still follow a pooled stream that is not their own (quiesce them -- any state "
+                  "getter does -- or destroy them first)", comms::g_followers[device].load(), device);
         streams.swap(comms::g_free_streams[device]);
         events.swap(p.free_events);
+        for (hipStream_t s : streams) {
+            auto& all = comms::g_pool_streams[device];
+            for (size_t i = 0; i < all.size(); ++i)
+                if (all[i] == s) {
+                    all[i] = all.back();
+                    all.pop_back();
+                    break;
+                }
+        }
     }
     const comms_status_t st = comms_buf_pool_trim(device);
+    {
+        // the cached blocks' use-events came back into the pool's free list while the buffer cache was emptied: they
+        // were last recorded on streams that are about to go, so they go too
+        std::lock_guard<std::mutex> lp(p.m);
+        events.insert(events.end(), p.free_events.begin(), p.free_events.end());
+        p.free_events.clear();
+    }
     if (streams.empty() && events.empty()) return st;
     COMMS_TRY(use_device(device));
     COMMS_HIP_TRY(hipDeviceSynchronize());

@@ -1669,32 +1669,68 @@ def fm_radio_taps():
 
 
 def test_fm_radio_example_chain(c):
-    # the literal example chain (examples/fm_radio.rs:144-152) with the example's own 63 taps: RTL-SDR bytes ->
-    # (x - 127.5) / 127.5 -> 63-tap FIR -> /5 -> FM demod -> (re, 0) -> 63-tap FIR -> .re -> /5
+    """The literal example chain (examples/fm_radio.rs:144-152) with the example's own 63 taps: RTL-SDR bytes ->
+    (x - 127.5) / 127.5 -> 63-tap FIR -> /5 -> FM demod -> (re, 0) -> 63-tap FIR -> .re -> /5, against the oracle, held to
+    the bounds of every other chain test (round 5; the round-4 form accepted 1e-4 sum|taps| and 2e-3 rad flat):
+      * complex stages: max|d| <= TOL sum|taps| max|x|  (north_star's 1e-5 relative);
+      * demodulated angles: circular error x min(|y[j]|, |y[j-1]|) <= 4 TOL sum|taps| -- an angle is as good as the two
+        samples it is the argument of, and a FIR error of TOL sum|taps| on each moves arg(y[j] conj y[j-1]) by that over
+        their magnitude;
+      * the audio half filters those angles: per output, sum_k |h[k]| x (the bound of the angle it multiplies) plus the
+        second filter's own TOL sum|taps| max|angle|.
+    The first n_taps // 5 + 1 decimated outputs are the zero-state start-up of the first filter (the history is zeros, |y|
+    runs through 0 there, and the angle of a sample of magnitude ~0 is arbitrary in the reference as well): they are checked
+    through the magnitude-weighted bound like the rest, but excluded from the flat 1e-4 rad check of well-conditioned angles."""
     taps = fm_radio_taps()
     n = 262125  # ~ two of the example's radio blocks (RadioRxNode::new(rtlsdr, 0, 262144): 131072 samples); a multiple of 25,
     #             since the fused chain node takes whole decimation periods
     x = fm_stream(n)
     u8 = np.clip(np.round(np.stack([x.real, x.imag], axis=1) * 127.5 + 127.5), 0, 255).astype(np.uint8)
     xin = oracle.iq_u8_to_c32(u8)
-    w = oracle.FM().demod(oracle.decimate(oracle.batch_fir(xin, taps, oracle.default_state(taps), norotate=True), 5))
+    scale = float(np.sum(np.abs(taps)))
+    skip = taps.size // 5 + 1
+    wy = oracle.decimate(oracle.batch_fir(xin, taps, oracle.default_state(taps), norotate=True), 5)
+    w = oracle.FM().demod(wy)
     w2 = oracle.decimate(oracle.batch_fir(w.astype(np.complex64), taps, oracle.default_state(taps), norotate=True).real.copy(), 5)
+    mag = np.minimum(np.abs(wy), np.abs(np.concatenate([[1.0], wy[:-1]]))).astype(np.float64)
+
+    def check_angles(got, what):
+        d = circ(got.astype(np.float64) - w)
+        worst = int(np.argmax(d * mag))
+        assert got.shape == w.shape and d[worst] * mag[worst] <= 4 * TOL * scale, \
+            "%s: output %d off by %.3e rad at |y| = %.3e" % (what, worst, d[worst], mag[worst])
+        ok = mag > 0.5
+        ok[:skip] = False
+        assert float(np.max(d[ok])) <= 1e-4, (what, float(np.max(d[ok])))
+        return 4 * TOL * scale / np.maximum(mag, 1e-30)   # per-angle bound, for the audio half
+
+    def audio_bound(angle_bound):
+        # |sum_k h[k] (a[j-k] + e[j-k]) - sum_k h[k] a[j-k]| <= sum_k |h[k]| |e[j-k]|, plus the filter's own rounding; per filter
+        # OUTPUT (before the last decimator)
+        ab = np.minimum(angle_bound, np.pi)
+        return np.convolve(ab, np.abs(taps.real).astype(np.float64))[:ab.size] + TOL * scale * np.pi
+
+    def check_audio(got, want, bound, what):
+        d = np.abs(got.astype(np.float64) - want)
+        worst = int(np.argmax(d / bound))
+        assert got.shape == want.shape and d[worst] <= bound[worst], "%s: output %d off by %.3e (bound %.3e)" % (what, worst, d[worst], bound[worst])
+
     # node by node, as the example wires them (ConvertNode = the u8 conversion, Convert2 / Convert3 = casts)
-    g = c.FMDemodNode().run(c.DecimateNode(5).run(c.BatchFirNode(taps).run(c.iq_u8_to_c32(u8))))
+    gy = c.DecimateNode(5).run(c.BatchFirNode(taps).run(c.iq_u8_to_c32(u8)))
+    assert float(np.max(np.abs(gy - wy))) <= TOL * scale
+    g = c.FMDemodNode().run(gy)
+    ab = check_angles(g, "node by node")
     g2 = c.DecimateNode(5).run(np.ascontiguousarray(c.BatchFirNode(taps).run(g.astype(np.complex64)).real))
     assert g2.shape == w2.shape == (-(-(-(-n // 5)) // 5),)  # ceil(ceil(n / 5) / 5): decimate keeps sample 0 of every block
-    scale = float(np.sum(np.abs(taps)))
-    assert np.max(np.abs(g2 - w2)) <= 1e-4 * scale
+    check_audio(g2, w2, audio_bound(ab)[::5], "node by node")
     # the front half as ONE launch reading the radio's bytes (chain kernel at rate 5, u8 load stage) ...
     front = c.ChainNode(0.0, 0.0, taps, 5, True)
     front.set_input_format("u8")
     gf = front.run(u8)
-    d = np.abs(gf.astype(np.float64) - w)
-    d = np.minimum(d, 2 * np.pi - d)
-    assert gf.shape == w.shape and float(np.median(d)) <= 1e-5 and float(np.max(d)) <= 2e-3
+    ab = check_angles(gf, "fused front")
     # ... and the audio half (real samples through the complex filter, as Convert2 / Convert3 do)
     g3 = c.DecimateNode(5).run(np.ascontiguousarray(c.BatchFirNode(taps).run(gf.astype(np.complex64)).real))
-    assert np.max(np.abs(g3 - w2)) <= 2e-3 * scale  # (the demodulated angle's last bits pass through a filter of gain ~1)
+    check_audio(g3, w2, audio_bound(ab)[::5], "fused front + audio")
     # two blocks in a row keep every state the example's nodes keep (FIR histories, FM.prev; decimation restarts per block)
     f1, fm, f2 = c.BatchFirNode(taps), c.FMDemodNode(), c.BatchFirNode(taps)
     got = []
@@ -1703,11 +1739,16 @@ def test_fm_radio_example_chain(c):
         a = fm.run(c.DecimateNode(5).run(f1.run(c.iq_u8_to_c32(blk))))
         got.append(c.DecimateNode(5).run(np.ascontiguousarray(f2.run(a.astype(np.complex64)).real)))
     o1, ofm, o2 = oracle.default_state(taps), oracle.FM(), oracle.default_state(taps)
-    want = []
+    want, wya = [], []
     for blk in (xin[:cut], xin[cut:]):
-        a = ofm.demod(oracle.decimate(oracle.batch_fir(blk, taps, o1, norotate=True), 5))
+        yb = oracle.decimate(oracle.batch_fir(blk, taps, o1, norotate=True), 5)
+        wya.append(yb)
+        a = ofm.demod(yb)
         want.append(oracle.decimate(oracle.batch_fir(a.astype(np.complex64), taps, o2, norotate=True).real.copy(), 5))
-    assert np.max(np.abs(np.concatenate(got) - np.concatenate(want))) <= 1e-4 * scale
+    assert np.array_equal(np.concatenate(wya), wy)   # (cut is a multiple of 5: the first decimator's restart is in step)
+    fb = audio_bound(4 * TOL * scale / np.maximum(mag, 1e-30))
+    m1 = cut // 5                                    # the second decimator restarts with the second block
+    check_audio(np.concatenate(got), np.concatenate(want), np.concatenate([fb[:m1][::5], fb[m1:][::5]]), "two blocks")
 
 
 # ------------------------------------------------------------------ raw IQ wire formats
@@ -1790,45 +1831,47 @@ def test_device_buf_size_classes_and_limits(c):
 
 
 def test_stream_pool_trim_success_and_refusal_with_live_handles(c):
-    """comms_stream_pool_trim destroys pooled streams: it must refuse while a node handle is alive (the handle may
-    still follow a pooled stream that its owner released -- get_state / destroy would then synchronise a destroyed
-    stream) and succeed once handles and buffers are gone; the library works on afterwards."""
+    """comms_stream_pool_trim destroys the pool's idle streams.  It must refuse while a node handle still FOLLOWS a pooled
+    stream that is not its own (its owner may have released that stream; the handle's next drain would synchronise a
+    destroyed stream), and succeed as soon as that handle has been quiesced -- with node handles ALIVE (round 5: a
+    long-running host that retired node threads trims without tearing its graph down; the success path no longer depends on
+    what else the test process holds).  The library works on afterwards, old handles included."""
     import ctypes as C
-    import gc
 
     import torch
     from comms_rs_amd._lib import check, lib
 
-    gc.collect()
     n = 1 << 16
     x = torch.empty(n, dtype=torch.complex64, device="cuda:0")
     y = torch.empty_like(x)
     c.synth_iq_dev(x.data_ptr(), n, 0, 3)
+    taps = lowpass_taps(63, 0.1)
+    bystander = c.BatchFirNode(taps)                                  # a live handle that only ever used its own stream
+    first = bystander.run(c.synth_iq(4096, 0, 3))
     streams = []
     for _ in range(4):
         sp = C.c_void_p()
         check(lib().comms_stream_create(0, C.byref(sp)))
         streams.append(sp)
-    fir = c.BatchFirNode(lowpass_taps(63, 0.1))
+    fir = c.BatchFirNode(taps)
     fir.run_dev(x.data_ptr(), n, y.data_ptr(), streams[0].value)     # the handle now follows a pooled stream ...
     for sp in streams:
         check(lib().comms_stream_destroy(0, sp))                      # ... which goes back to the pool
     with pytest.raises(c.CommsError) as e:
         check(lib().comms_stream_pool_trim(0))
     assert e.value.code == c.COMMS_ERR_ARG and "handles" in str(e.value)
-    st = fir.state(63)                                                # drains the released (still existing) stream
+    st = fir.state(63)                                                # quiesce: drains the released (still existing) stream
     assert st.shape == (63,)
-    del fir
-    gc.collect()
-    alive = [o for o in gc.get_objects() if type(o).__module__ == "comms_rs_amd.nodes" and getattr(o, "_h", None)]
-    if alive:
-        pytest.skip("other node handles of this process are alive: %d" % len(alive))
-    check(lib().comms_stream_pool_trim(0))                            # the success path
+    check(lib().comms_stream_pool_trim(0))                            # the success path, both handles alive
     check(lib().comms_stream_pool_trim(0))                            # idempotent on an empty pool
-    fir2 = c.BatchFirNode(lowpass_taps(63, 0.1))                      # new streams are created on demand
+    fir.run_dev(x.data_ptr(), n, y.data_ptr(), 0)                     # the quiesced handle goes on (legacy stream here)
+    torch.cuda.synchronize()
+    assert np.array_equal(bystander.run(c.synth_iq(4096, 4096, 3)).shape, first.shape)
+    fir2 = c.BatchFirNode(taps)                                       # new streams are created on demand
     got = fir2.run(c.synth_iq(4096, 0, 3))
-    want = oracle.batch_fir(c.synth_iq(4096, 0, 3), lowpass_taps(63, 0.1), oracle.default_state(lowpass_taps(63, 0.1)), norotate=True)
-    assert np.max(np.abs(got - want)) <= TOL * np.sum(np.abs(lowpass_taps(63, 0.1)))
+    want = oracle.batch_fir(c.synth_iq(4096, 0, 3), taps, oracle.default_state(taps), norotate=True)
+    assert np.max(np.abs(got - want)) <= TOL * np.sum(np.abs(taps))
+    assert np.array_equal(got, first)
 
 
 def test_handles_create_destroy_many_times(c):
@@ -1856,7 +1899,15 @@ def test_handles_create_destroy_many_times(c):
         cycle(i)
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
-    assert free0 - free1 < (16 << 20), (free0, free1)
+    for i in range(300):
+        cycle(i)
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info()
+    # A leak costs every window the same.  (Run on its own -- nothing before it in the process -- the FIRST window also sees the
+    # runtime's heaps grow once more, 25 MB on one box, with nine handles alive at a time; one node type at a time loses nothing in
+    # 300 cycles: scripts/probe_leak.py.  The second window is the measurement, the first only bounded.)
+    assert free1 - free2 < (4 << 20), (free0, free1, free2)
+    assert free0 - free1 < (64 << 20), (free0, free1, free2)
     assert np.allclose(c.MixerNode(0.0).run(x), x)
 
 

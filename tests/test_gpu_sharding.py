@@ -7,6 +7,7 @@ share the one GPU of the box (the N>1 logic of bench.py with the real kernels). 
 Reference behaviour being preserved: state persists across `run` calls -- src/filter/fir_node.rs:193-220,
 src/mixer.rs:79-82, src/modulation/analog.rs:9,31,43-47; SURVEY.md section 8e for the partitioning.
 """
+import json
 import os
 import subprocess
 import sys
@@ -323,3 +324,21 @@ def test_two_ranks_share_the_gpu_gloo_product_nodes(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r))) for r in range(2)]
     rcs = [p.wait(timeout=600) for p in procs]
     assert rcs == [0, 0], rcs
+
+
+def test_bench_dry_comm_two_ranks():
+    """`bench.py --gpus 2 --dry-comm`: the rendezvous, one halo hand-over at every config's message size, the collectives
+    of the timed loop -- here with gloo and both ranks on the box's one GPU (the nccl form is the driver's first
+    multi-GPU step; with one GPU only its one-rank form can run: second call)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-comm"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["dry_comm"] and line["world_size_seen"] == 2 and line["over_ranks"] == [0.0, 1.0] and line["max_over_ranks"] == 1.0
+    assert line["halos"]["config2_fir_halo"]["bytes_per_neighbour_pair"] == 255 * 8
+    assert line["halos"]["config3_chain_prefix"]["bytes_per_neighbour_pair"] == 136 * 8
+    assert line["halos"]["config5_fir_halo"]["bytes_per_neighbour_pair"] == 4097 * 8
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-comm"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert one.returncode == 0 and json.loads(one.stdout.strip().splitlines()[-1])["world_size_seen"] == 1

@@ -3,6 +3,8 @@ examples/fm_radio.rs:82-90, examples/single_thread_bpsk.rs:43): a node told that
 converts in its load stage.  The conversion must be iqformat.hip's (= the oracle's) bit for bit, so
 "node on raw input" == "node on converted input" exactly, and == the oracle chain within the node's own
 tolerance.  Run with -m gpu."""
+import os
+
 import numpy as np
 import pytest
 
@@ -181,3 +183,20 @@ def test_transmit_chain_writes_the_i16_wire_format(c, n_taps, sps, mix):
     assert np.mean(np.isin(sat, [-32768, 32767, 0])) > 0.9   # (a few outputs of the long filters are ~1e-9: not saturated)
     a.set_output_format("c32")
     assert a.run(sym[:16]).dtype == np.complex64
+
+
+def test_raw_iq_i16_reference_vector_bit_exact(c):
+    """The byte stream of the reference's own raw-IQ tests (src/io/raw_iq.rs:239-300: Complex<i16>(2i, 2i+1), i = 0..99,
+    native-endian; tests/golden/reference_kats.json "raw_iq_i16"): comms_iq_i16_to_c32 yields exactly those samples, the FIR
+    node's i16 load stage reads them as such, and comms_iq_c32_to_i16 writes the same bytes back."""
+    import json
+
+    k = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kats.json")))["raw_iq_i16"]
+    raw = np.ascontiguousarray(np.frombuffer(bytes.fromhex(k["bytes_hex_le"]), "<i2").reshape(-1, 2)).astype(np.int16)
+    want = np.array([complex(a, b) for a, b in k["expected"]], np.complex64)
+    got = c.iq_i16_to_c32(raw)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(got.view(np.uint32), oracle.iq_i16_to_c32(raw).view(np.uint32))
+    assert np.array_equal(c.iq_c32_to_i16(got, 1.0), raw)
+    one = c.BatchFirNode(np.array([1 + 0j], np.complex64)).set_algo(c.FIR_DIRECT).set_input_format("i16", 1.0).run(raw)
+    assert np.array_equal(one.view(np.uint32), want.view(np.uint32))

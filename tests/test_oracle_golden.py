@@ -214,13 +214,26 @@ def test_prbs7_golden(kats):
     bits, _ = oracle.prns_u8(k["poly_mask"], k["state"], 128)
     assert bits.tolist() == k["expected"]
     assert oracle.prns_u8(0xC0, 0xFF, 1)[0][0] == 1
-    # maximal-length PRBS8 (prns.rs:146-188): period 255 with mask 0xB8
-    seen, st = set(), 1
-    for _ in range(255):
+    # maximal-length PRBS8 (prns.rs:146-189, golden "prns8"): 255 distinct states, then the first again
+    k8 = kats["prns8"]
+    seen, st = set(), k8["state"]
+    for _ in range(k8["distinct_states"]):
         assert st not in seen
         seen.add(st)
-        _, st = oracle.prns_u8(0xB8, st, 1)
-    assert st == 1
+        _, st = oracle.prns_u8(k8["poly_mask"], st, 1)
+    assert st == k8["state"] and len(seen) == 255
+
+
+def test_raw_iq_i16_golden(kats):
+    # src/io/raw_iq.rs:239-300: the byte stream the reference's IQInput tests read, and what its samples are; the
+    # Complex<f32> the hot path then sees is cast_complex of them (util/math.rs:20-28), exactly
+    k = kats["raw_iq_i16"]
+    raw = np.frombuffer(bytes.fromhex(k["bytes_hex_le"]), "<i2").reshape(-1, 2)
+    assert raw.shape == (k["n"], 2) and raw.tolist() == k["expected"]
+    got = oracle.iq_i16_to_c32(np.ascontiguousarray(raw).astype(np.int16))
+    want = np.array([complex(a, b) for a, b in k["expected"]], np.complex64)
+    assert np.array_equal(got, want)
+    assert np.array_equal(oracle.iq_c32_to_i16(got, 1.0), raw)   # and back: what IQOutput would write (raw_iq.rs:303-372)
 
 
 def test_iq_wire_formats():
