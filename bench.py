@@ -1133,6 +1133,21 @@ def run_config4(ctx):
     if rank != 0:
         return None
     ach = FFT_BYTES_PER_POINT * n / (kernel_ms * 1e-3) / 1e9
+    # the two-pass ceiling, measured in this run: a 2^20-point transform does not fit a workgroup, so every point crosses
+    # HBM twice each way; the plain copy of one launch group's footprint (what ONE pass would cost if it did nothing else)
+    grp = min(n, (2048 << 20) // 8)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    for a, b in ev:
+        a.record()
+        y[:grp].copy_(x[:grp])
+        b.record()
+    torch.cuda.synchronize()
+    copy_ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+    copy_gbs = 16.0 * grp / (copy_ms * 1e-3) / 1e9
+    ceiling = {"passes": 2, "copy_GBps": round(copy_gbs, 1), "copy_points": grp,
+               "frac_at_copy_rate": round(copy_gbs / 2 / HBM_PEAK_GBS, 4),
+               "note": "a plain device copy of %d points (16 B/point), timed here; two passes at that rate = the most this "
+                       "two-pass transform can show against the 16 B/point roofline" % grp}
     res = {"metric": "Mpoints/s Complex<f32> through the 2^20-point FFT node, batch 4096 (BASELINE config 4)",
            "value": round(float(batch_total) * FFT_N * args.steps / elapsed / 1e6, 1), "unit": "Mpoints/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -1144,7 +1159,7 @@ def run_config4(ctx):
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                         "traffic": pmc_traffic("fft1024x16_kernel", n), "kernel_ms": round(kernel_ms, 5),
                         "launches_timed": int(kms.size), "timer_stride": 1, **in_stream_fields(sms),
-                        "algorithmic_bytes_per_launch": FFT_BYTES_PER_POINT * n}}
+                        "algorithmic_bytes_per_launch": FFT_BYTES_PER_POINT * n, "ceiling": ceiling}}
     res["world_size_seen"], res["ranks"] = ranks["world_size_seen"], ranks
     if transfer:
         res["transfer"] = transfer

@@ -231,6 +231,14 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void fft1024x16_kernel(c
 
     // A tile's 16 elements per lane: global element u of this lane and where it goes in LDS.
     constexpr int LOG = NW == 16 ? 4 : 3;
+    // Column tiles (in_c_fast): which (column, row) of the tile a thread loads and puts into LDS.  A wave-instruction
+    // covers four rows x sixteen adjacent columns either way (whole 128-byte pieces); WITHIN it, sixteen consecutive
+    // lanes used to hold the sixteen columns of one row -- sixteen ds_write_b64 to buffers 2180 dwords apart, banks
+    // 4 c mod 32: columns c and c + 8 on the same pair of banks, two-way conflicts on every tile-in write (pass 1 of the
+    // two-pass sizes: 18 % of its LDS cycles were conflict cycles against 10 % in pass 2, profiles/r04_pmc_config4.txt).
+    // Now a group of sixteen lanes holds eight columns x two rows: banks 4 c + 2 r, all thirty-two pairs distinct.
+    const int lc = NW == 16 ? ((l & 7) | ((l >> 1) & 8)) : (tid & (NW - 1));
+    const int lr = NW == 16 ? (4 * wave + (((l >> 3) & 1) | ((l >> 4) & 2))) : (tid >> LOG);
     auto tile_src = [&](size_t tix) {
         const size_t b = tix / p.tiles_per_xform;
         return in + b * p.N + (tix - b * p.tiles_per_xform) * p.tile_step_in;
@@ -239,8 +247,8 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void fft1024x16_kernel(c
     // SGPRs + one 32-bit VGPR offset per load keeps the 16 in-flight loads cheap in registers
     const unsigned in_cs = static_cast<unsigned>(p.in_cs), in_ls = static_cast<unsigned>(p.in_ls);
     auto fetch = [&](const cf* src, cf (&r)[16]) {
-        if (p.in_c_fast) {  // lane holds (c = tid % NW, rows tid / NW + 64u)
-            const unsigned o0 = (tid & (NW - 1)) * in_cs + (tid >> LOG) * in_ls, step = 64u * in_ls;
+        if (p.in_c_fast) {  // lane holds (column lc, rows lr + 64u)
+            const unsigned o0 = lc * in_cs + lr * in_ls, step = 64u * in_ls;
 #pragma unroll
             for (int u = 0; u < 16; ++u) r[u] = src[o0 + u * step];
         } else if (NW == 16) {  // element i = tid + 1024u -> (c = u, r = tid)
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void fft1024x16_kernel(c
         }
         if (!PREFETCH) fetch(tile_src(tix), pre);
         if (p.in_c_fast) {
-            cf* d = bufs + (tid & (NW - 1)) * FW_BUF + (tid >> LOG);
+            cf* d = bufs + lc * FW_BUF + lr;
 #pragma unroll
             for (int u = 0; u < 16; ++u) d[u * 64] = pre[u];
         } else {
