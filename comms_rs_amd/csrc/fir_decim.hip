@@ -1017,11 +1017,14 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
     // spread evenly over the waves of the chip (every wave runs ONE contiguous run: the launch lasts as long as its
     // longest run, so a batch of 4.3 tiles per wave would pay for 5)
     static const int wave_knob = diag_knob("COMMS_DECIM_WAVE", COMMS_DECIM_WAVE_DEFAULT);
-    if (wave_knob && R == 8 && h->in_fmt == COMMS_IQ_C32 && opl == 2 && tile == DC_TILE &&
+    // Up to 129 taps (two halo rows).  Longer filters stay on the workgroup kernel: with four halo rows a wave's LDS image is
+    // 10.4 KB, fifteen waves per CU instead of sixteen, and the 255-tap chain then runs 164 -> 187 us at 2^26 samples and
+    // 42.9 -> 48.8 us at 2^24 (scripts/ab_chain.py, CASES=c2,c2c,c2b with COMMS_DECIM_WAVE=2; NOTES.md round 5).
+    if (wave_knob && R == 8 && h->in_fmt == COMMS_IQ_C32 && opl == 2 && tile == DC_TILE && a.hlq * PR <= 128 &&
         (reinterpret_cast<uintptr_t>(d_out) & 15) == 0) {  // (its stores are 8 / 16 bytes per lane)
-        const int HR = a.hlq * PR <= 128 ? 2 : 4;
+        constexpr int HR = 2;
         const long long tiles = static_cast<long long>((a.n_out + 127) / 128);
-        const long long waves = (HR == 2 ? 16 : 15) * static_cast<long long>(kNumCU);  // single-wave workgroups: 10240 / 10368 B of LDS each
+        const long long waves = 16 * static_cast<long long>(kNumCU);  // single-wave workgroups, 10240 B of LDS each
         const long long nt = (tiles + waves - 1) / waves;
         const bool balanced = tiles >= waves && nt * waves * 100 <= tiles * 104;
         if (balanced || wave_knob == 2) {
@@ -1051,10 +1054,7 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
 #else
 #define COMMS_DW(REAL_, PRE_, HR_) (nt_loads ? launch_decim_wave_v<8, REAL_, PRE_, HR_, 1, 6>(a, s) : launch_decim_wave_v<8, REAL_, PRE_, HR_, 1, 0>(a, s))
 #endif
-            if (HR == 2)
-                st = real ? (pre ? COMMS_DW(true, true, 2) : COMMS_DW(true, false, 2)) : (pre ? COMMS_DW(false, true, 2) : COMMS_DW(false, false, 2));
-            else
-                st = real ? (pre ? COMMS_DW(true, true, 4) : COMMS_DW(true, false, 4)) : (pre ? COMMS_DW(false, true, 4) : COMMS_DW(false, false, 4));
+            st = real ? (pre ? COMMS_DW(true, true, 2) : COMMS_DW(true, false, 2)) : (pre ? COMMS_DW(false, true, 2) : COMMS_DW(false, false, 2));
 #undef COMMS_DW
             COMMS_TRY(st);
             h->cur ^= 1;

@@ -23,7 +23,8 @@ for p in paths:
     libs.append(C.CDLL(os.path.abspath(p.split(":")[0])))
 s = torch.cuda.current_stream().cuda_stream
 cases = {"c3": (26, lpf(127, 1 / 16.0), 8, 1 | 16), "c2": (24, np.ascontiguousarray(c.rrc_taps(255, 8.0, 0.35)), 8, 2 | 16),
-         "r5": (26, lpf(63, 1 / 10.0), 5, 1 | 16), "c3n": (26, lpf(127, 1 / 16.0), 8, 16)}
+         "r5": (26, lpf(63, 1 / 10.0), 5, 1 | 16), "c3n": (26, lpf(127, 1 / 16.0), 8, 16),
+         "c2b": (26, np.ascontiguousarray(c.rrc_taps(255, 8.0, 0.35)), 8, 2 | 16), "c2c": (25, np.ascontiguousarray(c.rrc_taps(255, 8.0, 0.35)), 8, 2 | 16)}
 for name in os.environ.get("CASES", "c3,c2").split(","):
     logn, taps, rate, flags = cases[name]
     n = 1 << logn
