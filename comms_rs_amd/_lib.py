@@ -90,6 +90,16 @@ _PROTOS = {
     "comms_fir_i16_run_dev": [_vp, _vp, _sz, _vp, _vp],
     "comms_fir_i16_get_state": [_vp, _vp, _sz],
     "comms_fir_i16_destroy": [_vp],
+    "comms_fir_f64_create": [_vp, _sz, _vp, _sz, _i32, _pp],
+    "comms_fir_f64_run": [_vp, _vp, _sz, _vp],
+    "comms_fir_f64_run_dev": [_vp, _vp, _sz, _vp, _vp],
+    "comms_fir_f64_get_state": [_vp, _vp, _sz],
+    "comms_fir_f64_set_state": [_vp, _vp, _sz],
+    "comms_fir_f64_destroy": [_vp],
+    "comms_pulse_f64_create": [_vp, _sz, _sz, _i32, _pp],
+    "comms_pulse_f64_run": [_vp, _vp, _sz, _vp],
+    "comms_pulse_f64_run_dev": [_vp, _vp, _sz, _vp, _vp],
+    "comms_pulse_f64_destroy": [_vp],
     "comms_pulse_i16_create": [_vp, _sz, _sz, _i32, _pp],
     "comms_pulse_i16_run": [_vp, _vp, _sz, _vp],
     "comms_pulse_i16_run_dev": [_vp, _vp, _sz, _vp, _vp],

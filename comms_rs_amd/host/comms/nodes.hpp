@@ -248,6 +248,97 @@ private:
     size_t sps_;
 };
 
+// ---------------------------------------------------------------- Complex<f64> instantiations
+// FirNode<f64> / BatchFirNode<f64> / PulseNode<f64>: the reference's own doc example of batch_fir (fir.rs:68-86) and its timing
+// estimator (timing_estimator.rs:102-103) run on Complex<f64>; the reference's arithmetic operation for operation, outputs
+// bit-identical to it (comms_fir_f64_*, round 5).
+
+class BatchFirNodeF64 : public DeriveNode<BatchFirNodeF64> {
+public:
+    NodeReceiver<std::vector<Complex64>> input;
+    NodeSender<std::vector<Complex64>> output;
+    BatchFirNodeF64(const std::vector<Complex64>& taps, const std::optional<std::vector<Complex64>>& state = std::nullopt,
+                    int device = 0) {
+        throw_on(comms_fir_f64_create(c64(taps.data()), taps.size(), state ? c64(state->data()) : nullptr,
+                                      state ? state->size() : 0, device, &h_),
+                 "BatchFirNode<f64>::new");
+    }
+    BatchFirNodeF64(BatchFirNodeF64&& o) noexcept : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_) { o.h_ = nullptr; }
+    ~BatchFirNodeF64() { comms_fir_f64_destroy(h_); }
+    Result<std::vector<Complex64>> run(const std::vector<Complex64>& in) {
+        std::vector<Complex64> out(in.size());
+        comms_status_t st = comms_fir_f64_run(h_, c64(in.data()), in.size(), c64(out.data()));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_fir_f64_t* h_ = nullptr;
+};
+
+class FirNodeF64 : public DeriveNode<FirNodeF64> {
+public:
+    NodeReceiver<Complex64> input;
+    NodeSender<Complex64> output;
+    FirNodeF64(const std::vector<Complex64>& taps, const std::optional<std::vector<Complex64>>& state = std::nullopt, int device = 0) {
+        throw_on(comms_fir_f64_create(c64(taps.data()), taps.size(), state ? c64(state->data()) : nullptr,
+                                      state ? state->size() : 0, device, &h_),
+                 "FirNode<f64>::new");
+    }
+    FirNodeF64(FirNodeF64&& o) noexcept : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_) { o.h_ = nullptr; }
+    ~FirNodeF64() { comms_fir_f64_destroy(h_); }
+    Result<Complex64> run(const Complex64& in) {
+        Complex64 out;
+        comms_status_t st = comms_fir_f64_run(h_, c64(&in), 1, c64(&out));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    Result<std::vector<Complex64>> run_block(const std::vector<Complex64>& ins) {  // queued samples in one launch
+        std::vector<Complex64> out(ins.size());
+        comms_status_t st = comms_fir_f64_run(h_, c64(ins.data()), ins.size(), c64(out.data()));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_fir_f64_t* h_ = nullptr;
+};
+
+class PulseNodeF64 : public DeriveNode<PulseNodeF64> {
+public:
+    NodeReceiver<Complex64> input;
+    NodeSender<std::vector<Complex64>> output;
+    PulseNodeF64(const std::vector<Complex64>& taps, size_t sam_per_sym, int device = 0) : sps_(sam_per_sym) {
+        throw_on(comms_pulse_f64_create(c64(taps.data()), taps.size(), sam_per_sym, device, &h_), "PulseNode<f64>::new");
+    }
+    PulseNodeF64(PulseNodeF64&& o) noexcept : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_), sps_(o.sps_) { o.h_ = nullptr; }
+    ~PulseNodeF64() { comms_pulse_f64_destroy(h_); }
+    Result<std::vector<Complex64>> run(const Complex64& sym) {
+        std::vector<Complex64> out(sps_);
+        comms_status_t st = comms_pulse_f64_run(h_, c64(&sym), 1, c64(out.data()));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    Result<std::vector<std::vector<Complex64>>> run_block(const std::vector<Complex64>& syms) {
+        std::vector<Complex64> flat(syms.size() * sps_);
+        comms_status_t st = comms_pulse_f64_run(h_, c64(syms.data()), syms.size(), c64(flat.data()));
+        if (st != COMMS_OK) return to_node_error(st);
+        std::vector<std::vector<Complex64>> out(syms.size());
+        for (size_t i = 0; i < syms.size(); ++i) out[i].assign(flat.begin() + i * sps_, flat.begin() + (i + 1) * sps_);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_pulse_f64_t* h_ = nullptr;
+    size_t sps_;
+};
+
 // ---------------------------------------------------------------- pulse shaping
 class PulseNode : public DeriveNode<PulseNode> {
 public:

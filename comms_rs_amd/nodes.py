@@ -255,6 +255,64 @@ class BatchFirNodeI16(_Handle):
 FirNodeI16 = BatchFirNodeI16
 
 
+class BatchFirNodeF64(_Handle):
+    """BatchFirNode<f64>::new(taps, state) / run (fir_node.rs:193-220) on Complex<f64> = numpy complex128: the reference's
+    arithmetic operation for operation, bit-identical outputs (comms_fir_f64_*).  A scalar in gives a scalar out: FirNode<f64>."""
+    _destroy = "comms_fir_f64_destroy"
+
+    def __init__(self, taps, state=None, device=0):
+        super().__init__()
+        taps = np.ascontiguousarray(taps, dtype=np.complex128).ravel()
+        if state is None:
+            check(lib().comms_fir_f64_create(_ptr(taps), taps.size, None, 0, device, C.byref(self._h)))
+        else:
+            state = np.ascontiguousarray(state, dtype=np.complex128).ravel()
+            check(lib().comms_fir_f64_create(_ptr(taps), taps.size, _ptr(state), state.size, device, C.byref(self._h)))
+
+    def run(self, x):
+        scalar = np.ndim(x) == 0
+        x = np.ascontiguousarray(np.atleast_1d(x), dtype=np.complex128)
+        out = np.empty_like(x)
+        check(lib().comms_fir_f64_run(self._h, _ptr(x), x.size, _ptr(out)))
+        return out[0] if scalar else out
+
+    def run_dev(self, in_ptr, n, out_ptr, stream=0):
+        check(lib().comms_fir_f64_run_dev(self._h, in_ptr, n, out_ptr, stream))
+
+    def state(self, n_state):
+        st = np.empty(int(n_state), np.complex128)
+        check(lib().comms_fir_f64_get_state(self._h, _ptr(st), int(n_state)))
+        return st
+
+    def set_state(self, state):
+        st = np.ascontiguousarray(state, dtype=np.complex128).ravel()
+        check(lib().comms_fir_f64_set_state(self._h, _ptr(st), st.size))
+        return self
+
+
+FirNodeF64 = BatchFirNodeF64
+
+
+class PulseNodeF64(_Handle):
+    """PulseNode<f64>::new(taps, sam_per_sym) / run (pulse.rs:71-92) on Complex<f64>, bit-identical to the reference."""
+    _destroy = "comms_pulse_f64_destroy"
+
+    def __init__(self, taps, sam_per_sym, device=0):
+        super().__init__()
+        taps = np.ascontiguousarray(taps, dtype=np.complex128).ravel()
+        self.sam_per_sym = int(sam_per_sym)
+        check(lib().comms_pulse_f64_create(_ptr(taps), taps.size, self.sam_per_sym, device, C.byref(self._h)))
+
+    def run(self, sym):
+        s = np.ascontiguousarray(np.atleast_1d(sym), dtype=np.complex128)
+        out = np.empty(s.size * self.sam_per_sym, np.complex128)
+        check(lib().comms_pulse_f64_run(self._h, _ptr(s), s.size, _ptr(out)))
+        return out
+
+    def run_dev(self, sym_ptr, n_sym, out_ptr, stream=0):
+        check(lib().comms_pulse_f64_run_dev(self._h, sym_ptr, n_sym, out_ptr, stream))
+
+
 class PulseNodeI16(_Handle):
     """PulseNode<i16>::new(taps, sam_per_sym) / run (pulse.rs:71-92) on Complex<i16>."""
     _destroy = "comms_pulse_i16_destroy"

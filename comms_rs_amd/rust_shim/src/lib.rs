@@ -22,7 +22,7 @@
 //!
 //! | node | reference | `T` here |
 //! |---|---|---|
-//! | `FirNode<T>`, `BatchFirNode<T>`, `PulseNode<T>` | fir_node.rs:45,148; pulse.rs:38 | `f32`, `i16` (`FirSample`) |
+//! | `FirNode<T>`, `BatchFirNode<T>`, `PulseNode<T>` | fir_node.rs:45,148; pulse.rs:38 | `f32`, `f64`, `i16` (`FirSample`) |
 //! | `MixerNode<T>` | mixer.rs:93 | `f32`, `f64` (`MixerSample`) |
 //! | `FFTBatchNode<T>`, `FFTSampleNode<T>`, `FMDemodNode<T>` | fft_node.rs:28,104; analog_node.rs:20 | `f32` (`FloatSample`) |
 //! | `DecimateNode<T>`, `UpsampleNode<T>` | resample_node.rs:10,74 | any `Copy + Send` type of 1, 2, 4, 8 or 16 bytes |
@@ -48,8 +48,9 @@ mod sealed {
     impl Sealed for i16 {}
 }
 
-/// Sample types the FIR and pulse-shaping kernels are built for: `f32` (every BASELINE config) and
-/// `i16` (the type of the reference's own FIR / pulse goldens; wrapping arithmetic as in a release build).
+/// Sample types the FIR and pulse-shaping kernels are built for: `f32` (every BASELINE config), `f64` (the type of the
+/// reference's batch_fir doc example and timing estimator; bit-identical outputs) and `i16` (the type of the reference's own
+/// FIR / pulse goldens; wrapping arithmetic as in a release build).
 pub trait FirSample: sealed::Sealed + Num + Copy + Send + 'static {
     #[doc(hidden)] type Fir;
     #[doc(hidden)] type Pulse;
@@ -88,6 +89,21 @@ impl FirSample for i16 {
     }
     unsafe fn pulse_run(h: *mut comms_pulse_i16_t, s: *const Complex<i16>, n: usize, y: *mut Complex<i16>) -> comms_status_t { comms_pulse_i16_run(h, s, n, y) }
     unsafe fn pulse_destroy(h: *mut comms_pulse_i16_t) { comms_pulse_i16_destroy(h); }
+}
+
+impl FirSample for f64 {  // round 5: the reference's arithmetic operation for operation, bit-identical outputs (comms_fir_f64_*)
+    type Fir = comms_fir_f64_t;
+    type Pulse = comms_pulse_f64_t;
+    unsafe fn fir_create(t: *const Complex<f64>, n: usize, s: *const Complex<f64>, ns: usize, out: *mut *mut comms_fir_f64_t) -> comms_status_t {
+        comms_fir_f64_create(t, n, s, ns, 0, out)
+    }
+    unsafe fn fir_run(h: *mut comms_fir_f64_t, x: *const Complex<f64>, n: usize, y: *mut Complex<f64>) -> comms_status_t { comms_fir_f64_run(h, x, n, y) }
+    unsafe fn fir_destroy(h: *mut comms_fir_f64_t) { comms_fir_f64_destroy(h); }
+    unsafe fn pulse_create(t: *const Complex<f64>, n: usize, sps: usize, out: *mut *mut comms_pulse_f64_t) -> comms_status_t {
+        comms_pulse_f64_create(t, n, sps, 0, out)
+    }
+    unsafe fn pulse_run(h: *mut comms_pulse_f64_t, s: *const Complex<f64>, n: usize, y: *mut Complex<f64>) -> comms_status_t { comms_pulse_f64_run(h, s, n, y) }
+    unsafe fn pulse_destroy(h: *mut comms_pulse_f64_t) { comms_pulse_f64_destroy(h); }
 }
 
 /// Sample types of `MixerNode<T>`: `f32`, and `f64` -- the instantiation the reference's own mixer tests use

@@ -291,6 +291,18 @@ void orc_pulse_f32(const float* sym, size_t n_sym, const float* taps, size_t n_t
             *o++ = fir_step(Cx<float>{0, 0}, t, n_taps, st, n_taps);
     }
 }
+void orc_pulse_f64(const double* sym, size_t n_sym, const double* taps, size_t n_taps,
+                   size_t sam_per_sym, double* state, double* out) {
+    const Cx<double>* s = reinterpret_cast<const Cx<double>*>(sym);
+    const Cx<double>* t = reinterpret_cast<const Cx<double>*>(taps);
+    Cx<double>* st = reinterpret_cast<Cx<double>*>(state);
+    Cx<double>* o = reinterpret_cast<Cx<double>*>(out);
+    for (size_t i = 0; i < n_sym; ++i) {
+        *o++ = fir_step(s[i], t, n_taps, st, n_taps);
+        for (size_t j = 0; j + 1 < sam_per_sym; ++j)
+            *o++ = fir_step(Cx<double>{0, 0}, t, n_taps, st, n_taps);
+    }
+}
 void orc_pulse_i16(const int16_t* sym, size_t n_sym, const int16_t* taps, size_t n_taps,
                    size_t sam_per_sym, int16_t* state, int16_t* out) {
     const Cx<int16_t>* s = reinterpret_cast<const Cx<int16_t>*>(sym);

@@ -106,6 +106,9 @@ def pulse(sym, taps, sam_per_sym, state):
     if taps.dtype == np.int16:
         out = np.zeros((n * sam_per_sym, 2), np.int16)
         f = lib().orc_pulse_i16
+    elif taps.dtype == np.complex128:
+        out = np.zeros(n * sam_per_sym, np.complex128)
+        f = lib().orc_pulse_f64
     else:
         assert taps.dtype == np.complex64
         out = np.zeros(n * sam_per_sym, np.complex64)

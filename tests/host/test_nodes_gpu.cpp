@@ -112,6 +112,36 @@ static void test_integer_nodes() {
     CHECK(r.is_ok() && r.value()[0] == I(static_cast<int16_t>(90000 & 0xffff), 0));
 }
 
+static void test_f64_nodes() {
+    // the same two reference tests on Complex<f64> (the type of the reference's batch_fir doc example, fir.rs:68-86): the
+    // goldens are small integers, which f64 holds exactly, and the f64 kernel does the reference's arithmetic operation for
+    // operation -- equality, not a tolerance
+    using D = Complex64;
+    std::vector<D> in, taps, want;
+    for (auto& v : kFirIn) in.emplace_back(v.real(), v.imag());
+    for (auto& v : kFirTaps) taps.emplace_back(v.real(), v.imag());
+    for (auto& v : kFirOut) want.emplace_back(v.real(), v.imag());
+    Collect<D> chk;
+    pump(Replay<D>(in), FirNodeF64(taps), chk);
+    CHECK(chk.got.size() == 10);
+    for (size_t i = 0; i < want.size() && i < chk.got.size(); ++i) CHECK(chk.got[i] == want[i]);
+    Collect<std::vector<D>> chkb;
+    pump(Replay<std::vector<D>>({std::vector<D>(in.begin(), in.begin() + 5), std::vector<D>(in.begin() + 5, in.end())}),
+         BatchFirNodeF64(taps), chkb);
+    std::vector<D> flat;
+    for (auto& b : chkb.got) flat.insert(flat.end(), b.begin(), b.end());
+    CHECK(flat.size() == 10);
+    for (size_t i = 0; i < want.size() && i < flat.size(); ++i) CHECK(flat[i] == want[i]);
+    const std::vector<D> sym = {{-1, -1}, {1, -1}, {1, -1}, {1, 1}, {-1, 1}};
+    Collect<std::vector<D>> chk2;
+    pump(Replay<D>(sym), PulseNodeF64(std::vector<D>(4, D(1, 0)), 4), chk2);
+    CHECK(chk2.got.size() == 5);
+    for (size_t i = 0; i < chk2.got.size(); ++i) {
+        CHECK(chk2.got[i].size() == 4);
+        for (auto& v : chk2.got[i]) CHECK(v == sym[i]);
+    }
+}
+
 static void test_fft_nodes() {
     std::vector<C> in, want = {{5.5f, 5.5f},           {-2.03884f, 1.03884f}, {-1.18819f, 0.18819f},
                                {-0.86327f, -0.13673f}, {-0.66246f, -0.33754f}, {-0.5f, -0.5f},
@@ -757,6 +787,7 @@ int main() {
     }
     test_fir_nodes();
     test_integer_nodes();
+    test_f64_nodes();
     test_fft_nodes();
     test_mixer_nodes();
     test_pulse_node();
