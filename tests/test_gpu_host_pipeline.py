@@ -96,3 +96,21 @@ def test_pipelined_host_call_carries_state_in_and_out():
     assert np.array_equal(a.state(63).view(np.uint8), b.state(63).view(np.uint8))
     tail = x[:4096]
     assert np.array_equal(a.run(tail).view(np.uint8), b.run(tail).view(np.uint8))
+
+
+def test_pipelined_host_calls_from_several_node_threads_at_once():
+    """comms-rs runs one OS thread per node (src/node/mod.rs:276-284): four threads, each with its own FIR node, make
+    pipelined host calls at the same time (every call brings its own helper thread and second stream); each gets exactly
+    the samples a lone call gets."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import comms_rs_amd as c
+
+    taps = [_lpf(31 + 8 * i, 0.1) for i in range(4)]
+    xs = [c.synth_iq((5 << 20) + 1000 * i, 0, 50 + i) for i in range(4)]
+    want = [c.BatchFirNode(t).set_algo(c.FIR_DIRECT).run(x) for t, x in zip(taps, xs)]
+    nodes = [c.BatchFirNode(t).set_algo(c.FIR_DIRECT) for t in taps]
+    with ThreadPoolExecutor(4) as ex:
+        got = list(ex.map(lambda i: nodes[i].run(xs[i]), range(4)))
+    for g, w in zip(got, want):
+        assert np.array_equal(g.view(np.uint8), w.view(np.uint8))
