@@ -809,6 +809,11 @@ def run_config2(ctx):
         st.update(total=total, per=per, steps=s_steps)
         return st
 
+    # The host-pointer leg runs FIRST, on a process that has allocated nothing big yet: behind the 2^30-sample leg (16 GiB of
+    # device buffers allocated and released again) the same pageable copies run at half the rate (FIR node 5.2 -> 2.8
+    # Gsamples/s on one box, `profiles/r05_host_pipeline.txt`), which says something about that process state, not about
+    # the path.  It touches the GPU for a few milliseconds: the legs below are not affected.
+    host_vec = host_vec_leg(ctx, min(n, N_SAMPLES)) if (ctx.rank == 0 and not args.no_host_vec) else None
     stream = None
     if args.stream_log2 and not args.head_first:
         stream = stream_leg()
@@ -866,8 +871,8 @@ def run_config2(ctx):
                                        "clock": "step period of the timed loop (one launch per step, back to back)"},
                           "note": "same FIR->mixer->decimate chain as one comms_chain_* launch "
                                   "(8 B read + 1 B written per input sample); not the headline value"}
-    if ctx.rank == 0 and not args.no_host_vec:
-        out["host_vec"] = host_vec_leg(ctx, min(n, N_SAMPLES))
+    if host_vec is not None:
+        out["host_vec"] = host_vec
     if stream is not None:
         st = stream
         ach = FIR_BYTES_PER_SAMPLE * st["per"] / (st["kernel_ms"] * 1e-3) / 1e9
