@@ -31,6 +31,7 @@ struct comms_chain : Handle {
     bool fused = false;
     bool decim = false;  // fused on the time-domain decimating kernel
     bool decim_any = false;  // ... on its any-rate form (fir_decim_any.hip; a mixer in front is folded into the taps)
+    bool poly8 = false;      // COMMS_CHAIN_POLYPHASE: always the polyphase frequency-domain kernel (fir_poly8.hip)
     bool fm_separate = false;  // fused mixer / FIR / decimate launch, FM demod as its own (small) kernel behind it
     bool pre_as_post = false;  // series of launches, mixer in front folded into the taps: runs as the mixer-behind form
     int mode = 0;
@@ -139,6 +140,17 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
     const bool can_any = st == COMMS_OK && !can_decim && !(flags & (COMMS_CHAIN_UNFUSED | COMMS_CHAIN_FREQ_DOMAIN)) &&
                          comms_fir_decim_any_supported(h->fir, static_cast<uint32_t>(rate)) &&
                          ((flags & COMMS_CHAIN_TIME_DOMAIN) || rate >= any_from);
+    const bool force_poly8 = st == COMMS_OK && (flags & COMMS_CHAIN_POLYPHASE) && !(flags & COMMS_CHAIN_UNFUSED) && rate == 8 &&
+                             n_taps <= 257 && !h->fm_demod;
+    if (force_poly8) {
+        h->fused = true;
+        h->poly8 = true;
+        h->mode = (h->mixer_after ? COMMS_CHAIN_POST : COMMS_CHAIN_PRE) | COMMS_CHAIN_DEC;
+        h->frac = mix_to_turns(mix_wrap_dphase(dphase));
+        h->turns = mix_to_turns(phase);
+        *out = h;
+        return COMMS_OK;
+    }
     if (can_any && !h->mixer_after) {
         // mixer in front: sum_k h[k] x[n-k] e^{i phi(n-k)} = e^{i phi(n)} sum_k (h[k] e^{-i k dphi}) x[n-k] -- the kernel
         // filters the RAW samples with modulated (complex) taps and mixes the kept outputs (the roundings fall
@@ -213,6 +225,7 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
         free_chain(h);
         return st;
     }
+    if (h->fir) h->fir->no_poly8 = (flags & COMMS_CHAIN_TIME_DOMAIN) != 0;
     *out = h;
     return COMMS_OK;
 }
@@ -225,7 +238,7 @@ comms_status_t comms_chain_create(double dphase, double phase, const comms_c32* 
 
 comms_status_t comms_chain_is_fused(const comms_chain_t* h, int32_t* out_fused) {
     COMMS_ARG(h && out_fused, "NULL argument");
-    *out_fused = h->fused ? (h->decim_any ? 3 : h->decim ? 2 : 1) : 0;
+    *out_fused = h->fused ? (h->poly8 ? 4 : h->decim_any ? 3 : h->decim ? 2 : 1) : 0;
     return COMMS_OK;
 }
 
@@ -263,7 +276,9 @@ comms_status_t comms_chain_run_dev(comms_chain_t* h, const comms_c32* d_in_any, 
             COMMS_TRY(h->t3.reserve(n_dec * sizeof(comms_c32)));
             stage_out = h->t3.p;
         }
-        if (h->decim_any)
+        if (h->poly8)
+            COMMS_TRY(comms_fir_run_poly8_dev(h->fir, d_in, n, stage_out, h->mode, h->turns, h->frac, s));
+        else if (h->decim_any)
             COMMS_TRY(comms_fir_run_decim_any_dev(h->fir, d_in, n, stage_out, h->mode, h->turns, h->frac, static_cast<uint32_t>(h->rate),
                                                   h->d_prev[h->cur], h->d_prev[h->cur ^ 1], s));
         else if (h->decim)

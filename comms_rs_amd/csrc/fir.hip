@@ -1346,6 +1346,7 @@ static void free_fir(comms_fir* h) {
     h->conv.release();
     if (h->d_qt) (void)hipFree(h->d_qt);
     if (h->d_any_taps) (void)hipFree(h->d_any_taps);
+    if (h->d_p8) (void)hipFree(h->d_p8);
     (void)use_device(h->device);
     if (h->d_taps_pad) (void)hipFree(h->d_taps_pad);
     if (h->d_wtw1) (void)hipFree(h->d_wtw1);

@@ -165,6 +165,10 @@ struct comms_fir : comms::Handle {
     int qt_rate = 0;
     float2* d_any_taps = nullptr;  // any-rate chain kernel: taps zero-padded to 32 * any_nt
     int any_nt = 0;
+    float2* d_p8 = nullptr;     // polyphase frequency-domain chain kernel (fir_poly8.hip): branch spectra + twiddle tables ...
+    bool p8_pre = false;        //   ... built for this mixer order and (mixer first: folded into the taps) increment
+    uint64_t p8_frac = 0;
+    bool no_poly8 = false;      // COMMS_CHAIN_TIME_DOMAIN: the time-domain kernel on every call
     // direct form
     int NP = 0;          // taps padded to a multiple of 8
     float2* d_taps_pad = nullptr;

@@ -1,0 +1,433 @@
+// fir_poly8.hip -- FIR -> mixer -> keep every 8th sample (the BASELINE metric's chain as one launch; the mixer-first
+// order through modulated taps), computed as EIGHT POLYPHASE BRANCHES IN THE FREQUENCY DOMAIN.
+//
+// Same results as BatchFirNode (src/filter/fir.rs:87-102), MixerNode (src/mixer.rs:73-85) and DecimateNode
+// (src/util/resample_node.rs:53-65) in series, within the FIR tolerance.  Why another form: the time-domain chain
+// kernel (fir_decim.hip) spends taps/8 packed FMAs per input sample -- at 255 taps it is bound by vector issue, not by
+// HBM (NOTES.md round 5: ~30 us of issue in a 40-us launch) -- and the overlap-save fusion (fir.hip, MODE != 0)
+// computes all eight outputs of which seven are dropped.  With
+//     y[8j] = sum_c sum_m h[8m - c] x[8(j - m) + c]          (c = 0 ... 7: the sample's position within its group of 8)
+// the kept outputs are the sum of eight 33-tap filters g_c[m] = h[8m - c], each running at the LOW rate on the phase
+// stream v_c[i] = x[8i + c].  Per segment of 1024 input samples (128 per phase, 32 of them halo: 768 new samples,
+// 96 outputs) a wave does eight 128-point forward transforms (as ONE 16-point DFT per lane, a twiddle, one exchange
+// and two 8-point DFTs per lane), multiplies by the branch spectra G_c and sums over c, and ONE 128-point inverse
+// transform: ~300 vector instructions per segment against ~500 for the same 768 samples in the time domain, and a
+// third of the overlap-save kernel's.
+//
+// Lane maps (l = lane):
+//   load      row a = 0..15: sample base + 64a + l -> phase c = l & 7, position q = 8a + (l >> 3) within the phase
+//   stage 1   DFT16 over a in registers, x W128^{d k1} (d = l >> 3), exchange 1 [k1][l]
+//   stage 2   lane (k1 = l & 15, cg = l >> 4) holds phases c = cg, cg + 4, all d: two DFT8 over d -> V_c[k1 + 16 k2]
+//   multiply  P[k2] = sum_ci G_{cg + 4 ci}[k1 + 16 k2] V[ci][k2]            (spectra in LDS, lane-major)
+//   reduce    exchange 2 [k2][cg][k1]; lane (k1, j = l >> 4) sums the four cg of k2 = j and k2 = j + 4
+//   inverse   DFT8 over k2: in-lane radix 2, then v_permlane32_swap / v_permlane16_swap butterflies over j;
+//             x w128^{q1 k1}; exchange 3 [q1][k1]; DFT4 over k1's upper digit; twiddle; exchange 4; DFT4 over the
+//             lower digit -> lane nu = l & 31 holds z[nu + 32 t], t = 0..3; t = 0 is the segment's halo, dropped
+//   store     out[96 seg + l] (64 lanes: t = 1 from lanes 0-31, t = 2 from lanes 32-63), out[96 seg + 64 + l] (t = 3)
+// A wave's LDS operations execute in order: the four exchanges share one private buffer, no barrier after set-up.
+// Segments are drawn from an LDS ticket counter per workgroup, dealt in round-robin chunks as in fir_os1024_dyn_kernel.
+#include <hip/hip_ext.h>
+
+#include <cmath>
+#include <vector>
+
+#include "common.hpp"
+#include "fft_radix.hpp"
+#include "fir_handle.hpp"
+
+namespace comms {
+
+constexpr int P8_S1 = 66;               // exchange 1: row stride (k1), 2 mod 32: the read side's (k1, cg) spread over all banks
+constexpr int P8_BUF = 16 * P8_S1;      // per-wave exchange buffer, in cf
+constexpr int P8_NEW = 768, P8_HALO = 256, P8_OUT = 96;
+// LDS: G [16][64], forward twiddle [16][8], sin / cos table [64], 16 exchange buffers, ticket
+constexpr int P8_TAB = 1024 + 128 + 64;
+constexpr size_t P8_LDS_BYTES = (P8_TAB + 16 * P8_BUF) * sizeof(float2) + 16;
+
+struct P8Tables {
+    const cf* g;     // [16][64]  G_{cg + 4 ci}[k1 + 16 k2] / 128 at [8 ci + k2][lane], k1 = lane & 15, cg = lane >> 4
+    const cf* tw;    // [16][8]   W128^{d k1} at [k1][d]
+    const cf* sc;    // [64]      (cos, sin)(2 pi i / 64)
+    const cf* lane;  // [7][64]   per-lane constants of the inverse (below)
+};
+struct P8Mix {
+    uint64_t turns0, frac;  // mixer phase of input sample 0, increment per input sample (turns of fl(2 pi) x 2^64)
+    float2 step512;         // e^{i 512 dphi}: 64 outputs on
+};
+
+__device__ __forceinline__ void p8_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// acc + a * b
+__device__ __forceinline__ cf cmacf(cf acc, cf a, cf b) {
+    cf p, d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(p) : "v"(a), "v"(b), "v"(acc));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(p));
+    return d;
+}
+
+// 8-point DFT, natural order in and out: two radix-4 and the W8 butterflies (28 packed instructions)
+template <int DIR>
+__device__ __forceinline__ void radix8(const cf (&x)[8], cf (&X)[8]) {
+    cf e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6];
+    cf o0 = x[1], o1 = x[3], o2 = x[5], o3 = x[7];
+    radix4<DIR>(e0, e1, e2, e3);
+    radix4<DIR>(o0, o1, o2, o3);
+    o1 = tw_mul_s<DIR>(o1, w16<2>());  // W8^1
+    o3 = tw_mul_s<DIR>(o3, w16<6>());  // W8^3
+    X[0] = cadd(e0, o0);
+    X[4] = csub(e0, o0);
+    X[1] = cadd(e1, o1);
+    X[5] = csub(e1, o1);
+    X[2] = cadd_di<DIR>(e2, o2);       // W8^2 = -+i
+    X[6] = csub_di<DIR>(e2, o2);
+    X[3] = cadd(e3, o3);
+    X[7] = csub(e3, o3);
+}
+
+struct P8Lane {
+    cf w8j;   // w8^{j}, j = lane >> 4                       (w = conjugate of the forward root)
+    cf tau;   // i on odd 16-lane rows, 1 on even ones
+    cf u0;    // w128^{q1 k1},       q1 = 2 (row & 1) + (lane >> 5), k1 = lane & 15
+    cf u1;    // w128^{(q1 + 4) k1}
+    cf m1, m2, m3;  // w16^{t ka}, t = 1..3, ka = (lane & 31) >> 3
+};
+
+// One segment: v[a] = samples base + 64a + lane -> ya = z[nu + 32 (1 + (lane >> 5))], yb = z[nu + 96]  (nu = lane & 31;
+// output index within the segment: lane for ya, 64 + nu for yb), before the mixer.
+__device__ __forceinline__ void poly8_core(cf (&v)[16], cf* lds, const cf* tw, const cf* gsp, const P8Lane& lc, int l,
+                                           cf& ya, cf& yb) {
+    const int d = l >> 3;
+    radix16<-1>(v);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        cf x = v[R16_POS(k)];
+        if (k) x = cmulf(x, tw[k * 8 + d]);
+        lds[k * P8_S1 + l] = x;
+    }
+    p8_lds_sync();
+    const int k1 = l & 15, cg = l >> 4;
+    cf xa[8], xb[8];
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd) {
+        xa[dd] = lds[k1 * P8_S1 + cg + 8 * dd];
+        xb[dd] = lds[k1 * P8_S1 + cg + 4 + 8 * dd];
+    }
+    p8_lds_sync();
+    cf va[8], vb[8];
+    radix8<-1>(xa, va);
+    radix8<-1>(xb, vb);
+    // ---- spectra, summed over the lane's two phases; exchange 2 [k2][cg][k1] (row stride 80: both j of a 32-lane read group on
+    // different banks)
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) {
+        cf p = cmulf(va[k2], gsp[k2 * 64 + l]);
+        p = cmacf(p, vb[k2], gsp[(8 + k2) * 64 + l]);
+        lds[k2 * 80 + cg * 16 + k1] = p;
+    }
+    p8_lds_sync();
+    const int j = cg;
+    cf za = lds[j * 80 + k1], zb = lds[(j + 4) * 80 + k1];
+#pragma unroll
+    for (int g = 1; g < 4; ++g) {
+        za = za + lds[j * 80 + g * 16 + k1];
+        zb = zb + lds[(j + 4) * 80 + g * 16 + k1];
+    }
+    p8_lds_sync();
+    // ---- inverse DFT8 over k2 = j + 4 kappa: radix 2 in the lane, radix 4 over j across the lanes.  After the swaps lane
+    // (k1, row parity j0, half j1) holds T[k1][q1] for q1 = 2 j0 + j1 (u) and q1 + 4 (w).
+    cf a = za + zb;
+    cf b = cmulf(za - zb, lc.w8j);
+    lane_swap32(a, b);
+    cf s = a + b;
+    cf dd = cmulf(a - b, lc.tau);
+    lane_swap16(s, dd);
+    const cf u = cmulf(s + dd, lc.u0);
+    const cf w = cmulf(s - dd, lc.u1);
+    // ---- exchange 3 [q1][k1], row stride 20
+    const int q1a = 2 * ((l >> 4) & 1) + (l >> 5);
+    lds[q1a * 20 + k1] = u;
+    lds[(q1a + 4) * 20 + k1] = w;
+    p8_lds_sync();
+    const int nu = l & 31;
+    const int r8 = nu & 7, r4 = nu >> 3;  // exchange 3 read: (q1, ka); exchange 4 read: (q1, t)
+    cf y0 = lds[r8 * 20 + r4], y1 = lds[r8 * 20 + r4 + 4], y2 = lds[r8 * 20 + r4 + 8], y3 = lds[r8 * 20 + r4 + 12];
+    p8_lds_sync();
+    radix4<1>(y0, y1, y2, y3);
+    y1 = cmulf(y1, lc.m1);
+    y2 = cmulf(y2, lc.m2);
+    y3 = cmulf(y3, lc.m3);
+    // ---- exchange 4 [t][ka][q1], row stride 40
+    lds[0 * 40 + r4 * 8 + r8] = y0;
+    lds[1 * 40 + r4 * 8 + r8] = y1;
+    lds[2 * 40 + r4 * 8 + r8] = y2;
+    lds[3 * 40 + r4 * 8 + r8] = y3;
+    p8_lds_sync();
+    cf m0 = lds[r4 * 40 + r8], m1 = lds[r4 * 40 + 8 + r8], m2 = lds[r4 * 40 + 16 + r8], m3 = lds[r4 * 40 + 24 + r8];
+    p8_lds_sync();
+    // DFT4 without its output 0 (the halo): z1, z2, z3
+    const cf t0 = cadd(m0, m2), t1 = csub(m0, m2), t2 = cadd(m1, m3), t3 = csub(m1, m3);
+    const cf z1 = cadd_di<1>(t1, t3), z2 = csub(t0, t2), z3 = csub_di<1>(t1, t3);
+    ya = l < 32 ? z1 : z2;
+    yb = z3;
+}
+
+// (cos, sin) of 2 pi u / 2^32: a 64-entry table for the upper six bits, a short series for the rest (|error| ~ 1e-7)
+__device__ __forceinline__ cf p8_rotor(unsigned u, const cf* sc) {
+    const cf t = sc[u >> 26];
+    const float th = static_cast<float>(u & 0x3FFFFFFu) * 1.4629180792671596e-09f;  // 2 pi / 2^32
+    const float z = th * th;
+    float sp = __builtin_fmaf(z, 8.3333333e-3f, -1.6666667e-1f);
+    sp = __builtin_fmaf(z, sp, 1.0f);
+    const float sn = th * sp;
+    float cp = __builtin_fmaf(z, -1.3888889e-3f, 4.1666667e-2f);
+    cp = __builtin_fmaf(z, cp, -0.5f);
+    const float cs = __builtin_fmaf(z, cp, 1.0f);
+    return cmulf(t, cf{cs, sn});
+}
+
+template <class In = const float2*>
+__global__ __launch_bounds__(1024, 4) void fir_poly8_kernel(In in, const float2* __restrict__ hist, int hist_len,
+                                                            float2* __restrict__ out, size_t n, P8Tables tb,
+                                                            float2* __restrict__ new_hist, unsigned chunk_log2, P8Mix mx,
+                                                            KStamp ks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    kstamp_begin(ks);
+    hist_advance(hist, in, n, new_hist, hist_len);
+    cf* gsp = reinterpret_cast<cf*>(smem);  // [16][64]
+    cf* tw = gsp + 1024;                    // [16][8]
+    cf* sc = tw + 128;                      // [64]
+    const int l = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    cf* lds = sc + 64 + wave * P8_BUF;
+    unsigned* ticket = reinterpret_cast<unsigned*>(sc + 64 + 16 * P8_BUF);
+    gsp[threadIdx.x] = tb.g[threadIdx.x];
+    if (threadIdx.x < 128) tw[threadIdx.x] = tb.tw[threadIdx.x];
+    if (threadIdx.x < 64) sc[threadIdx.x] = tb.sc[threadIdx.x];
+    if (threadIdx.x == 0) *ticket = 0;
+    P8Lane lc;
+    lc.w8j = tb.lane[0 * 64 + l];
+    lc.tau = tb.lane[1 * 64 + l];
+    lc.u0 = tb.lane[2 * 64 + l];
+    lc.u1 = tb.lane[3 * 64 + l];
+    lc.m1 = tb.lane[4 * 64 + l];
+    lc.m2 = tb.lane[5 * 64 + l];
+    lc.m3 = tb.lane[6 * 64 + l];
+    __syncthreads();
+
+    const size_t n_out = n >> 3;
+    const size_t nfull = n / P8_NEW;  // segments whose 768 new samples are all inside `in`
+    const size_t inner = nfull > 1 ? nfull - 1 : 0;
+    const bool contiguous = chunk_log2 >= 32u;
+    const unsigned G = gridDim.x;
+    const unsigned wg = (G % 8u == 0u) ? (blockIdx.x % 8u) * (G / 8u) + blockIdx.x / 8u : blockIdx.x;
+    const size_t lo = 1 + blockIdx.x * inner / gridDim.x;
+    const size_t hi = contiguous ? 1 + (blockIdx.x + 1) * inner / gridDim.x : nfull;
+    auto draw = [&]() -> size_t {
+        unsigned t = 0;
+        if (l == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned tk = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(t)));
+        if (contiguous) return lo + tk;
+        const size_t c = static_cast<size_t>(tk >> chunk_log2) * G + wg;
+        return 1 + (c << chunk_log2) + (tk & ((1u << chunk_log2) - 1u));
+    };
+    // mixer phase of output 96 seg + lane (input sample 8 x that): a scalar part per segment + the lane's own
+    const uint64_t lane_turns = mx.turns0 + static_cast<uint64_t>(8 * l) * mx.frac;
+    const uint64_t seg_turns = static_cast<uint64_t>(P8_NEW) * mx.frac;
+    const cf step512 = to_cf(mx.step512);
+    auto emit = [&](size_t sg, cf ya, cf yb, bool guard) {
+        const uint64_t tl = lane_turns + static_cast<uint64_t>(sg) * seg_turns;
+        const cf rot = p8_rotor(static_cast<unsigned>(tl >> 32), sc);
+        ya = cmulf(ya, rot);
+        yb = cmulf(yb, cmulf_s(rot, step512));
+        const size_t o = sg * P8_OUT + l;
+        if (!guard) {
+            out[o] = to_f2(ya);
+            if (l < 32) out[o + 64] = to_f2(yb);
+        } else {
+            if (o < n_out) out[o] = to_f2(ya);
+            if (l < 32 && o + 64 < n_out) out[o + 64] = to_f2(yb);
+        }
+    };
+
+    cf v[16], ya, yb;
+    // The stream's first segment (halo from the history) and its partial last one: wave 0 of the first / last workgroup,
+    // before it joins the ticket loop
+    if (wave == 0) {
+        const size_t nseg = (n + P8_NEW - 1) / P8_NEW;
+        for (int e = 0; e < 2; ++e) {
+            const size_t sg = e ? nseg - 1 : 0;
+            if (e ? (blockIdx.x != gridDim.x - 1 || nseg < 2 || nseg == nfull) : blockIdx.x != 0) continue;
+            const long long b0 = static_cast<long long>(sg * P8_NEW) - P8_HALO + l;
+#pragma unroll
+            for (int a = 0; a < 16; ++a) v[a] = to_cf(stream_at(in, hist, hist_len, b0 + 64 * a, n));
+            poly8_core(v, lds, tw, gsp, lc, l, ya, yb);
+            emit(sg, ya, yb, true);
+        }
+    }
+    size_t seg = draw();
+    while (seg < hi) {
+        const size_t p = seg * P8_NEW - P8_HALO + l;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = to_cf(in[p + 64 * a]);
+        const size_t seg_next = draw();
+        poly8_core(v, lds, tw, gsp, lc, l, ya, yb);
+        emit(seg, ya, yb, false);
+        seg = seg_next;
+    }
+    kstamp_end(ks);
+}
+
+}  // namespace comms
+
+using namespace comms;
+
+namespace {
+
+const double kPi8 = 3.14159265358979323846264338327950288;
+float2 root(long long e, int denom, int sign) {  // e^{sign 2 pi i e / denom}
+    e %= denom;
+    if (e < 0) e += denom;
+    const double a = 2.0 * kPi8 * static_cast<double>(e) / denom;
+    return make_float2(static_cast<float>(std::cos(a)), static_cast<float>(sign * std::sin(a)));
+}
+
+}  // namespace
+
+// Tables of the handle for mixer increment `frac` (the mixer-first chain folds the mixer into the taps:
+// sum_k h[k] x[n-k] e^{i phi(n-k)} = e^{i phi(n)} sum_k (h[k] e^{-i k dphi}) x[n-k]).  Built once per (handle, frac, order).
+static comms_status_t poly8_prepare(comms_fir* h, bool pre, uint64_t frac, hipStream_t s) {
+    if (h->d_p8 && h->p8_pre == pre && (!pre || h->p8_frac == frac)) return COMMS_OK;
+    const int N = h->n_eff;
+    std::vector<double> hr(264, 0.0), hi(264, 0.0);
+    const double dphi = static_cast<double>(frac >> 11) * (kMixT * 0x1.0p-53);
+    for (int k = 0; k < N; ++k) {
+        double tr = h->taps[k].re, ti = h->taps[k].im;
+        if (pre) {
+            const double ang = -dphi * static_cast<double>(k);
+            const double cr = std::cos(ang), ci = std::sin(ang);
+            const double r = tr * cr - ti * ci;
+            ti = tr * ci + ti * cr;
+            tr = r;
+        }
+        hr[k] = tr;
+        hi[k] = ti;
+    }
+    std::vector<float2> t(static_cast<size_t>(P8_TAB) + 7 * 64);
+    float2* g = t.data();
+    float2* tw = g + 1024;
+    float2* sc = tw + 128;
+    float2* ln = sc + 64;
+    // G_c[k] = (1/128) sum_m h[8m - c] W128^{mk}
+    std::vector<double> cs(128), sn(128);
+    for (int i = 0; i < 128; ++i) {
+        cs[i] = std::cos(2.0 * kPi8 * i / 128.0);
+        sn[i] = -std::sin(2.0 * kPi8 * i / 128.0);
+    }
+    for (int lane = 0; lane < 64; ++lane) {
+        const int k1 = lane & 15, cg = lane >> 4;
+        for (int ci = 0; ci < 2; ++ci)
+            for (int k2 = 0; k2 < 8; ++k2) {
+                const int c = cg + 4 * ci, k = k1 + 16 * k2;
+                double re = 0.0, im = 0.0;
+                for (int m = 0; m <= 32; ++m) {
+                    const int tap = 8 * m - c;
+                    if (tap < 0 || tap >= N) continue;
+                    const int e = (m * k) & 127;
+                    re += hr[tap] * cs[e] - hi[tap] * sn[e];
+                    im += hr[tap] * sn[e] + hi[tap] * cs[e];
+                }
+                g[(8 * ci + k2) * 64 + lane] = make_float2(static_cast<float>(re / 128.0), static_cast<float>(im / 128.0));
+            }
+    }
+    for (int k1 = 0; k1 < 16; ++k1)
+        for (int d = 0; d < 8; ++d) tw[k1 * 8 + d] = root(static_cast<long long>(d) * k1, 128, -1);
+    for (int i = 0; i < 64; ++i) sc[i] = root(i, 64, +1);
+    for (int lane = 0; lane < 64; ++lane) {
+        const int k1 = lane & 15, j = lane >> 4, j0 = j & 1, j1 = j >> 1, q1 = 2 * j0 + j1, ka = (lane & 31) >> 3;
+        ln[0 * 64 + lane] = root(j, 8, +1);
+        ln[1 * 64 + lane] = j0 ? make_float2(0.f, 1.f) : make_float2(1.f, 0.f);
+        ln[2 * 64 + lane] = root(static_cast<long long>(q1) * k1, 128, +1);
+        ln[3 * 64 + lane] = root(static_cast<long long>(q1 + 4) * k1, 128, +1);
+        for (int tq = 1; tq < 4; ++tq) ln[(3 + tq) * 64 + lane] = root(static_cast<long long>(tq) * ka, 16, +1);
+    }
+    if (!h->d_p8) COMMS_HIP_TRY(hipMalloc(&h->d_p8, t.size() * sizeof(float2)));
+    // (in stream order behind the launches that still read the old tables; the source is pageable memory, so the call returns
+    // once the copy has been staged)
+    COMMS_HIP_TRY(hipMemcpyAsync(h->d_p8, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice, s));
+    COMMS_HIP_TRY(hipStreamSynchronize(s));
+    h->p8_pre = pre;
+    h->p8_frac = frac;
+    return COMMS_OK;
+}
+
+extern "C" {
+
+// 1: this chain (taps, rate, stages, batch) runs on the polyphase frequency-domain kernel
+int32_t comms_fir_poly8_supported(const comms_fir_t* h, uint32_t rate, int32_t mode, size_t n) {
+    if (!h || rate != 8 || h->n_eff < 1 || h->n_eff > 257 || h->in_fmt != COMMS_IQ_C32 || h->no_poly8) return 0;
+    if (!(mode & COMMS_CHAIN_DEC) || (mode & COMMS_CHAIN_FM)) return 0;
+    static const int knob = diag_knob("COMMS_POLY8", 1);          // 0: never, 1: where it wins, 2: wherever it can run
+    static const int min_taps = diag_knob("COMMS_POLY8_MIN_TAPS", 130);
+    static const int min_log2 = diag_knob("COMMS_POLY8_MIN_LOG2", 22);
+    if (!knob) return 0;
+    if (knob == 2) return n >= 8 ? 1 : 0;
+    return h->n_eff >= min_taps && n >= (static_cast<size_t>(1) << min_log2) ? 1 : 0;
+}
+
+comms_status_t comms_fir_run_poly8_dev(comms_fir_t* h, const void* d_in, size_t n, void* d_out, int32_t mode,
+                                       uint64_t turns0, uint64_t frac, void* stream) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG((d_in && d_out) || !n, "NULL device pointer");
+    COMMS_ARG(n % 8 == 0, "n must be a multiple of the decimation rate");
+    COMMS_ARG(h->n_eff <= 257 && h->in_fmt == COMMS_IQ_C32, "the polyphase kernel takes <= 257 taps and Complex<f32> input");
+    COMMS_ARG((mode & COMMS_CHAIN_DEC) && !(mode & COMMS_CHAIN_FM) && !((mode & COMMS_CHAIN_PRE) && (mode & COMMS_CHAIN_POST)),
+              "bad chain mode");
+    COMMS_TRY(fir_check_sticky(h));
+    COMMS_TRY(use_device(h->device));
+    if (!n) return COMMS_OK;
+    COMMS_ARG(!ranges_overlap(d_in, n * 8, d_out, n), "the decimating chain cannot run in place");
+    COMMS_ARG((reinterpret_cast<uintptr_t>(d_in) & 7) == 0, "input must be aligned to one IQ sample");
+    hipStream_t s = nullptr;
+    COMMS_TRY(h->enter(stream, &s));
+    COMMS_TRY(poly8_prepare(h, (mode & COMMS_CHAIN_PRE) != 0, frac, s));
+    P8Tables tb;
+    tb.g = reinterpret_cast<const cf*>(h->d_p8);
+    tb.tw = tb.g + 1024;
+    tb.sc = tb.tw + 128;
+    tb.lane = tb.sc + 64;
+    P8Mix mx;
+    mx.turns0 = turns0;
+    mx.frac = frac;
+    double c, sn;
+    mix_host_rotor(512u * frac, c, sn);
+    mx.step512 = make_float2(static_cast<float>(c), static_cast<float>(sn));
+    const size_t nseg = (n + P8_NEW - 1) / P8_NEW;
+    const size_t want = (nseg + 15) / 16;
+    const dim3 grid(static_cast<unsigned>(want < static_cast<size_t>(kNumCU) ? want : kNumCU));
+    static const int chunk_knob = diag_knob("COMMS_POLY8_CHUNK_LOG2", -1);
+    const unsigned chunk_log2 = chunk_knob >= 0 ? static_cast<unsigned>(chunk_knob) : nseg < 160u * static_cast<size_t>(grid.x) ? 1u : 3u;
+    static DeviceOnce attr_once;
+    if (attr_once.need())
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_poly8_kernel<const float2*>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(P8_LDS_BYTES)));
+    hipEvent_t ea = nullptr, eb = nullptr;
+    (void)h->take_events(ea, eb);
+    const KStamp ks = h->next_stamp();
+    const float2* in = static_cast<const float2*>(d_in);
+    float2* o = static_cast<float2*>(d_out);
+    if (ea)
+        hipExtLaunchKernelGGL((fir_poly8_kernel<const float2*>), grid, dim3(1024), static_cast<uint32_t>(P8_LDS_BYTES), s, ea, eb, 0u,
+                              in, h->d_hist[h->cur], h->n_eff, o, n, tb, h->d_hist[h->cur ^ 1], chunk_log2, mx, ks);
+    else
+        fir_poly8_kernel<const float2*><<<grid, dim3(1024), P8_LDS_BYTES, s>>>(in, h->d_hist[h->cur], h->n_eff, o, n, tb,
+                                                                              h->d_hist[h->cur ^ 1], chunk_log2, mx, ks);
+    COMMS_TRY(launch_ok("fir_poly8_kernel"));
+    h->cur ^= 1;
+    return COMMS_OK;
+}
+
+}  // extern "C"

@@ -509,13 +509,13 @@ class ChainNode(_Handle):
 
     def __init__(self, dphase, phase, taps, rate, fm_demod, device=0, mixer_after_fir=False, unfused=False,
                  kernel="auto"):
-        """kernel: "auto", "freq" (always the overlap-save kernel) or "time" (the decimating
-        time-domain kernel wherever it applies)."""
+        """kernel: "auto", "freq" (always the overlap-save kernel), "time" (the decimating
+        time-domain kernel wherever it applies) or "poly" (the polyphase frequency-domain kernel: rate 8, <= 257 taps, no FM)."""
         super().__init__()
         taps = _as_c64(taps)
         self.rate, self.fm_demod = int(rate), bool(fm_demod)
         flags = (1 if fm_demod else 0) | (2 if mixer_after_fir else 0) | (4 if unfused else 0)
-        flags |= {"auto": 0, "freq": 8, "time": 16}[kernel]
+        flags |= {"auto": 0, "freq": 8, "time": 16, "poly": 32}[kernel]
         check(lib().comms_chain_create_ex(float(dphase), float(phase), _ptr(taps), taps.size, self.rate,
                                           flags, device, C.byref(self._h)))
 
@@ -527,10 +527,11 @@ class ChainNode(_Handle):
 
     @property
     def kernel(self):
-        """"unfused", "freq" (fir_os1024_kernel), "time" (fir_decim_kernel) or "time_any" (fir_decim_any_kernel)."""
+        """"unfused", "freq" (fir_os1024_kernel), "time" (fir_decim_kernel), "time_any" (fir_decim_any_kernel) or "poly"
+        (fir_poly8_kernel on every call)."""
         f = C.c_int32()
         check(lib().comms_chain_is_fused(self._h, C.byref(f)))
-        return ("unfused", "freq", "time", "time_any")[f.value]
+        return ("unfused", "freq", "time", "time_any", "poly")[f.value]
 
     _fmt = "c32"
 

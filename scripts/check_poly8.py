@@ -1,0 +1,76 @@
+"""fir_poly8_kernel against the oracle (small sizes, ragged calls with state) and against the time-domain chain kernel
+(2^22 ... 2^26 samples), then bursts of launches of both, timed.  GPU box only."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import comms_rs_amd as c
+from oracle import oracle
+
+rng = np.random.default_rng(5)
+
+
+def rand_c(n):
+    return (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+
+
+worst = 0.0
+for n_taps, cplx, after in [(255, False, True), (255, True, True), (255, False, False), (257, True, False), (131, False, True),
+                            (200, True, True), (33, False, True), (1, False, True), (8, True, False)]:
+    taps = oracle.rrc_taps(n_taps, 8.0, 0.35) if n_taps > 8 else np.ones(n_taps, np.complex64)
+    if cplx:
+        taps = (taps * np.exp(1j * 0.01 * np.arange(n_taps))).astype(np.complex64)
+    dphase, phase = 2 * np.pi * 0.1, 0.3
+    node = c.ChainNode(dphase, phase, taps, 8, False, mixer_after_fir=after, kernel="poly")
+    assert node.kernel == "poly", node.kernel
+    n = 768 * 37 + 8 * 11
+    x = rand_c(n)
+    ost, om = oracle.default_state(taps), oracle.Mixer(phase, dphase)
+    cuts = [0, 8, 776, 768 * 3, 768 * 3 + 16, 768 * 20 + 8 * 50, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if after:
+            w = oracle.decimate(om.mix(oracle.batch_fir(x[a:b], taps, ost, norotate=True)), 8)
+        else:
+            w = oracle.decimate(oracle.batch_fir(om.mix(x[a:b]), taps, ost, norotate=True), 8)
+        got = node.run(x[a:b])
+        scale = np.sum(np.abs(taps)) * np.max(np.abs(x))
+        err = np.max(np.abs(got - w)) / scale
+        worst = max(worst, err)
+        assert err <= 2e-5, (n_taps, cplx, after, a, b, err)
+    # FIR history as the reference keeps it
+    st = node.fir_state(len(taps))
+    print("taps %3d cplx %d after %d: worst so far %.2e" % (n_taps, cplx, after, worst), flush=True)
+print("oracle parity OK, worst %.3e of sum|taps| max|x|" % worst, flush=True)
+
+taps = oracle.rrc_taps(255, 8.0, 0.35)
+for lg in (20, 22, 24, 26):
+    n = 1 << lg
+    x = torch.empty(n, dtype=torch.complex64, device="cuda:0")
+    c.synth_iq_dev(x.data_ptr(), n, 0)
+    s = torch.cuda.current_stream().cuda_stream
+    kerns = ("time", "poly")
+    nodes = [c.ChainNode(2 * np.pi * 0.05, 0.1, taps, 8, False, mixer_after_fir=True, kernel=k) for k in kerns]
+    outs = [torch.empty(n // 8, dtype=torch.complex64, device="cuda:0") for _ in kerns]
+    for i, nd in enumerate(nodes):
+        nd.run_dev(x.data_ptr(), n, outs[i].data_ptr(), s)
+    torch.cuda.synchronize()
+    d = (outs[0] - outs[1]).abs().max().item()
+    sc = np.sum(np.abs(taps)) * float(x[:1 << 20].abs().max().item())
+    print("2^%d poly vs time (first call, zero state): max |diff| %.3e = %.2e of sum|taps| max|x|" % (lg, d, d / sc), flush=True)
+    assert d / sc < 2e-5
+    ts = [[] for _ in kerns]
+    for rep in range(8):
+        for i, nd in enumerate(nodes):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(20):
+                nd.run_dev(x.data_ptr(), n, outs[i].data_ptr(), s)
+            b.record()
+            torch.cuda.synchronize()
+            ts[i].append(a.elapsed_time(b) / 20 * 1e3)
+    for i, k in enumerate(kerns):
+        print("2^%d %s: median %.1f us per launch (bursts of 20, kernels taking turns): %s" % (lg, k, np.median(ts[i]), " ".join("%.1f" % t for t in ts[i])), flush=True)

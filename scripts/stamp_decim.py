@@ -13,13 +13,21 @@ import torch
 
 import comms_rs_amd as c
 
-n = 1 << 26
-k = np.arange(127) - 63.0
-taps = (2 / 16 * np.sinc(2 / 16 * k) * np.hamming(127)).astype(np.complex64)
-x = torch.empty(n, dtype=torch.complex64, device="cuda:0")
-c.synth_iq_dev(x.data_ptr(), n, 0)
-out = torch.empty(n // 8, dtype=torch.float32, device="cuda:0")
-ch = c.ChainNode(2 * np.pi * 0.05, 0.0, taps, 8, True, kernel="time")
+if os.environ.get("CASE", "c3") == "c2":   # the metric's chain as one launch: 255 taps -> mixer -> /8, 2^24
+    n = 1 << 24
+    taps = c.rrc_taps(255, 8.0, 0.35)
+    x = torch.empty(n, dtype=torch.complex64, device="cuda:0")
+    c.synth_iq_dev(x.data_ptr(), n, 0)
+    out = torch.empty(n // 8, dtype=torch.complex64, device="cuda:0")
+    ch = c.ChainNode(2 * np.pi * 0.05, 0.0, taps, 8, False, mixer_after_fir=True, kernel="time")
+else:                                      # config 3 (needs COMMS_DECIM_WAVE=0: the stamps are the workgroup kernel's)
+    n = 1 << 26
+    k = np.arange(127) - 63.0
+    taps = (2 / 16 * np.sinc(2 / 16 * k) * np.hamming(127)).astype(np.complex64)
+    x = torch.empty(n, dtype=torch.complex64, device="cuda:0")
+    c.synth_iq_dev(x.data_ptr(), n, 0)
+    out = torch.empty(n // 8, dtype=torch.float32, device="cuda:0")
+    ch = c.ChainNode(2 * np.pi * 0.05, 0.0, taps, 8, True, kernel="time")
 s = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
     ch.run_dev(x.data_ptr(), n, out.data_ptr(), s)
