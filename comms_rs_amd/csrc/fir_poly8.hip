@@ -96,10 +96,9 @@ struct P8Lane {
     cf m1, m2, m3;  // w16^{t ka}, t = 1..3, ka = (lane & 31) >> 3
 };
 
-// One segment: v[a] = samples base + 64a + lane -> ya = z[nu + 32 (1 + (lane >> 5))], yb = z[nu + 96]  (nu = lane & 31;
-// output index within the segment: lane for ya, 64 + nu for yb), before the mixer.
-__device__ __forceinline__ void poly8_core(cf (&v)[16], cf* lds, const cf* tw, const cf* gsp, const P8Lane& lc, int l,
-                                           cf& ya, cf& yb) {
+// One segment, first half: v[a] = samples base + 64a + lane -> the spectrum products of the lane's two phases, written to
+// exchange 2.  v is dead afterwards (the caller fetches the next segment's rows into it while the second half runs).
+__device__ __forceinline__ void poly8_forward(cf (&v)[16], cf* lds, const cf* tw, const cf* gsp, int l) {
     const int d = l >> 3;
     radix16<-1>(v);
 #pragma unroll
@@ -129,6 +128,12 @@ __device__ __forceinline__ void poly8_core(cf (&v)[16], cf* lds, const cf* tw, c
         lds[k2 * 80 + cg * 16 + k1] = p;
     }
     p8_lds_sync();
+}
+
+// ... second half: the sum over the phases and the 128-point inverse transform -> ya = z[nu + 32 (1 + (lane >> 5))],
+// yb = z[nu + 96] (nu = lane & 31; output index within the segment: lane for ya, 64 + nu for yb), before the mixer.
+__device__ __forceinline__ void poly8_inverse(cf* lds, const P8Lane& lc, int l, cf& ya, cf& yb) {
+    const int k1 = l & 15, cg = l >> 4;
     const int j = cg;
     cf za = lds[j * 80 + k1], zb = lds[(j + 4) * 80 + k1];
 #pragma unroll
@@ -264,20 +269,33 @@ __global__ __launch_bounds__(1024, 4) void fir_poly8_kernel(In in, const float2*
             const long long b0 = static_cast<long long>(sg * P8_NEW) - P8_HALO + l;
 #pragma unroll
             for (int a = 0; a < 16; ++a) v[a] = to_cf(stream_at(in, hist, hist_len, b0 + 64 * a, n));
-            poly8_core(v, lds, tw, gsp, lc, l, ya, yb);
+            poly8_forward(v, lds, tw, gsp, l);
+            poly8_inverse(lds, lc, l, ya, yb);
             emit(sg, ya, yb, true);
         }
     }
-    size_t seg = draw();
-    while (seg < hi) {
-        const size_t p = seg * P8_NEW - P8_HALO + l;
+    auto fetch = [&](size_t sg) {
+        const size_t p = sg * P8_NEW - P8_HALO + l;
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = to_cf(in[p + 64 * a]);
+    };
+    // Order within an iteration: forward half of this segment; the STORES of the segment before it; the loads of the
+    // next one; inverse half.  vmcnt counts loads and stores in one in-order queue: with the stores issued in front of the
+    // loads, the wait for the rows at the top of the loop does not wait for stores issued a moment earlier.
+    size_t seg = draw(), seg_prev = 0;
+    bool have = false;
+    if (seg < hi) fetch(seg);
+    while (seg < hi) {
         const size_t seg_next = draw();
-        poly8_core(v, lds, tw, gsp, lc, l, ya, yb);
-        emit(seg, ya, yb, false);
+        poly8_forward(v, lds, tw, gsp, l);
+        if (have) emit(seg_prev, ya, yb, false);
+        if (seg_next < hi) fetch(seg_next);  // v is dead: the rows travel while the inverse half runs (few registers)
+        poly8_inverse(lds, lc, l, ya, yb);
+        seg_prev = seg;
+        have = true;
         seg = seg_next;
     }
+    if (have) emit(seg_prev, ya, yb, false);
     kstamp_end(ks);
 }
 
