@@ -140,14 +140,24 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
     const bool can_any = st == COMMS_OK && !can_decim && !(flags & (COMMS_CHAIN_UNFUSED | COMMS_CHAIN_FREQ_DOMAIN)) &&
                          comms_fir_decim_any_supported(h->fir, static_cast<uint32_t>(rate)) &&
                          ((flags & COMMS_CHAIN_TIME_DOMAIN) || rate >= any_from);
-    const bool force_poly8 = st == COMMS_OK && (flags & COMMS_CHAIN_POLYPHASE) && !(flags & COMMS_CHAIN_UNFUSED) && rate == 8 &&
-                             n_taps <= 257 && !h->fm_demod;
+    const int32_t poly_mode = (h->mixer_after ? COMMS_CHAIN_POST : COMMS_CHAIN_PRE) | COMMS_CHAIN_DEC | (h->fm_demod ? COMMS_CHAIN_FM : 0);
+    const bool force_poly8 = st == COMMS_OK && (flags & COMMS_CHAIN_POLYPHASE) && !(flags & COMMS_CHAIN_UNFUSED) &&
+                             comms_fir_poly8_supported(h->fir, static_cast<uint32_t>(rate), poly_mode, 8) != 0;
     if (force_poly8) {
         h->fused = true;
         h->poly8 = true;
-        h->mode = (h->mixer_after ? COMMS_CHAIN_POST : COMMS_CHAIN_PRE) | COMMS_CHAIN_DEC;
+        h->mode = poly_mode;
         h->frac = mix_to_turns(mix_wrap_dphase(dphase));
         h->turns = mix_to_turns(phase);
+        for (int i = 0; i < 2 && st == COMMS_OK; ++i) {
+            hipError_t e = hipMalloc(&h->d_prev[i], sizeof(float2));
+            if (e == hipSuccess) e = zero_device(h->d_prev[i], sizeof(float2));
+            if (e != hipSuccess) st = fail(COMMS_ERR_DEVICE, "chain state alloc: %s", hipGetErrorString(e));
+        }
+        if (st != COMMS_OK) {
+            free_chain(h);
+            return st;
+        }
         *out = h;
         return COMMS_OK;
     }
@@ -277,7 +287,7 @@ comms_status_t comms_chain_run_dev(comms_chain_t* h, const comms_c32* d_in_any, 
             stage_out = h->t3.p;
         }
         if (h->poly8)
-            COMMS_TRY(comms_fir_run_poly8_dev(h->fir, d_in, n, stage_out, h->mode, h->turns, h->frac, s));
+            COMMS_TRY(comms_fir_run_poly8_dev(h->fir, d_in, n, stage_out, h->mode, h->turns, h->frac, h->d_prev[h->cur], h->d_prev[h->cur ^ 1], s));
         else if (h->decim_any)
             COMMS_TRY(comms_fir_run_decim_any_dev(h->fir, d_in, n, stage_out, h->mode, h->turns, h->frac, static_cast<uint32_t>(h->rate),
                                                   h->d_prev[h->cur], h->d_prev[h->cur ^ 1], s));

@@ -115,34 +115,6 @@ __device__ __forceinline__ void rotor_step(double& c, double& s, double sc, doub
     c = nc;
 }
 
-// atan2 for the fused FM demod: |error| <= ~2e-7 rad (the reference's f32 atan2 is good to 1 ulp,
-// 2.4e-7 near pi), about a third of the library routine's instructions.  Minimax fit of
-// atan(t)/t in t^2 on [0, 1] (degree 8), octant folding on max/min, signed zeros as atan2.
-__device__ __forceinline__ float fast_atan2f(float y, float x) {
-    const float ax = fabsf(x), ay = fabsf(y);
-    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    const float t = mx > 0.f ? mn * __builtin_amdgcn_rcpf(mx) : 0.f;
-    const float z = t * t;
-    float p = 0.0024567078799009323f;
-    p = __builtin_fmaf(p, z, -0.014401284977793694f);
-    p = __builtin_fmaf(p, z, 0.03978108987212181f);
-    p = __builtin_fmaf(p, z, -0.0723484456539154f);
-    p = __builtin_fmaf(p, z, 0.10498938709497452f);
-    p = __builtin_fmaf(p, z, -0.14161226153373718f);
-    p = __builtin_fmaf(p, z, 0.19985906779766083f);
-    p = __builtin_fmaf(p, z, -0.33332598209381104f);
-    p = __builtin_fmaf(p, z, 0.9999998807907104f);
-    float r = p * t;
-    if (ay > ax) r = 1.57079637f - r;
-    if (__builtin_signbit(x)) r = 3.14159274f - r;
-    return __builtin_copysignf(r, y);
-}
-// FM::demod step (src/modulation/analog.rs:27-28) with the fast atan2
-__device__ __forceinline__ float fm_step_fast(float2 x, float2 p) {
-    const float pcr = p.x, pci = -p.y;
-    return fast_atan2f(x.x * pci + x.y * pcr, x.x * pcr - x.y * pci);
-}
-
 // A sample of the input stream, read once by this launch (the tile's halo a second time).  COMMS_DECIM_NT=1 (trial
 // build): Complex<f32> rows as nontemporal loads.
 #ifndef COMMS_DECIM_NT
@@ -528,10 +500,6 @@ struct DwGeom {
     static_assert(64 % PR == 0, "a row of 64 samples must be whole phase-array columns");
 };
 
-// lane l takes lane l - 1's value, lane 0 keeps `first` (DPP wave_shr:1)
-__device__ __forceinline__ float wave_shr1(float v, float first) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
-}
 
 template <int R, bool REAL, bool PRE, int HR, int WPB, int AUX>
 __global__ __launch_bounds__(64 * WPB, 4) void fir_decim_wave_kernel(const DecimArgs a) {
@@ -929,7 +897,8 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
     // long filters on long batches at rate 8: the polyphase frequency-domain kernel (fir_poly8.hip)
-    if (comms_fir_poly8_supported(h, rate, mode, n)) return comms_fir_run_poly8_dev(h, d_in, n, d_out, mode, turns0, frac, stream);
+    if (comms_fir_poly8_supported(h, rate, mode, n) == 2)
+        return comms_fir_run_poly8_dev(h, d_in, n, d_out, mode, turns0, frac, fm_prev, fm_prev_new, stream);
     const size_t in_elem = h->in_fmt == COMMS_IQ_I16 ? 4 : h->in_fmt == COMMS_IQ_U8 ? 2 : 8;
     COMMS_ARG(!ranges_overlap(d_in, n * in_elem, d_out, (n / rate) * ((mode & COMMS_CHAIN_FM) ? 4 : 8)),
               "the decimating chain cannot run in place");

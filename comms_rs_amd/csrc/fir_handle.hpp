@@ -151,6 +151,38 @@ __device__ __forceinline__ float fm_step(float2 x, float2 p) {
     return atan2f(im, re);
 }
 
+// atan2 for the fused FM demod: |error| <= ~2e-7 rad (the reference's f32 atan2 is good to 1 ulp,
+// 2.4e-7 near pi), about a third of the library routine's instructions.  Minimax fit of
+// atan(t)/t in t^2 on [0, 1] (degree 8), octant folding on max/min, signed zeros as atan2.
+__device__ __forceinline__ float fast_atan2f(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mx > 0.f ? mn * __builtin_amdgcn_rcpf(mx) : 0.f;
+    const float z = t * t;
+    float p = 0.0024567078799009323f;
+    p = __builtin_fmaf(p, z, -0.014401284977793694f);
+    p = __builtin_fmaf(p, z, 0.03978108987212181f);
+    p = __builtin_fmaf(p, z, -0.0723484456539154f);
+    p = __builtin_fmaf(p, z, 0.10498938709497452f);
+    p = __builtin_fmaf(p, z, -0.14161226153373718f);
+    p = __builtin_fmaf(p, z, 0.19985906779766083f);
+    p = __builtin_fmaf(p, z, -0.33332598209381104f);
+    p = __builtin_fmaf(p, z, 0.9999998807907104f);
+    float r = p * t;
+    if (ay > ax) r = 1.57079637f - r;
+    if (__builtin_signbit(x)) r = 3.14159274f - r;
+    return __builtin_copysignf(r, y);
+}
+// FM::demod step (src/modulation/analog.rs:27-28) with the fast atan2
+__device__ __forceinline__ float fm_step_fast(float2 x, float2 p) {
+    const float pcr = p.x, pci = -p.y;
+    return fast_atan2f(x.x * pci + x.y * pcr, x.x * pcr - x.y * pci);
+}
+// lane l takes lane l - 1's value, lane 0 keeps `first` (DPP wave_shr:1)
+__device__ __forceinline__ float wave_shr1(float v, float first) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+
 }  // namespace comms
 
 struct comms_fir : comms::Handle {

@@ -39,7 +39,12 @@ namespace comms {
 
 constexpr int P8_S1 = 66;               // exchange 1: row stride (k1), 2 mod 32: the read side's (k1, cg) spread over all banks
 constexpr int P8_BUF = 16 * P8_S1;      // per-wave exchange buffer, in cf
-constexpr int P8_NEW = 768, P8_HALO = 256, P8_OUT = 96;
+// HR halo rows of 64 samples (8 HR positions per phase): branch filters of up to 8 HR + 1 taps, i.e. up to 64 HR + 1 taps of
+// the FIR; the FM demodulator needs one more valid output in front of the segment's first (y[j-1]): 64 HR - 7 taps.
+template <int HR>
+struct P8Geom {
+    static constexpr int HQ = 8 * HR, HALO = 64 * HR, NEW = 1024 - 64 * HR, OUT = 128 - 8 * HR;
+};
 // LDS: G [16][64], forward twiddle [16][8], sin / cos table [64], 16 exchange buffers, ticket
 constexpr int P8_TAB = 1024 + 128 + 64;
 constexpr size_t P8_LDS_BYTES = (P8_TAB + 16 * P8_BUF) * sizeof(float2) + 16;
@@ -130,8 +135,8 @@ __device__ __forceinline__ void poly8_forward(cf (&v)[16], cf* lds, const cf* tw
     p8_lds_sync();
 }
 
-// ... second half: the sum over the phases and the 128-point inverse transform -> ya = z[nu + 32 (1 + (lane >> 5))],
-// yb = z[nu + 96] (nu = lane & 31; output index within the segment: lane for ya, 64 + nu for yb), before the mixer.
+// ... second half: the sum over the phases and the 128-point inverse transform -> ya = z[lane], yb = z[64 + lane], the
+// segment's 128 positions (the first 8 HR of them are its halo), before the mixer.
 __device__ __forceinline__ void poly8_inverse(cf* lds, const P8Lane& lc, int l, cf& ya, cf& yb) {
     const int k1 = l & 15, cg = l >> 4;
     const int j = cg;
@@ -173,11 +178,9 @@ __device__ __forceinline__ void poly8_inverse(cf* lds, const P8Lane& lc, int l, 
     p8_lds_sync();
     cf m0 = lds[r4 * 40 + r8], m1 = lds[r4 * 40 + 8 + r8], m2 = lds[r4 * 40 + 16 + r8], m3 = lds[r4 * 40 + 24 + r8];
     p8_lds_sync();
-    // DFT4 without its output 0 (the halo): z1, z2, z3
-    const cf t0 = cadd(m0, m2), t1 = csub(m0, m2), t2 = cadd(m1, m3), t3 = csub(m1, m3);
-    const cf z1 = cadd_di<1>(t1, t3), z2 = csub(t0, t2), z3 = csub_di<1>(t1, t3);
-    ya = l < 32 ? z1 : z2;
-    yb = z3;
+    radix4<1>(m0, m1, m2, m3);  // z[nu + 32 t], t = 0..3
+    ya = l < 32 ? m0 : m1;
+    yb = l < 32 ? m2 : m3;
 }
 
 // (cos, sin) of 2 pi u / 2^32: a 64-entry table for the upper six bits, a short series for the rest (|error| ~ 1e-7)
@@ -194,11 +197,19 @@ __device__ __forceinline__ cf p8_rotor(unsigned u, const cf* sc) {
     return cmulf(t, cf{cs, sn});
 }
 
-template <class In = const float2*>
-__global__ __launch_bounds__(1024, 4) void fir_poly8_kernel(In in, const float2* __restrict__ hist, int hist_len,
-                                                            float2* __restrict__ out, size_t n, P8Tables tb,
+struct P8Fm {
+    const float2* prev;  // FM.prev before this call (the last decimated sample of the batch before)
+    float2* prev_new;    //   ... and after it
+};
+
+// NT: the rows as nontemporal loads, the outputs as nontemporal stores (batches past the Infinity Cache)
+template <int HR, bool FM, bool NT>
+__global__ __launch_bounds__(1024, 4) void fir_poly8_kernel(const float2* __restrict__ in, const float2* __restrict__ hist,
+                                                            int hist_len, void* __restrict__ out_any, size_t n, P8Tables tb,
                                                             float2* __restrict__ new_hist, unsigned chunk_log2, P8Mix mx,
-                                                            KStamp ks) {
+                                                            P8Fm fmx, KStamp ks) {
+    using Gm = P8Geom<HR>;
+    typedef float nt_f2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     kstamp_begin(ks);
     hist_advance(hist, in, n, new_hist, hist_len);
@@ -223,8 +234,10 @@ __global__ __launch_bounds__(1024, 4) void fir_poly8_kernel(In in, const float2*
     lc.m3 = tb.lane[6 * 64 + l];
     __syncthreads();
 
+    float2* out = static_cast<float2*>(out_any);
+    float* outf = static_cast<float*>(out_any);
     const size_t n_out = n >> 3;
-    const size_t nfull = n / P8_NEW;  // segments whose 768 new samples are all inside `in`
+    const size_t nfull = n / Gm::NEW;  // segments whose new samples are all inside `in`
     const size_t inner = nfull > 1 ? nfull - 1 : 0;
     const bool contiguous = chunk_log2 >= 32u;
     const unsigned G = gridDim.x;
@@ -239,22 +252,46 @@ __global__ __launch_bounds__(1024, 4) void fir_poly8_kernel(In in, const float2*
         const size_t c = static_cast<size_t>(tk >> chunk_log2) * G + wg;
         return 1 + (c << chunk_log2) + (tk & ((1u << chunk_log2) - 1u));
     };
-    // mixer phase of output 96 seg + lane (input sample 8 x that): a scalar part per segment + the lane's own
-    const uint64_t lane_turns = mx.turns0 + static_cast<uint64_t>(8 * l) * mx.frac;
-    const uint64_t seg_turns = static_cast<uint64_t>(P8_NEW) * mx.frac;
+    // Position l of a segment is output OUT seg + l - HQ (ya) and 64 more (yb); its mixer phase is that of input sample
+    // 8 x the output index: a scalar part per segment + the lane's own
+    const uint64_t lane_turns = mx.turns0 + static_cast<uint64_t>(static_cast<long long>(8 * (l - Gm::HQ))) * mx.frac;
+    const uint64_t seg_turns = static_cast<uint64_t>(Gm::NEW) * mx.frac;
     const cf step512 = to_cf(mx.step512);
     auto emit = [&](size_t sg, cf ya, cf yb, bool guard) {
         const uint64_t tl = lane_turns + static_cast<uint64_t>(sg) * seg_turns;
         const cf rot = p8_rotor(static_cast<unsigned>(tl >> 32), sc);
         ya = cmulf(ya, rot);
         yb = cmulf(yb, cmulf_s(rot, step512));
-        const size_t o = sg * P8_OUT + l;
-        if (!guard) {
-            out[o] = to_f2(ya);
-            if (l < 32) out[o + 64] = to_f2(yb);
+        const long long o = static_cast<long long>(sg * Gm::OUT) + l - Gm::HQ;  // ya's output; yb's: o + 64
+        const bool a_on = l >= Gm::HQ && (!guard || static_cast<size_t>(o) < n_out);
+        const bool b_on = !guard || static_cast<size_t>(o + 64) < n_out;
+        if (!FM) {
+            if (NT) {
+                if (a_on) __builtin_nontemporal_store(nt_f2{ya.x, ya.y}, reinterpret_cast<nt_f2*>(out + o));
+                if (b_on) __builtin_nontemporal_store(nt_f2{yb.x, yb.y}, reinterpret_cast<nt_f2*>(out + o + 64));
+            } else {
+                if (a_on) out[o] = to_f2(ya);
+                if (b_on) out[o + 64] = to_f2(yb);
+            }
         } else {
-            if (o < n_out) out[o] = to_f2(ya);
-            if (l < 32 && o + 64 < n_out) out[o + 64] = to_f2(yb);
+            // y[j - 1]: the lane below; position 64's comes from lane 63 of ya.  Position HQ - 1 is a valid output (of the
+            // segment before) whenever the filter leaves one spare halo position, which the launcher guarantees.
+            float cx, cy;
+            asm volatile("s_nop 1\n\tv_readlane_b32 %0, %2, 63\n\tv_readlane_b32 %1, %3, 63" : "=s"(cx), "=s"(cy) : "v"(ya.x), "v"(ya.y));
+            float2 pa = make_float2(wave_shr1(ya.x, 0.f), wave_shr1(ya.y, 0.f));
+            const float2 pb = make_float2(wave_shr1(yb.x, cx), wave_shr1(yb.y, cy));
+            if (guard && o == 0) pa = fmx.prev[0];  // the call's first output: FM.prev of the batch before
+            const float fa = fm_step_fast(to_f2(ya), pa), fb = fm_step_fast(to_f2(yb), pb);
+            if (NT) {
+                if (a_on) __builtin_nontemporal_store(fa, outf + o);
+                if (b_on) __builtin_nontemporal_store(fb, outf + o + 64);
+            } else {
+                if (a_on) outf[o] = fa;
+                if (b_on) outf[o + 64] = fb;
+            }
+            // the call's last output becomes FM.prev
+            if (a_on && static_cast<size_t>(o) + 1 == n_out) fmx.prev_new[0] = to_f2(ya);
+            if (b_on && static_cast<size_t>(o + 64) + 1 == n_out) fmx.prev_new[0] = to_f2(yb);
         }
     };
 
@@ -262,11 +299,11 @@ __global__ __launch_bounds__(1024, 4) void fir_poly8_kernel(In in, const float2*
     // The stream's first segment (halo from the history) and its partial last one: wave 0 of the first / last workgroup,
     // before it joins the ticket loop
     if (wave == 0) {
-        const size_t nseg = (n + P8_NEW - 1) / P8_NEW;
+        const size_t nseg = (n + Gm::NEW - 1) / Gm::NEW;
         for (int e = 0; e < 2; ++e) {
             const size_t sg = e ? nseg - 1 : 0;
             if (e ? (blockIdx.x != gridDim.x - 1 || nseg < 2 || nseg == nfull) : blockIdx.x != 0) continue;
-            const long long b0 = static_cast<long long>(sg * P8_NEW) - P8_HALO + l;
+            const long long b0 = static_cast<long long>(sg * Gm::NEW) - Gm::HALO + l;
 #pragma unroll
             for (int a = 0; a < 16; ++a) v[a] = to_cf(stream_at(in, hist, hist_len, b0 + 64 * a, n));
             poly8_forward(v, lds, tw, gsp, l);
@@ -275,9 +312,16 @@ __global__ __launch_bounds__(1024, 4) void fir_poly8_kernel(In in, const float2*
         }
     }
     auto fetch = [&](size_t sg) {
-        const size_t p = sg * P8_NEW - P8_HALO + l;
+        const size_t p = sg * Gm::NEW - Gm::HALO + l;
 #pragma unroll
-        for (int a = 0; a < 16; ++a) v[a] = to_cf(in[p + 64 * a]);
+        for (int a = 0; a < 16; ++a) {
+            if (NT) {
+                const nt_f2 q = __builtin_nontemporal_load(reinterpret_cast<const nt_f2*>(in) + p + 64 * a);
+                v[a] = cf{q.x, q.y};
+            } else {
+                v[a] = to_cf(in[p + 64 * a]);
+            }
+        }
     };
     // Order within an iteration: forward half of this segment; the STORES of the segment before it; the loads of the
     // next one; inverse half.  vmcnt counts loads and stores in one in-order queue: with the stores issued in front of the
@@ -382,32 +426,78 @@ static comms_status_t poly8_prepare(comms_fir* h, bool pre, uint64_t frac, hipSt
     return COMMS_OK;
 }
 
+namespace {
+
+// Halo rows for (taps, FM demod), or 0 when the kernel cannot run them: 8 HR positions per phase hold the 8 HR + 1 taps of a
+// branch filter; FM demod takes one position more (the output in front of the segment's first).
+int poly8_halo_rows(int n_eff, bool fm) {
+    const int hq = (n_eff - 1 + 7) / 8 + (fm ? 1 : 0);
+    const int hr = hq <= 16 ? 2 : (hq + 7) / 8;
+    return hr <= 4 ? hr : 0;
+}
+
+template <int HR, bool FM, bool NT>
+comms_status_t poly8_launch(comms_fir* h, hipStream_t s, const float2* in, void* out, size_t n, const P8Tables& tb, const P8Mix& mx,
+                            const P8Fm& fmx) {
+    using Gm = P8Geom<HR>;
+    const size_t nseg = (n + Gm::NEW - 1) / Gm::NEW;
+    const size_t want = (nseg + 15) / 16;
+    const dim3 grid(static_cast<unsigned>(want < static_cast<size_t>(kNumCU) ? want : kNumCU));
+    static const int chunk_knob = diag_knob("COMMS_POLY8_CHUNK_LOG2", -1);
+    const unsigned chunk_log2 = chunk_knob >= 0 ? static_cast<unsigned>(chunk_knob) : nseg < 160u * static_cast<size_t>(grid.x) ? 1u : 3u;
+    static DeviceOnce attr_once;
+    if (attr_once.need())
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_poly8_kernel<HR, FM, NT>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(P8_LDS_BYTES)));
+    hipEvent_t ea = nullptr, eb = nullptr;
+    (void)h->take_events(ea, eb);
+    const KStamp ks = h->next_stamp();
+    if (ea)
+        hipExtLaunchKernelGGL((fir_poly8_kernel<HR, FM, NT>), grid, dim3(1024), static_cast<uint32_t>(P8_LDS_BYTES), s, ea, eb, 0u, in,
+                              h->d_hist[h->cur], h->n_eff, out, n, tb, h->d_hist[h->cur ^ 1], chunk_log2, mx, fmx, ks);
+    else
+        fir_poly8_kernel<HR, FM, NT><<<grid, dim3(1024), P8_LDS_BYTES, s>>>(in, h->d_hist[h->cur], h->n_eff, out, n, tb,
+                                                                           h->d_hist[h->cur ^ 1], chunk_log2, mx, fmx, ks);
+    return launch_ok("fir_poly8_kernel");
+}
+
+template <int HR>
+comms_status_t poly8_launch_hr(bool fm, bool nt, comms_fir* h, hipStream_t s, const float2* in, void* out, size_t n, const P8Tables& tb,
+                               const P8Mix& mx, const P8Fm& fmx) {
+    if (fm) return nt ? poly8_launch<HR, true, true>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<HR, true, false>(h, s, in, out, n, tb, mx, fmx);
+    return nt ? poly8_launch<HR, false, true>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<HR, false, false>(h, s, in, out, n, tb, mx, fmx);
+}
+
+}  // namespace
+
 extern "C" {
 
-// 1: this chain (taps, rate, stages, batch) runs on the polyphase frequency-domain kernel
+// 0: no; 1: this chain (taps, rate, stages, batch) can run on the polyphase frequency-domain kernel; 2: and it is the faster form
 int32_t comms_fir_poly8_supported(const comms_fir_t* h, uint32_t rate, int32_t mode, size_t n) {
-    if (!h || rate != 8 || h->n_eff < 1 || h->n_eff > 257 || h->in_fmt != COMMS_IQ_C32 || h->no_poly8) return 0;
-    if (!(mode & COMMS_CHAIN_DEC) || (mode & COMMS_CHAIN_FM)) return 0;
+    if (!h || rate != 8 || h->n_eff < 1 || h->in_fmt != COMMS_IQ_C32 || n < 8) return 0;
+    if (!(mode & COMMS_CHAIN_DEC) || !poly8_halo_rows(h->n_eff, (mode & COMMS_CHAIN_FM) != 0)) return 0;
     static const int knob = diag_knob("COMMS_POLY8", 1);          // 0: never, 1: where it wins, 2: wherever it can run
     static const int min_taps = diag_knob("COMMS_POLY8_MIN_TAPS", 130);
-    static const int min_log2 = diag_knob("COMMS_POLY8_MIN_LOG2", 22);
-    if (!knob) return 0;
-    if (knob == 2) return n >= 8 ? 1 : 0;
-    return h->n_eff >= min_taps && n >= (static_cast<size_t>(1) << min_log2) ? 1 : 0;
+    static const int min_log2 = diag_knob("COMMS_POLY8_MIN_LOG2", 20);
+    if (!knob || h->no_poly8) return 0;
+    if (knob == 2) return 2;
+    return h->n_eff >= min_taps && n >= (static_cast<size_t>(1) << min_log2) ? 2 : 1;
 }
 
 comms_status_t comms_fir_run_poly8_dev(comms_fir_t* h, const void* d_in, size_t n, void* d_out, int32_t mode,
-                                       uint64_t turns0, uint64_t frac, void* stream) {
+                                       uint64_t turns0, uint64_t frac, const void* fm_prev, void* fm_prev_new, void* stream) {
     COMMS_ARG(h != nullptr, "handle is NULL");
     COMMS_ARG((d_in && d_out) || !n, "NULL device pointer");
     COMMS_ARG(n % 8 == 0, "n must be a multiple of the decimation rate");
-    COMMS_ARG(h->n_eff <= 257 && h->in_fmt == COMMS_IQ_C32, "the polyphase kernel takes <= 257 taps and Complex<f32> input");
-    COMMS_ARG((mode & COMMS_CHAIN_DEC) && !(mode & COMMS_CHAIN_FM) && !((mode & COMMS_CHAIN_PRE) && (mode & COMMS_CHAIN_POST)),
-              "bad chain mode");
+    const bool fm = (mode & COMMS_CHAIN_FM) != 0;
+    const int hr = poly8_halo_rows(h->n_eff, fm);
+    COMMS_ARG(hr != 0 && h->in_fmt == COMMS_IQ_C32, "the polyphase kernel takes <= 257 taps (249 with FM demod) and Complex<f32> input");
+    COMMS_ARG((mode & COMMS_CHAIN_DEC) && !((mode & COMMS_CHAIN_PRE) && (mode & COMMS_CHAIN_POST)), "bad chain mode");
+    COMMS_ARG(!fm || (fm_prev && fm_prev_new), "FM demod needs its state");
     COMMS_TRY(fir_check_sticky(h));
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
-    COMMS_ARG(!ranges_overlap(d_in, n * 8, d_out, n), "the decimating chain cannot run in place");
+    COMMS_ARG(!ranges_overlap(d_in, n * 8, d_out, (n / 8) * (fm ? 4 : 8)), "the decimating chain cannot run in place");
     COMMS_ARG((reinterpret_cast<uintptr_t>(d_in) & 7) == 0, "input must be aligned to one IQ sample");
     hipStream_t s = nullptr;
     COMMS_TRY(h->enter(stream, &s));
@@ -423,27 +513,18 @@ comms_status_t comms_fir_run_poly8_dev(comms_fir_t* h, const void* d_in, size_t 
     double c, sn;
     mix_host_rotor(512u * frac, c, sn);
     mx.step512 = make_float2(static_cast<float>(c), static_cast<float>(sn));
-    const size_t nseg = (n + P8_NEW - 1) / P8_NEW;
-    const size_t want = (nseg + 15) / 16;
-    const dim3 grid(static_cast<unsigned>(want < static_cast<size_t>(kNumCU) ? want : kNumCU));
-    static const int chunk_knob = diag_knob("COMMS_POLY8_CHUNK_LOG2", -1);
-    const unsigned chunk_log2 = chunk_knob >= 0 ? static_cast<unsigned>(chunk_knob) : nseg < 160u * static_cast<size_t>(grid.x) ? 1u : 3u;
-    static DeviceOnce attr_once;
-    if (attr_once.need())
-        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_poly8_kernel<const float2*>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(P8_LDS_BYTES)));
-    hipEvent_t ea = nullptr, eb = nullptr;
-    (void)h->take_events(ea, eb);
-    const KStamp ks = h->next_stamp();
+    P8Fm fmx{static_cast<const float2*>(fm_prev), static_cast<float2*>(fm_prev_new)};
+    // nontemporal rows and outputs once the batch is past what the 256 MiB Infinity Cache can hold for the next kernel
+    static const int nt_knob = diag_knob("COMMS_POLY8_NT", -1);
+    const bool nt = nt_knob >= 0 ? nt_knob != 0 : n * sizeof(float2) > (192u << 20);
     const float2* in = static_cast<const float2*>(d_in);
-    float2* o = static_cast<float2*>(d_out);
-    if (ea)
-        hipExtLaunchKernelGGL((fir_poly8_kernel<const float2*>), grid, dim3(1024), static_cast<uint32_t>(P8_LDS_BYTES), s, ea, eb, 0u,
-                              in, h->d_hist[h->cur], h->n_eff, o, n, tb, h->d_hist[h->cur ^ 1], chunk_log2, mx, ks);
-    else
-        fir_poly8_kernel<const float2*><<<grid, dim3(1024), P8_LDS_BYTES, s>>>(in, h->d_hist[h->cur], h->n_eff, o, n, tb,
-                                                                              h->d_hist[h->cur ^ 1], chunk_log2, mx, ks);
-    COMMS_TRY(launch_ok("fir_poly8_kernel"));
+    comms_status_t st;
+    switch (hr) {
+        case 2: st = poly8_launch_hr<2>(fm, nt, h, s, in, d_out, n, tb, mx, fmx); break;
+        case 3: st = poly8_launch_hr<3>(fm, nt, h, s, in, d_out, n, tb, mx, fmx); break;
+        default: st = poly8_launch_hr<4>(fm, nt, h, s, in, d_out, n, tb, mx, fmx); break;
+    }
+    COMMS_TRY(st);
     h->cur ^= 1;
     return COMMS_OK;
 }
