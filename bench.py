@@ -862,12 +862,12 @@ def run_config2(ctx):
     fused_bytes = 9.0 * n   # 8 B read + 8/8 B written per input sample
     out["fused_chain"] = {"value": round(total / head["fused_elapsed"] / 1e6, 1), "unit": "Msamples/s",
                           "ms_per_step": round(fused_ms, 4), "fused": head["fused"],
-                          "kernel": {"time": "fir_decim_kernel", "freq": "fir_os1024_kernel<.., MODE>",
+                          "kernel": {"time": "fir_decim_kernel", "freq": "fir_os1024_kernel<.., MODE>", "poly": "fir_poly8_kernel",
                                      "unfused": "four kernels"}[head["fused_kernel"]],
                           "roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": fused_bytes,
                                        "achieved": round(fused_bytes / (fused_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": round(fused_bytes / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                       "traffic": pmc_traffic("fir_decim_kernel:fused_chain", n),
+                                       "traffic": pmc_traffic({"poly": "fir_poly8_kernel"}.get(head["fused_kernel"], "fir_decim_kernel") + ":fused_chain", n),
                                        "clock": "step period of the timed loop (one launch per step, back to back)"},
                           "note": "same FIR->mixer->decimate chain as one comms_chain_* launch "
                                   "(8 B read + 1 B written per input sample); not the headline value"}
@@ -990,6 +990,7 @@ def run_config3(ctx):
     if rank != 0:
         return None
     ach = C3_BYTES_PER_SAMPLE * n / (kernel_ms * 1e-3) / 1e9
+    c3_kernel = {"time": "fir_decim_kernel", "poly": "fir_poly8_kernel"}.get(chain.kernel, chain.kernel)  # (after the runs: what they ran on)
     res = {"metric": "Msamples/s Complex<f32> through mixer->127-tap FIR->decimate-by-8->FM demod (BASELINE config 3)",
            "value": round(float(world) * n * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -999,9 +1000,9 @@ def run_config3(ctx):
                                   % int(np.log2(n)),
                       "samples_per_gpu_per_step": n, "kernel": chain.kernel, "prefix_samples": W,
                       "variant": args.variant, "backend": args.backend},
-           "roofline": {"bound": "hbm", "kernel": "fir_decim_kernel" if chain.kernel == "time" else chain.kernel,
+           "roofline": {"bound": "hbm", "kernel": c3_kernel,
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                        "traffic": pmc_traffic("fir_decim_kernel" if chain.kernel == "time" else chain.kernel, n),
+                        "traffic": pmc_traffic(c3_kernel, n),
                         "kernel_ms": round(kernel_ms, 5), "launches_timed": int(kms.size), "timer_stride": TIMER_STRIDE,
                         **in_stream_fields(sms), "algorithmic_bytes_per_launch": C3_BYTES_PER_SAMPLE * n}}
     res["literal_example"] = {"value": round(float(world) * nl * lit_steps / lit_elapsed / 1e6, 1), "unit": "Msamples/s",

@@ -248,7 +248,7 @@ comms_status_t comms_chain_create(double dphase, double phase, const comms_c32* 
 
 comms_status_t comms_chain_is_fused(const comms_chain_t* h, int32_t* out_fused) {
     COMMS_ARG(h && out_fused, "NULL argument");
-    *out_fused = h->fused ? (h->poly8 ? 4 : h->decim_any ? 3 : h->decim ? 2 : 1) : 0;
+    *out_fused = h->fused ? (h->poly8 || (h->decim && h->fir && h->fir->last_poly8) ? 4 : h->decim_any ? 3 : h->decim ? 2 : 1) : 0;
     return COMMS_OK;
 }
 

@@ -201,6 +201,7 @@ struct comms_fir : comms::Handle {
     bool p8_pre = false;        //   ... built for this mixer order and (mixer first: folded into the taps) increment
     uint64_t p8_frac = 0;
     bool no_poly8 = false;      // COMMS_CHAIN_TIME_DOMAIN: the time-domain kernel on every call
+    bool last_poly8 = false;    // the last decimating chain launch of this handle ran fir_poly8_kernel (comms_chain_is_fused)
     // direct form
     int NP = 0;          // taps padded to a multiple of 8
     float2* d_taps_pad = nullptr;

@@ -477,11 +477,14 @@ int32_t comms_fir_poly8_supported(const comms_fir_t* h, uint32_t rate, int32_t m
     if (!h || rate != 8 || h->n_eff < 1 || h->in_fmt != COMMS_IQ_C32 || n < 8) return 0;
     if (!(mode & COMMS_CHAIN_DEC) || !poly8_halo_rows(h->n_eff, (mode & COMMS_CHAIN_FM) != 0)) return 0;
     static const int knob = diag_knob("COMMS_POLY8", 1);          // 0: never, 1: where it wins, 2: wherever it can run
-    static const int min_taps = diag_knob("COMMS_POLY8_MIN_TAPS", 130);
-    static const int min_log2 = diag_knob("COMMS_POLY8_MIN_LOG2", 20);
     if (!knob || h->no_poly8) return 0;
     if (knob == 2) return 2;
-    return h->n_eff >= min_taps && n >= (static_cast<size_t>(1) << min_log2) ? 2 : 1;
+    // Against the time-domain kernels (scripts/sweep_poly8.py, profiles/r05_sweep_poly8.txt: taps x batch length, with and
+    // without FM demod): its time does not depend on the taps -- ahead from 64 taps at every batch length (255 taps: 47 -> 29 us
+    // at 2^24 samples, 12 -> 7 us at 2^14), level with them on shorter filters up to 2^24 samples, 7 % ahead at 2^26.
+    static const int min_taps = diag_knob("COMMS_POLY8_MIN_TAPS", 64);
+    static const int min_log2 = diag_knob("COMMS_POLY8_MIN_LOG2", 25);
+    return h->n_eff >= min_taps || n >= (static_cast<size_t>(1) << min_log2) ? 2 : 1;
 }
 
 comms_status_t comms_fir_run_poly8_dev(comms_fir_t* h, const void* d_in, size_t n, void* d_out, int32_t mode,
@@ -526,6 +529,7 @@ comms_status_t comms_fir_run_poly8_dev(comms_fir_t* h, const void* d_in, size_t 
     }
     COMMS_TRY(st);
     h->cur ^= 1;
+    h->last_poly8 = true;
     return COMMS_OK;
 }
 

@@ -510,7 +510,8 @@ class ChainNode(_Handle):
     def __init__(self, dphase, phase, taps, rate, fm_demod, device=0, mixer_after_fir=False, unfused=False,
                  kernel="auto"):
         """kernel: "auto", "freq" (always the overlap-save kernel), "time" (the decimating
-        time-domain kernel wherever it applies) or "poly" (the polyphase frequency-domain kernel: rate 8, <= 257 taps, no FM)."""
+        time-domain kernel wherever it applies) or "poly" (the polyphase frequency-domain kernel: rate 8, <= 257 taps, 249 with
+        FM demod)."""
         super().__init__()
         taps = _as_c64(taps)
         self.rate, self.fm_demod = int(rate), bool(fm_demod)
@@ -528,7 +529,7 @@ class ChainNode(_Handle):
     @property
     def kernel(self):
         """"unfused", "freq" (fir_os1024_kernel), "time" (fir_decim_kernel), "time_any" (fir_decim_any_kernel) or "poly"
-        (fir_poly8_kernel on every call)."""
+        (fir_poly8_kernel: forced, or what the chain's last call ran on)."""
         f = C.c_int32()
         check(lib().comms_chain_is_fused(self._h, C.byref(f)))
         return ("unfused", "freq", "time", "time_any", "poly")[f.value]

@@ -1,0 +1,184 @@
+"""GPU parity tests of fir_poly8_kernel (csrc/fir_poly8.hip): the rate-8 chains -- BatchFirNode (src/filter/fir.rs:87-102),
+MixerNode (src/mixer.rs:73-85), DecimateNode (src/util/resample_node.rs:53-65) [, FMDemodNode (src/modulation/analog.rs:22-35)]
+in either mixer order -- computed as eight polyphase branches in the frequency domain, against the oracle's nodes in series.
+
+Tolerances as for every other chain kernel (tests/test_gpu_parity.py): a chain's decimated output max|d| <= 2 * 1e-5 * sum|taps| *
+max|x| (FIR error plus the mixer's rounding of it); a demodulated angle <= 1e-4 rad on the circle where both samples it is the
+argument of exceed 0.05 (it is ill-conditioned where the filtered signal is ~0)."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def c():
+    import comms_rs_amd as c
+
+    assert c.device_count() >= 1, "no MI355X visible: the HIP path cannot be tested (no CPU fallback)"
+    return c
+
+
+def rand_c(rng, n):
+    return (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+
+
+def lpf(n_taps, cutoff):
+    k = np.arange(n_taps) - (n_taps - 1) / 2.0
+    return (2 * cutoff * np.sinc(2 * cutoff * k) * np.hamming(n_taps)).astype(np.complex64)
+
+
+def circ(d):
+    return np.abs((d + np.pi) % (2 * np.pi) - np.pi)
+
+
+def chain_close(got, want, taps, x):
+    d = np.abs(got.astype(np.complex128) - want.astype(np.complex128))
+    bound = 2 * TOL * np.sum(np.abs(taps)) * max(np.max(np.abs(x)), 1e-30)
+    assert got.shape == want.shape
+    assert d.max(initial=0.0) <= bound, (d.max(), bound, int(np.argmax(d)))
+
+
+# halo rows by tap count: <= 129 taps two, <= 193 three, <= 257 four; ragged calls cross segment sizes 896 / 832 / 768
+@pytest.mark.parametrize("after", [False, True])
+@pytest.mark.parametrize("n_taps,cplx", [(255, False), (255, True), (257, True), (256, False), (194, False), (193, True), (131, False),
+                                         (130, True), (129, False), (127, False), (65, True), (33, False), (8, True), (1, False)])
+def test_poly8_chain_against_oracle_ragged_calls(c, n_taps, cplx, after):
+    rng = np.random.default_rng(n_taps * 2 + cplx)
+    taps = oracle.rrc_taps(n_taps, 8.0, 0.35) if n_taps > 8 else np.ones(n_taps, np.complex64)
+    if cplx:
+        taps = (taps * np.exp(1j * 0.01 * np.arange(n_taps))).astype(np.complex64)
+    dphase, phase = 2 * np.pi * 0.1, 0.3
+    node = c.ChainNode(dphase, phase, taps, 8, False, mixer_after_fir=after, kernel="poly")
+    assert node.fused and node.kernel == "poly"
+    n = 896 * 37 + 8 * 11
+    x = rand_c(rng, n)
+    ost, om = oracle.default_state(taps), oracle.Mixer(phase, dphase)
+    cuts = [0, 8, 776, 768 * 3, 768 * 3 + 16, 832 * 20 + 8 * 50, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if after:
+            w = oracle.decimate(om.mix(oracle.batch_fir(x[a:b], taps, ost, norotate=True)), 8)
+        else:
+            w = oracle.decimate(oracle.batch_fir(om.mix(x[a:b]), taps, ost, norotate=True), 8)
+        chain_close(node.run(x[a:b]), w, taps, x)
+    # the FIR history is the reference's `state` (newest first), raw samples in either mixer order
+    np.testing.assert_array_equal(node.fir_state(n_taps), x[::-1][:n_taps])
+
+
+@pytest.mark.parametrize("n_taps", [127, 63, 9, 121, 122, 185, 186, 249])
+def test_poly8_fm_chain_against_oracle(c, n_taps):
+    """mixer -> FIR -> /8 -> FM demod (BASELINE config 3's order): the demodulator takes y[j-1] from the lane below, the
+    segment's first output from the halo position in front of it (121 / 185 / 249 taps: the last counts with that spare
+    position), the call's first from FM.prev."""
+    rng = np.random.default_rng(n_taps)
+    taps = lpf(n_taps, 1 / 16.0)
+    n = 896 * 30 + 8 * 7
+    t = np.arange(n)
+    x = (np.exp(1j * (0.02 * t + 3.0 * np.sin(2 * np.pi * t / 5000.0))) * (1 + 0.1 * rng.standard_normal(n))).astype(np.complex64)
+    node = c.ChainNode(0.3, 0.1, taps, 8, True, kernel="poly")
+    assert node.kernel == "poly"
+    ost, om, ofm = oracle.default_state(taps), oracle.Mixer(0.1, 0.3), oracle.FM()
+    cuts = [0, 8, 16, 896, 896 * 3 + 24, 832 * 11, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        y = oracle.decimate(oracle.batch_fir(om.mix(x[a:b]), taps, ost, norotate=True), 8)
+        yp = np.concatenate([[complex(ofm.prev[0]) if a else 1.0], y[:-1]])
+        w = ofm.demod(y)
+        got = node.run(x[a:b])
+        assert got.dtype == np.float32 and got.shape == w.shape
+        ok = np.minimum(np.abs(y), np.abs(yp)) > 0.05
+        assert ok.mean() > 0.9 or b - a < 8 * 200  # (the zero-state start of the stream: the filter has not filled yet)
+        assert np.max(circ(got.astype(np.float64) - w)[ok], initial=0.0) <= 1e-4
+    p = node.fm_prev
+    assert abs(complex(p) - complex(y[-1])) <= 2 * TOL * np.sum(np.abs(taps)) * np.max(np.abs(x))
+
+
+def test_poly8_where_it_runs(c):
+    t255, t127, t31 = lpf(255, 0.05), lpf(127, 0.05), lpf(31, 0.05)
+    assert c.ChainNode(0.3, 0.1, t255, 8, False, kernel="poly").kernel == "poly"
+    assert c.ChainNode(0.3, 0.1, lpf(249, 0.05), 8, True, kernel="poly").kernel == "poly"
+    # no spare halo position for the demodulator / more than 257 taps / another rate: the flag asks, the chain falls back
+    assert c.ChainNode(0.3, 0.1, lpf(250, 0.05), 8, True, kernel="poly").kernel != "poly"
+    assert c.ChainNode(0.3, 0.1, lpf(300, 0.05), 8, False, kernel="poly").kernel != "poly"
+    assert c.ChainNode(0.3, 0.1, t127, 4, False, kernel="poly").kernel != "poly"
+    rng = np.random.default_rng(3)
+    x = rand_c(rng, 8 * 4096)
+    # a chain of kind "time" at rate 8: from 64 taps every call runs on the polyphase kernel, and says so afterwards
+    for taps, fm, want in [(t255, False, "poly"), (t127, True, "poly"), (t31, False, "time")]:
+        node = c.ChainNode(0.3, 0.1, taps, 8, fm)
+        assert node.kernel == "time"
+        node.run(x)
+        assert node.kernel == want
+    node = c.ChainNode(0.3, 0.1, t255, 8, False, kernel="time")  # forced: the time-domain kernel on every call
+    node.run(x)
+    assert node.kernel == "time"
+    node = c.ChainNode(0.3, 0.1, t255, 8, False).set_input_format("i16", 1.0 / 32768)  # raw formats stay on the time-domain kernel
+    node.run((rng.integers(-2000, 2000, 2 * 8 * 512)).astype(np.int16))
+    assert node.kernel == "time"
+    with pytest.raises(c.CommsError):
+        c.ChainNode(0.3, 0.1, t255, 8, False, kernel="poly").run(x[:12])  # n not a multiple of the rate
+
+
+@pytest.mark.parametrize("fm", [False, True])
+def test_poly8_short_calls_and_single_outputs(c, fm):
+    """Calls of one output (8 samples), of less than a segment, of exactly one segment: the guarded first / last segments."""
+    rng = np.random.default_rng(11)
+    taps = lpf(201, 0.05)
+    x = rand_c(rng, 8 * 700)
+    node = c.ChainNode(0.2, 0.0, taps, 8, fm, kernel="poly")
+    ref = c.ChainNode(0.2, 0.0, taps, 8, fm, kernel="freq")
+    cref = c.ChainNode(0.2, 0.0, taps, 8, False, kernel="freq")  # the decimated filter output the angles are arguments of
+    pos, last = 0, 0j
+    for m in (8, 8, 16, 768, 776, 760, 8, 1536, 8 * 100):
+        a, b, y = node.run(x[pos:pos + m]), ref.run(x[pos:pos + m]), cref.run(x[pos:pos + m])
+        pos += m
+        if fm:
+            mag = np.minimum(np.abs(y), np.abs(np.concatenate([[last], y[:-1]])))
+            last = y[-1]
+            bound = 4 * TOL * np.sum(np.abs(taps)) * np.max(np.abs(x))  # conditioned: error of the angle x the smaller magnitude
+            assert np.max(circ(a.astype(np.float64) - b) * mag) <= bound
+        else:
+            chain_close(a, b, taps, x)
+    assert pos <= x.size
+
+
+def test_poly8_is_deterministic_and_matches_the_time_kernel_at_2p24(c):
+    """Segments are drawn from a ticket counter in whatever order the waves arrive: the outputs do not depend on it."""
+    import torch
+
+    n = 1 << 24
+    x = torch.empty(n, dtype=torch.complex64, device="cuda:0")
+    c.synth_iq_dev(x.data_ptr(), n, 0)
+    taps = oracle.rrc_taps(255, 8.0, 0.35)
+    s = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for kern in ("poly", "poly", "time"):
+        node = c.ChainNode(2 * np.pi * 0.05, 0.1, taps, 8, False, mixer_after_fir=True, kernel=kern)
+        o = torch.empty(n // 8, dtype=torch.complex64, device="cuda:0")
+        node.run_dev(x.data_ptr(), n, o.data_ptr(), s)
+        torch.cuda.synchronize()
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+    d = (outs[0] - outs[2]).abs().max().item()
+    assert d <= 2 * TOL * np.sum(np.abs(taps)) * x[: 1 << 20].abs().max().item()
+
+
+def test_poly8_shard_continues_its_left_neighbour(c):
+    """A stream cut in two: the right half's node starts from the left half's FIR history and oscillator phase (and FM.prev)
+    and reproduces the single node's outputs (another segmentation: within the tolerance, not bit for bit)."""
+    rng = np.random.default_rng(5)
+    taps = lpf(255, 0.05)
+    n = 8 * 6000
+    x = rand_c(rng, n)
+    whole = c.ChainNode(0.25, 0.4, taps, 8, False, mixer_after_fir=True, kernel="poly").run(x)
+    cut = 8 * 2500
+    left = c.ChainNode(0.25, 0.4, taps, 8, False, mixer_after_fir=True, kernel="poly")
+    yl = left.run(x[:cut])
+    right = c.ChainNode(0.25, 0.0, taps, 8, False, mixer_after_fir=True, kernel="poly")
+    right.set_fir_state(x[:cut][::-1][:255])
+    right.phase = left.phase
+    yr = right.run(x[cut:])
+    chain_close(np.concatenate([yl, yr]), whole, taps, x)
