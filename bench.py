@@ -1406,9 +1406,10 @@ def main():
     if args.config == 1 and args.steps == 1000 and args.warmup == 50:
         args.steps, args.warmup = 200, 20
     elif args.config in (3, 5) and args.steps == 1000 and args.warmup == 50:
-        # steps of 0.15 / 0.6 ms: long enough a run to be past the chip's start-up clock transient (launches 4-25 of a
-        # burst run up to 40 % slower, profiles/r03_config5_kernel_trace.txt), short enough for a default run
-        args.steps, args.warmup = 200, 40
+        # steps of 0.11 / 0.6 ms: a warm-up as long as the chip's start-up clock transient (about 25 ms: the launches of the
+        # second to twentieth millisecond of a burst run up to 40 % slower, profiles/r03_config5_kernel_trace.txt,
+        # r05_config3_poly8_launch_order.txt), short enough for a default run
+        args.steps, args.warmup = 200, (200 if args.config == 3 else 40)
     elif args.config != 2 and args.steps == 1000 and args.warmup == 50:
         args.steps, args.warmup = 20, 3   # config 4's steps are 31 ms each
 
