@@ -268,7 +268,7 @@ comms_status_t comms_chain_run_dev(comms_chain_t* h, const comms_c32* d_in_any, 
     hipStream_t hs = nullptr;
     COMMS_TRY(h->enter(stream, &hs));  // the stages' state (history, prev) advances in stream order
     void* s = static_cast<void*>(hs);
-    if (h->in_fmt != COMMS_IQ_C32 && !(h->fused && (h->decim || h->decim_any))) {
+    if (h->in_fmt != COMMS_IQ_C32 && !(h->fused && (h->decim || h->decim_any || h->poly8))) {
         // only the time-domain kernel reads wire formats in its load stage; everything else gets one
         // conversion pass first (same arithmetic, iqformat.hip)
         COMMS_TRY(h->t0.reserve(n * sizeof(comms_c32)));
@@ -362,7 +362,7 @@ comms_status_t comms_chain_set_input_format(comms_chain_t* h, int32_t format, fl
     COMMS_ARG(format != COMMS_IQ_I16 || std::isfinite(scale), "scale must be finite");
     h->in_fmt = format;
     h->in_scale = format == COMMS_IQ_I16 ? scale : 1.0f;
-    if (h->fused && (h->decim || h->decim_any)) COMMS_TRY(comms_fir_set_input_format(h->fir, format, scale));
+    if (h->fused && (h->decim || h->decim_any || h->poly8)) COMMS_TRY(comms_fir_set_input_format(h->fir, format, scale));
     return COMMS_OK;
 }
 

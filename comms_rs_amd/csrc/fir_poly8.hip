@@ -202,14 +202,15 @@ struct P8Fm {
     float2* prev_new;    //   ... and after it
 };
 
-// NT: the rows as nontemporal loads, the outputs as nontemporal stores (batches past the Infinity Cache)
-template <int HR, bool FM, bool NT>
-__global__ __launch_bounds__(1024, 4) void fir_poly8_kernel(const float2* __restrict__ in, const float2* __restrict__ hist,
+// (Nontemporal rows and outputs, which help the wave-private time-domain kernel, were measured here and dropped: level at 2^26
+// samples, 6 % slower at 2^25 -- a segment's halo rows are its neighbour's rows, and plain loads leave them in L2.)
+// In: Complex<f32>, or raw i16 / u8 IQ converted in the load stage with iqformat.hip's arithmetic (fir_handle.hpp).
+template <int HR, bool FM, class In>
+__global__ __launch_bounds__(1024, 4) void fir_poly8_kernel(In in, const float2* __restrict__ hist,
                                                             int hist_len, void* __restrict__ out_any, size_t n, P8Tables tb,
                                                             float2* __restrict__ new_hist, unsigned chunk_log2, P8Mix mx,
                                                             P8Fm fmx, KStamp ks) {
     using Gm = P8Geom<HR>;
-    typedef float nt_f2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     kstamp_begin(ks);
     hist_advance(hist, in, n, new_hist, hist_len);
@@ -266,13 +267,8 @@ __global__ __launch_bounds__(1024, 4) void fir_poly8_kernel(const float2* __rest
         const bool a_on = l >= Gm::HQ && (!guard || static_cast<size_t>(o) < n_out);
         const bool b_on = !guard || static_cast<size_t>(o + 64) < n_out;
         if (!FM) {
-            if (NT) {
-                if (a_on) __builtin_nontemporal_store(nt_f2{ya.x, ya.y}, reinterpret_cast<nt_f2*>(out + o));
-                if (b_on) __builtin_nontemporal_store(nt_f2{yb.x, yb.y}, reinterpret_cast<nt_f2*>(out + o + 64));
-            } else {
-                if (a_on) out[o] = to_f2(ya);
-                if (b_on) out[o + 64] = to_f2(yb);
-            }
+            if (a_on) out[o] = to_f2(ya);
+            if (b_on) out[o + 64] = to_f2(yb);
         } else {
             // y[j - 1]: the lane below; position 64's comes from lane 63 of ya.  Position HQ - 1 is a valid output (of the
             // segment before) whenever the filter leaves one spare halo position, which the launcher guarantees.
@@ -282,13 +278,8 @@ __global__ __launch_bounds__(1024, 4) void fir_poly8_kernel(const float2* __rest
             const float2 pb = make_float2(wave_shr1(yb.x, cx), wave_shr1(yb.y, cy));
             if (guard && o == 0) pa = fmx.prev[0];  // the call's first output: FM.prev of the batch before
             const float fa = fm_step_fast(to_f2(ya), pa), fb = fm_step_fast(to_f2(yb), pb);
-            if (NT) {
-                if (a_on) __builtin_nontemporal_store(fa, outf + o);
-                if (b_on) __builtin_nontemporal_store(fb, outf + o + 64);
-            } else {
-                if (a_on) outf[o] = fa;
-                if (b_on) outf[o + 64] = fb;
-            }
+            if (a_on) outf[o] = fa;
+            if (b_on) outf[o + 64] = fb;
             // the call's last output becomes FM.prev
             if (a_on && static_cast<size_t>(o) + 1 == n_out) fmx.prev_new[0] = to_f2(ya);
             if (b_on && static_cast<size_t>(o + 64) + 1 == n_out) fmx.prev_new[0] = to_f2(yb);
@@ -314,14 +305,7 @@ __global__ __launch_bounds__(1024, 4) void fir_poly8_kernel(const float2* __rest
     auto fetch = [&](size_t sg) {
         const size_t p = sg * Gm::NEW - Gm::HALO + l;
 #pragma unroll
-        for (int a = 0; a < 16; ++a) {
-            if (NT) {
-                const nt_f2 q = __builtin_nontemporal_load(reinterpret_cast<const nt_f2*>(in) + p + 64 * a);
-                v[a] = cf{q.x, q.y};
-            } else {
-                v[a] = to_cf(in[p + 64 * a]);
-            }
-        }
+        for (int a = 0; a < 16; ++a) v[a] = to_cf(in[p + 64 * a]);
     };
     // Order within an iteration: forward half of this segment; the STORES of the segment before it; the loads of the
     // next one; inverse half.  vmcnt counts loads and stores in one in-order queue: with the stores issued in front of the
@@ -436,8 +420,8 @@ int poly8_halo_rows(int n_eff, bool fm) {
     return hr <= 4 ? hr : 0;
 }
 
-template <int HR, bool FM, bool NT>
-comms_status_t poly8_launch(comms_fir* h, hipStream_t s, const float2* in, void* out, size_t n, const P8Tables& tb, const P8Mix& mx,
+template <int HR, bool FM, class In>
+comms_status_t poly8_launch(comms_fir* h, hipStream_t s, In in, void* out, size_t n, const P8Tables& tb, const P8Mix& mx,
                             const P8Fm& fmx) {
     using Gm = P8Geom<HR>;
     const size_t nseg = (n + Gm::NEW - 1) / Gm::NEW;
@@ -447,25 +431,28 @@ comms_status_t poly8_launch(comms_fir* h, hipStream_t s, const float2* in, void*
     const unsigned chunk_log2 = chunk_knob >= 0 ? static_cast<unsigned>(chunk_knob) : nseg < 160u * static_cast<size_t>(grid.x) ? 1u : 3u;
     static DeviceOnce attr_once;
     if (attr_once.need())
-        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_poly8_kernel<HR, FM, NT>),
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_poly8_kernel<HR, FM, In>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(P8_LDS_BYTES)));
     hipEvent_t ea = nullptr, eb = nullptr;
     (void)h->take_events(ea, eb);
     const KStamp ks = h->next_stamp();
     if (ea)
-        hipExtLaunchKernelGGL((fir_poly8_kernel<HR, FM, NT>), grid, dim3(1024), static_cast<uint32_t>(P8_LDS_BYTES), s, ea, eb, 0u, in,
+        hipExtLaunchKernelGGL((fir_poly8_kernel<HR, FM, In>), grid, dim3(1024), static_cast<uint32_t>(P8_LDS_BYTES), s, ea, eb, 0u, in,
                               h->d_hist[h->cur], h->n_eff, out, n, tb, h->d_hist[h->cur ^ 1], chunk_log2, mx, fmx, ks);
     else
-        fir_poly8_kernel<HR, FM, NT><<<grid, dim3(1024), P8_LDS_BYTES, s>>>(in, h->d_hist[h->cur], h->n_eff, out, n, tb,
+        fir_poly8_kernel<HR, FM, In><<<grid, dim3(1024), P8_LDS_BYTES, s>>>(in, h->d_hist[h->cur], h->n_eff, out, n, tb,
                                                                            h->d_hist[h->cur ^ 1], chunk_log2, mx, fmx, ks);
     return launch_ok("fir_poly8_kernel");
 }
 
-template <int HR>
-comms_status_t poly8_launch_hr(bool fm, bool nt, comms_fir* h, hipStream_t s, const float2* in, void* out, size_t n, const P8Tables& tb,
+template <class In>
+comms_status_t poly8_launch_in(int hr, bool fm, comms_fir* h, hipStream_t s, In in, void* out, size_t n, const P8Tables& tb,
                                const P8Mix& mx, const P8Fm& fmx) {
-    if (fm) return nt ? poly8_launch<HR, true, true>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<HR, true, false>(h, s, in, out, n, tb, mx, fmx);
-    return nt ? poly8_launch<HR, false, true>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<HR, false, false>(h, s, in, out, n, tb, mx, fmx);
+    switch (hr) {
+        case 2: return fm ? poly8_launch<2, true, In>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<2, false, In>(h, s, in, out, n, tb, mx, fmx);
+        case 3: return fm ? poly8_launch<3, true, In>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<3, false, In>(h, s, in, out, n, tb, mx, fmx);
+        default: return fm ? poly8_launch<4, true, In>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<4, false, In>(h, s, in, out, n, tb, mx, fmx);
+    }
 }
 
 }  // namespace
@@ -474,7 +461,7 @@ extern "C" {
 
 // 0: no; 1: this chain (taps, rate, stages, batch) can run on the polyphase frequency-domain kernel; 2: and it is the faster form
 int32_t comms_fir_poly8_supported(const comms_fir_t* h, uint32_t rate, int32_t mode, size_t n) {
-    if (!h || rate != 8 || h->n_eff < 1 || h->in_fmt != COMMS_IQ_C32 || n < 8) return 0;
+    if (!h || rate != 8 || h->n_eff < 1 || n < 8) return 0;
     if (!(mode & COMMS_CHAIN_DEC) || !poly8_halo_rows(h->n_eff, (mode & COMMS_CHAIN_FM) != 0)) return 0;
     static const int knob = diag_knob("COMMS_POLY8", 1);          // 0: never, 1: where it wins, 2: wherever it can run
     if (!knob || h->no_poly8) return 0;
@@ -494,14 +481,15 @@ comms_status_t comms_fir_run_poly8_dev(comms_fir_t* h, const void* d_in, size_t 
     COMMS_ARG(n % 8 == 0, "n must be a multiple of the decimation rate");
     const bool fm = (mode & COMMS_CHAIN_FM) != 0;
     const int hr = poly8_halo_rows(h->n_eff, fm);
-    COMMS_ARG(hr != 0 && h->in_fmt == COMMS_IQ_C32, "the polyphase kernel takes <= 257 taps (249 with FM demod) and Complex<f32> input");
+    COMMS_ARG(hr != 0, "the polyphase kernel takes <= 257 taps (249 with FM demod)");
     COMMS_ARG((mode & COMMS_CHAIN_DEC) && !((mode & COMMS_CHAIN_PRE) && (mode & COMMS_CHAIN_POST)), "bad chain mode");
     COMMS_ARG(!fm || (fm_prev && fm_prev_new), "FM demod needs its state");
     COMMS_TRY(fir_check_sticky(h));
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
-    COMMS_ARG(!ranges_overlap(d_in, n * 8, d_out, (n / 8) * (fm ? 4 : 8)), "the decimating chain cannot run in place");
-    COMMS_ARG((reinterpret_cast<uintptr_t>(d_in) & 7) == 0, "input must be aligned to one IQ sample");
+    const size_t in_elem = h->in_fmt == COMMS_IQ_I16 ? 4 : h->in_fmt == COMMS_IQ_U8 ? 2 : 8;
+    COMMS_ARG(!ranges_overlap(d_in, n * in_elem, d_out, (n / 8) * (fm ? 4 : 8)), "the decimating chain cannot run in place");
+    COMMS_ARG((reinterpret_cast<uintptr_t>(d_in) & (in_elem - 1)) == 0, "input must be aligned to one IQ sample");
     hipStream_t s = nullptr;
     COMMS_TRY(h->enter(stream, &s));
     COMMS_TRY(poly8_prepare(h, (mode & COMMS_CHAIN_PRE) != 0, frac, s));
@@ -517,16 +505,13 @@ comms_status_t comms_fir_run_poly8_dev(comms_fir_t* h, const void* d_in, size_t 
     mix_host_rotor(512u * frac, c, sn);
     mx.step512 = make_float2(static_cast<float>(c), static_cast<float>(sn));
     P8Fm fmx{static_cast<const float2*>(fm_prev), static_cast<float2*>(fm_prev_new)};
-    // nontemporal rows and outputs once the batch is past what the 256 MiB Infinity Cache can hold for the next kernel
-    static const int nt_knob = diag_knob("COMMS_POLY8_NT", -1);
-    const bool nt = nt_knob >= 0 ? nt_knob != 0 : n * sizeof(float2) > (192u << 20);
-    const float2* in = static_cast<const float2*>(d_in);
     comms_status_t st;
-    switch (hr) {
-        case 2: st = poly8_launch_hr<2>(fm, nt, h, s, in, d_out, n, tb, mx, fmx); break;
-        case 3: st = poly8_launch_hr<3>(fm, nt, h, s, in, d_out, n, tb, mx, fmx); break;
-        default: st = poly8_launch_hr<4>(fm, nt, h, s, in, d_out, n, tb, mx, fmx); break;
-    }
+    if (h->in_fmt == COMMS_IQ_I16)
+        st = poly8_launch_in(hr, fm, h, s, InI16{static_cast<const short2*>(d_in), h->in_scale}, d_out, n, tb, mx, fmx);
+    else if (h->in_fmt == COMMS_IQ_U8)
+        st = poly8_launch_in(hr, fm, h, s, InU8{static_cast<const uchar2*>(d_in)}, d_out, n, tb, mx, fmx);
+    else
+        st = poly8_launch_in(hr, fm, h, s, static_cast<const float2*>(d_in), d_out, n, tb, mx, fmx);
     COMMS_TRY(st);
     h->cur ^= 1;
     h->last_poly8 = true;

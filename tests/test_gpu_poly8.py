@@ -115,9 +115,9 @@ def test_poly8_where_it_runs(c):
     node = c.ChainNode(0.3, 0.1, t255, 8, False, kernel="time")  # forced: the time-domain kernel on every call
     node.run(x)
     assert node.kernel == "time"
-    node = c.ChainNode(0.3, 0.1, t255, 8, False).set_input_format("i16", 1.0 / 32768)  # raw formats stay on the time-domain kernel
-    node.run((rng.integers(-2000, 2000, 2 * 8 * 512)).astype(np.int16))
-    assert node.kernel == "time"
+    node = c.ChainNode(0.3, 0.1, t255, 8, False).set_input_format("i16", 1.0 / 32768)  # raw formats: converted in its load stage
+    node.run((rng.integers(-2000, 2000, (8 * 512, 2))).astype(np.int16))
+    assert node.kernel == "poly"
     with pytest.raises(c.CommsError):
         c.ChainNode(0.3, 0.1, t255, 8, False, kernel="poly").run(x[:12])  # n not a multiple of the rate
 
@@ -182,3 +182,37 @@ def test_poly8_shard_continues_its_left_neighbour(c):
     right.phase = left.phase
     yr = right.run(x[cut:])
     chain_close(np.concatenate([yl, yr]), whole, taps, x)
+
+
+@pytest.mark.parametrize("fm,n_taps", [(False, 255), (True, 127), (False, 100)])
+@pytest.mark.parametrize("fmt", ["i16", "u8"])
+def test_poly8_reads_raw_iq(c, fmt, fm, n_taps):
+    """Raw i16 / u8 IQ (src/io/raw_iq.rs:16,50-51; the RTL-SDR bytes of examples/fm_radio.rs:82-90) into the polyphase kernel:
+    converted in its load stage with iqformat.hip's arithmetic, so bit for bit what the same chain makes of the converted
+    samples, in ragged calls (guarded first / last segments included); and the oracle's convert -> nodes in series."""
+    idx = np.arange(8 * 9000, dtype=np.float64)
+    z = np.exp(1j * (-2 * np.pi * 0.05 * idx + 8.0 * np.cos(2 * np.pi * idx / 4096)))
+    if fmt == "u8":
+        raw = np.stack([np.clip(np.rint(z.real * 100 + 127.5), 0, 255), np.clip(np.rint(z.imag * 100 + 127.5), 0, 255)], 1).astype(np.uint8)
+        raw[:256, 0], raw[:256, 1] = np.arange(256), np.arange(256)[::-1]
+        x = oracle.iq_u8_to_c32(raw)
+    else:
+        raw = np.stack([np.rint(z.real * 8192), np.rint(z.imag * 8192)], 1).astype(np.int16)
+        raw[:4] = [[-32768, 32767], [0, -1], [1, 0], [12345, -12345]]
+        x = oracle.iq_i16_to_c32(raw, 1.0 / 8192)
+    n = x.size
+    taps = lpf(n_taps, 1 / 16.0)
+    a = c.ChainNode(0.05, 0.3, taps, 8, fm, kernel="poly").set_input_format(fmt, 1.0 / 8192)
+    b = c.ChainNode(0.05, 0.3, taps, 8, fm, kernel="poly")
+    assert a.kernel == "poly" and b.kernel == "poly"
+    cuts = [0, 8, 8 * 700, 8 * 701, n]
+    got = np.concatenate([a.run(raw[p:q]) for p, q in zip(cuts[:-1], cuts[1:])])
+    ref = np.concatenate([b.run(x[p:q]) for p, q in zip(cuts[:-1], cuts[1:])])
+    assert np.array_equal(got, ref)
+    y = oracle.decimate(oracle.batch_fir(oracle.Mixer(0.3, 0.05).mix(x), taps, oracle.default_state(taps), norotate=True), 8)
+    if fm:
+        want = oracle.FM().demod(y)
+        mag = np.minimum(np.abs(y), np.abs(np.concatenate([[0.0], y[:-1]])))
+        assert np.max((circ(got.astype(np.float64) - want) * mag)[n_taps // 8 + 2:]) <= 4 * TOL * np.sum(np.abs(taps)) * np.max(np.abs(x))
+    else:
+        chain_close(got, y, taps, x)
