@@ -723,6 +723,9 @@ __global__ __launch_bounds__(64 * WPB, MINW) void fir_os1024_kernel(In in,
 // (Loading the NEXT segment's rows into spare registers before transforming this one -- the wait
 // then sits after the 16 - HR stores as a counted vmcnt -- was measured too: 3 us SLOWER at 2^24,
 // the 32 register moves per segment cost more than the covered latency.)
+#ifndef COMMS_OS1024_PREFETCH
+#define COMMS_OS1024_PREFETCH 0  // trial (round 5, second form): measured level or slower, see the loop
+#endif
 template <int HR, bool TRACE, class In = const float2*>
 __global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(In in,
                                                                  const float2* __restrict__ hist, int hist_len,
@@ -807,6 +810,36 @@ __global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(In in,
             ++count;
         }
     }
+#if COMMS_OS1024_PREFETCH
+    // TRIAL, not the product (-DCOMMS_OS1024_PREFETCH=1; scripts/build_variant.sh + ab_libs.py).  Two register sets taking
+    // turns (the kernel needs ~64 of the 128 VGPRs its sixteen waves per CU may have): the NEXT segment's rows are requested
+    // before this one is transformed, so a wave's own load latency leaves its critical path; those loads are OLDER than this
+    // segment's twelve stores in the in-order vmcnt queue, so the wait for them leaves the stores in flight; no register
+    // moves (round 1's attempt kept one set and moved the prefetched rows into it: 3 us slower).  Measured, the two builds
+    // alternating launch by launch: 255 taps 2^22 19.5 -> 20.8 us, 2^24 50.0 -> 52.1, 2^26 206.3 -> 206.5, 2^28 801 -> 805; 127
+    // taps 2^24 47.6 -> 49.2.  The same reordering is worth 9 % on fir_poly8_kernel, whose waves are short of work while they
+    // wait; this kernel's four waves per SIMD already cover each other's loads -- what bounds it is what the memory system
+    // gives its 1.33x-overlapped read stream and its write stream together (NOTES.md).
+    cf w[16];
+    auto finish = [&](size_t sg, cf (&r)[16]) {
+        os1024_core(r, lds, tw1, hsp, tw2, l, nostamp);
+        float2* o = out + sg * WVK + l;
+#pragma unroll
+        for (int a = HR; a < 16; ++a) o[64 * (a - HR)] = to_f2(r[R16_POS(a)]);
+        ++count;
+    };
+    size_t seg = draw();
+    if (seg < hi) fetch(seg, v);
+    while (seg < hi) {
+        const size_t s1 = draw();
+        if (s1 < hi) fetch(s1, w);
+        finish(seg, v);
+        if (!(s1 < hi)) break;
+        seg = draw();
+        if (seg < hi) fetch(seg, v);
+        finish(s1, w);
+    }
+#else
     size_t seg = draw();
     while (seg < hi) {
         fetch(seg, v);
@@ -818,6 +851,7 @@ __global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(In in,
         seg = seg_next;
         ++count;
     }
+#endif
 
     if (TRACE) trace.write(trace_buf, blockIdx.x * 16 + wave, l, count);
     kstamp_end(ks);
