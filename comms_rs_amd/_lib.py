@@ -135,6 +135,16 @@ _PROTOS = {
     "comms_fft_run": [_vp, _vp, _sz, _vp],
     "comms_fft_run_dev": [_vp, _vp, _sz, _vp, _vp],
     "comms_fft_destroy": [_vp],
+    "comms_fft_f64_create": [_sz, _i32, _i32, _pp],
+    "comms_fft_f64_run": [_vp, _vp, _sz, _vp],
+    "comms_fft_f64_run_dev": [_vp, _vp, _sz, _vp, _vp],
+    "comms_fft_f64_destroy": [_vp],
+    "comms_fmdemod_f64_create": [_i32, _pp],
+    "comms_fmdemod_f64_run": [_vp, _vp, _sz, _vp],
+    "comms_fmdemod_f64_run_dev": [_vp, _vp, _sz, _vp, _vp],
+    "comms_fmdemod_f64_get_prev": [_vp, _vp],
+    "comms_fmdemod_f64_set_prev": [_vp, _vp],
+    "comms_fmdemod_f64_destroy": [_vp],
     "comms_rrc_taps": [_u32, _f64, _f64, _vp],
     "comms_rc_taps": [_u32, _f64, _f64, _vp],
     "comms_gaussian_taps": [_u32, _f64, _f64, _vp],

@@ -574,6 +574,54 @@ private:
     comms_fft_t* h_ = nullptr;
 };
 
+// FFTBatchNode<f64> (the instantiation of the reference's doc examples, fft_node.rs:24) and FMDemodNode<f64>
+// (analog_node.rs:20 with T = f64): plain FP64 kernels, correct to f64 rounding (comms_fft_f64_*, comms_fmdemod_f64_*)
+class FFTBatchNodeF64 : public DeriveNode<FFTBatchNodeF64> {
+public:
+    NodeReceiver<std::vector<Complex64>> input;
+    NodeSender<std::vector<Complex64>> output;
+
+    FFTBatchNodeF64(size_t fft_size, bool ifft, int device = 0) {
+        throw_on(comms_fft_f64_create(fft_size, ifft ? 1 : 0, device, &h_), "FFTBatchNode<f64>::new");
+    }
+    FFTBatchNodeF64(FFTBatchNodeF64&& o) noexcept : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_) { o.h_ = nullptr; }
+    ~FFTBatchNodeF64() { comms_fft_f64_destroy(h_); }
+
+    Result<std::vector<Complex64>> run(const std::vector<Complex64>& data) {
+        std::vector<Complex64> out(data.size());
+        comms_status_t st = comms_fft_f64_run(h_, c64(data.data()), data.size(), c64(out.data()));
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_fft_f64_t* h_ = nullptr;
+};
+
+class FMDemodNodeF64 : public DeriveNode<FMDemodNodeF64> {
+public:
+    NodeReceiver<std::vector<Complex64>> input;
+    NodeSender<std::vector<double>> output;
+
+    explicit FMDemodNodeF64(int device = 0) { throw_on(comms_fmdemod_f64_create(device, &h_), "FMDemodNode<f64>::new"); }
+    FMDemodNodeF64(FMDemodNodeF64&& o) noexcept : input(std::move(o.input)), output(std::move(o.output)), h_(o.h_) { o.h_ = nullptr; }
+    ~FMDemodNodeF64() { comms_fmdemod_f64_destroy(h_); }
+
+    Result<std::vector<double>> run(const std::vector<Complex64>& samples) {
+        std::vector<double> out(samples.size());
+        comms_status_t st = comms_fmdemod_f64_run(h_, c64(samples.data()), samples.size(), out.data());
+        if (st != COMMS_OK) return to_node_error(st);
+        return out;
+    }
+    auto receivers() { return std::tie(input); }
+    auto senders() { return std::tie(output); }
+
+private:
+    comms_fmdemod_f64_t* h_ = nullptr;
+};
+
 // #[aggregate]: run returns Some(vec) every fft_size pushes, None otherwise
 class FFTSampleNode : public DeriveNode<FFTSampleNode> {
 public:

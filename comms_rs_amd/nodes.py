@@ -484,6 +484,71 @@ class FFTBatchNode(_Handle):
         check(lib().comms_fft_run_dev(self._h, in_ptr, n, out_ptr, stream))
 
 
+class FFTBatchNodeF64(_Handle):
+    """FFTBatchNode<f64>::new(fft_size, ifft) / run (fft_node.rs:65-83) on Complex<f64> = numpy complex128 (comms_fft_f64_*):
+    the instantiation of the reference's doc examples; correct to f64 rounding."""
+    _destroy = "comms_fft_f64_destroy"
+
+    def __init__(self, fft_size, ifft, device=0):
+        super().__init__()
+        self.fft_size = int(fft_size)
+        check(lib().comms_fft_f64_create(self.fft_size, 1 if ifft else 0, device, C.byref(self._h)))
+
+    def run(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex128).ravel()
+        out = np.empty_like(x)
+        check(lib().comms_fft_f64_run(self._h, _ptr(x), x.size, _ptr(out)))
+        return out
+
+    def run_dev(self, in_ptr, n, out_ptr, stream=0):
+        check(lib().comms_fft_f64_run_dev(self._h, in_ptr, n, out_ptr, stream))
+
+
+class FFTSampleNodeF64(FFTBatchNodeF64):
+    """FFTSampleNode<f64> (fft_node.rs:142-167), #[aggregate]: a sample per call, the spectrum every fft_size samples."""
+
+    def __init__(self, fft_size, ifft, device=0):
+        super().__init__(fft_size, ifft, device)
+        self._samples = []
+
+    def run(self, sample):
+        self._samples.append(np.complex128(sample))
+        if len(self._samples) == self.fft_size:
+            res = FFTBatchNodeF64.run(self, np.array(self._samples, np.complex128))
+            self._samples = []
+            return res
+        return None
+
+
+class FMDemodNodeF64(_Handle):
+    """FMDemodNode<f64>::new() / run (analog_node.rs:20-52; FM::demod analog.rs:22-35) on Complex<f64>."""
+    _destroy = "comms_fmdemod_f64_destroy"
+
+    def __init__(self, device=0):
+        super().__init__()
+        check(lib().comms_fmdemod_f64_create(device, C.byref(self._h)))
+
+    def run(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex128).ravel()
+        out = np.empty(x.size, np.float64)
+        check(lib().comms_fmdemod_f64_run(self._h, _ptr(x), x.size, _ptr(out)))
+        return out
+
+    def run_dev(self, in_ptr, n, out_ptr, stream=0):
+        check(lib().comms_fmdemod_f64_run_dev(self._h, in_ptr, n, out_ptr, stream))
+
+    @property
+    def prev(self):
+        p = np.zeros(1, np.complex128)
+        check(lib().comms_fmdemod_f64_get_prev(self._h, _ptr(p)))
+        return p[0]
+
+    @prev.setter
+    def prev(self, value):
+        p = np.array([value], np.complex128)
+        check(lib().comms_fmdemod_f64_set_prev(self._h, _ptr(p)))
+
+
 class FFTSampleNode(FFTBatchNode):
     """FFTSampleNode::new(fft_size, ifft) / run (fft_node.rs:142-167), #[aggregate]:
     push one sample; returns None until fft_size samples arrived, then the FFT."""

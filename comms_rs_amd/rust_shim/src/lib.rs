@@ -24,7 +24,7 @@
 //! |---|---|---|
 //! | `FirNode<T>`, `BatchFirNode<T>`, `PulseNode<T>` | fir_node.rs:45,148; pulse.rs:38 | `f32`, `f64`, `i16` (`FirSample`) |
 //! | `MixerNode<T>` | mixer.rs:93 | `f32`, `f64` (`MixerSample`) |
-//! | `FFTBatchNode<T>`, `FFTSampleNode<T>`, `FMDemodNode<T>` | fft_node.rs:28,104; analog_node.rs:20 | `f32` (`FloatSample`) |
+//! | `FFTBatchNode<T>`, `FFTSampleNode<T>`, `FMDemodNode<T>` | fft_node.rs:28,104; analog_node.rs:20 | `f32`, `f64` (`FloatSample`) |
 //! | `DecimateNode<T>`, `UpsampleNode<T>` | resample_node.rs:10,74 | any `Copy + Send` type of 1, 2, 4, 8 or 16 bytes |
 pub mod ffi;
 
@@ -118,15 +118,38 @@ impl MixerSample for f64 {
     unsafe fn mix(h: *mut comms_mixer_t, x: *const Complex<f64>, n: usize, y: *mut Complex<f64>) -> comms_status_t { comms_mixer_run_f64(h, x, n, y) }
 }
 
-/// Sample type of the FFT and FM-demodulation nodes (`f32`: the reference casts to f64 inside and back,
-/// fft/mod.rs:78-94; the kernels compute in f32 within the north star's 1e-5).
+/// Sample types of the FFT and FM-demodulation nodes: `f32` (the reference casts to f64 inside and back, fft/mod.rs:78-94; the
+/// kernels compute in f32 within the north star's 1e-5) and `f64` (the instantiation of the reference's doc examples,
+/// fft_node.rs:24,99: plain FP64 kernels, comms_fft_f64_* / comms_fmdemod_f64_*).
 pub trait FloatSample: sealed::Sealed + Num + Copy + Send + Default + 'static {
-    #[doc(hidden)] unsafe fn fft(h: *mut comms_fft_t, x: *const Complex<Self>, n: usize, y: *mut Complex<Self>) -> comms_status_t;
-    #[doc(hidden)] unsafe fn fm(h: *mut comms_fmdemod_t, x: *const Complex<Self>, n: usize, y: *mut Self) -> comms_status_t;
+    #[doc(hidden)] type Fft;
+    #[doc(hidden)] type Fm;
+    #[doc(hidden)] unsafe fn fft_create(fft_size: usize, ifft: i32, out: *mut *mut Self::Fft) -> comms_status_t;
+    #[doc(hidden)] unsafe fn fft(h: *mut Self::Fft, x: *const Complex<Self>, n: usize, y: *mut Complex<Self>) -> comms_status_t;
+    #[doc(hidden)] unsafe fn fft_destroy(h: *mut Self::Fft);
+    #[doc(hidden)] unsafe fn fm_create(out: *mut *mut Self::Fm) -> comms_status_t;
+    #[doc(hidden)] unsafe fn fm(h: *mut Self::Fm, x: *const Complex<Self>, n: usize, y: *mut Self) -> comms_status_t;
+    #[doc(hidden)] unsafe fn fm_destroy(h: *mut Self::Fm);
 }
 impl FloatSample for f32 {
+    type Fft = comms_fft_t;
+    type Fm = comms_fmdemod_t;
+    unsafe fn fft_create(fft_size: usize, ifft: i32, out: *mut *mut comms_fft_t) -> comms_status_t { comms_fft_create(fft_size, ifft, 0, out) }
     unsafe fn fft(h: *mut comms_fft_t, x: *const Complex<f32>, n: usize, y: *mut Complex<f32>) -> comms_status_t { comms_fft_run(h, x, n, y) }
+    unsafe fn fft_destroy(h: *mut comms_fft_t) { comms_fft_destroy(h); }
+    unsafe fn fm_create(out: *mut *mut comms_fmdemod_t) -> comms_status_t { comms_fmdemod_create(0, out) }
     unsafe fn fm(h: *mut comms_fmdemod_t, x: *const Complex<f32>, n: usize, y: *mut f32) -> comms_status_t { comms_fmdemod_run(h, x, n, y) }
+    unsafe fn fm_destroy(h: *mut comms_fmdemod_t) { comms_fmdemod_destroy(h); }
+}
+impl FloatSample for f64 {
+    type Fft = comms_fft_f64_t;
+    type Fm = comms_fmdemod_f64_t;
+    unsafe fn fft_create(fft_size: usize, ifft: i32, out: *mut *mut comms_fft_f64_t) -> comms_status_t { comms_fft_f64_create(fft_size, ifft, 0, out) }
+    unsafe fn fft(h: *mut comms_fft_f64_t, x: *const Complex<f64>, n: usize, y: *mut Complex<f64>) -> comms_status_t { comms_fft_f64_run(h, x, n, y) }
+    unsafe fn fft_destroy(h: *mut comms_fft_f64_t) { comms_fft_f64_destroy(h); }
+    unsafe fn fm_create(out: *mut *mut comms_fmdemod_f64_t) -> comms_status_t { comms_fmdemod_f64_create(0, out) }
+    unsafe fn fm(h: *mut comms_fmdemod_f64_t, x: *const Complex<f64>, n: usize, y: *mut f64) -> comms_status_t { comms_fmdemod_f64_run(h, x, n, y) }
+    unsafe fn fm_destroy(h: *mut comms_fmdemod_f64_t) { comms_fmdemod_f64_destroy(h); }
 }
 
 fn czeros<T: Num + Copy>(n: usize) -> Vec<Complex<T>> { vec![Complex::new(T::zero(), T::zero()); n] }
@@ -412,12 +435,12 @@ where
     T: FloatSample,
 {
     pub input: NodeReceiver<Vec<Complex<T>>>,
-    h: *mut comms_fmdemod_t,
+    h: *mut T::Fm,
     pub output: NodeSender<Vec<T>>,
 }
 unsafe impl<T: FloatSample> Send for FMDemodNode<T> {}
 impl<T: FloatSample> Drop for FMDemodNode<T> {
-    fn drop(&mut self) { unsafe { comms_fmdemod_destroy(self.h); } }
+    fn drop(&mut self) { unsafe { T::fm_destroy(self.h); } }
 }
 impl<T> FMDemodNode<T>
 where
@@ -425,7 +448,7 @@ where
 {
     pub fn new() -> Self {
         let mut h = ptr::null_mut();
-        let st = unsafe { comms_fmdemod_create(0, &mut h) };
+        let st = unsafe { T::fm_create(&mut h) };
         assert_eq!(st, COMMS_OK, "comms_fmdemod_create failed");
         FMDemodNode { input: Default::default(), h, output: Default::default() }
     }
@@ -447,12 +470,12 @@ where
     T: FloatSample,
 {
     pub input: NodeReceiver<Vec<Complex<T>>>,
-    h: *mut comms_fft_t,
+    h: *mut T::Fft,
     pub output: NodeSender<Vec<Complex<T>>>,
 }
 unsafe impl<T: FloatSample> Send for FFTBatchNode<T> {}
 impl<T: FloatSample> Drop for FFTBatchNode<T> {
-    fn drop(&mut self) { unsafe { comms_fft_destroy(self.h); } }
+    fn drop(&mut self) { unsafe { T::fft_destroy(self.h); } }
 }
 impl<T> FFTBatchNode<T>
 where
@@ -460,7 +483,7 @@ where
 {
     pub fn new(fft_size: usize, ifft: bool) -> Self {
         let mut h = ptr::null_mut();
-        let st = unsafe { comms_fft_create(fft_size, ifft as i32, 0, &mut h) };
+        let st = unsafe { T::fft_create(fft_size, ifft as i32, &mut h) };
         assert_eq!(st, COMMS_OK, "comms_fft_create failed");
         FFTBatchNode { input: Default::default(), h, output: Default::default() }
     }
@@ -481,14 +504,14 @@ where
     T: FloatSample,
 {
     pub input: NodeReceiver<Complex<T>>,
-    h: *mut comms_fft_t,
+    h: *mut T::Fft,
     fft_size: usize,
     samples: Vec<Complex<T>>,
     pub output: NodeSender<Vec<Complex<T>>>,
 }
 unsafe impl<T: FloatSample> Send for FFTSampleNode<T> {}
 impl<T: FloatSample> Drop for FFTSampleNode<T> {
-    fn drop(&mut self) { unsafe { comms_fft_destroy(self.h); } }
+    fn drop(&mut self) { unsafe { T::fft_destroy(self.h); } }
 }
 impl<T> FFTSampleNode<T>
 where
@@ -496,7 +519,7 @@ where
 {
     pub fn new(fft_size: usize, ifft: bool) -> Self {
         let mut h = ptr::null_mut();
-        let st = unsafe { comms_fft_create(fft_size, ifft as i32, 0, &mut h) };
+        let st = unsafe { T::fft_create(fft_size, ifft as i32, &mut h) };
         assert_eq!(st, COMMS_OK, "comms_fft_create failed");
         FFTSampleNode { input: Default::default(), h, fft_size, samples: Vec::with_capacity(fft_size), output: Default::default() }
     }
