@@ -148,3 +148,80 @@ def test_fir_ticketed_kernel_random_sweep(c):
             want = oracle.batch_fir(xs, taps, oracle.default_state(taps), norotate=True)[a - lo:]
             fir_close(ys[1][a:a + 3000].cpu().numpy(), want, taps, xs)
         del x, ys
+
+
+def test_poly8_chain_random_sweep(c):
+    """fir_poly8_kernel on random draws: tap count (every halo width, real / complex taps), mixer order, FM demod, oscillator, user
+    FIR state, batch cuts on multiples of 8 -- against the oracle's nodes in series."""
+    rng = np.random.default_rng(16 + 1000 * SEED_OFFSET)
+    for case in range(40):
+        fm = bool(rng.integers(0, 2))
+        n_taps = int(rng.integers(1, (249 if fm else 257) + 1))
+        taps = lowpass_taps(n_taps, float(rng.uniform(0.02, 0.06)))
+        if rng.integers(0, 2):
+            taps = (taps * np.exp(1j * rng.uniform(-0.05, 0.05) * np.arange(n_taps))).astype(np.complex64)
+        after = bool(rng.integers(0, 2)) and not fm
+        dphase, phase = float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3))
+        n = 8 * int(rng.integers(1, 3000))
+        t = np.arange(n)
+        x = (np.exp(1j * (0.3 * dphase * t + 2.0 * np.sin(t / 700.0))) * (1 + 0.05 * rng.standard_normal(n))).astype(np.complex64)
+        node = c.ChainNode(dphase, phase, taps, 8, fm, mixer_after_fir=after, kernel="poly")
+        assert node.kernel == "poly", case
+        ost, om, ofm = oracle.default_state(taps), oracle.Mixer(phase, dphase), oracle.FM()
+        if rng.integers(0, 3) == 0:  # a user state: the halo of a sharded stream (raw samples, newest first)
+            st = rand_c(rng, n_taps)
+            node.set_fir_state(st)
+            ost = (om_state := st.copy())
+            if not after:  # mixer first: the reference's FIR state holds MIXED samples, the oscillator running backwards from `phase`
+                k = np.arange(1, n_taps + 1)
+                ost = (st.astype(np.complex128) * np.exp(1j * (phase - k * dphase))).astype(np.complex64)
+        scale = np.sum(np.abs(taps)) * max(np.max(np.abs(x)), 1.0)
+        last = 0j
+        for a, b in zip(*(lambda cs: (cs[:-1], cs[1:]))(cuts_of(rng, n, 3, 8))):
+            if after:
+                y = oracle.decimate(om.mix(oracle.batch_fir(x[a:b], taps, ost, norotate=True)), 8)
+            else:
+                y = oracle.decimate(oracle.batch_fir(om.mix(x[a:b]), taps, ost, norotate=True), 8)
+            got = node.run(x[a:b])
+            if fm:
+                w = ofm.demod(y)
+                mag = np.minimum(np.abs(y), np.abs(np.concatenate([[last], y[:-1]])))
+                last = y[-1]
+                assert np.max(circ(got.astype(np.float64) - w) * mag) <= 4 * TOL * scale, (case, n_taps, a, b)
+            else:
+                assert np.max(np.abs(got - y)) <= 2 * TOL * scale, (case, n_taps, after, a, b)
+
+
+def test_poly8_ticketed_batches_random_sweep(c):
+    """Long batches (thousands of segments drawn from the ticket counter, both chunk sizes of the dealing): random tap counts and
+    lengths on and off a segment boundary, two calls with carried state -- against the overlap-save fusion (fir_os1024_kernel<MODE>,
+    another algorithm: full-rate transforms, seven of eight outputs dropped) on every output."""
+    import torch
+
+    rng = np.random.default_rng(17 + 1000 * SEED_OFFSET)
+    s = torch.cuda.current_stream().cuda_stream
+    for case in range(6):
+        fm = case % 3 == 2
+        n_taps = int(rng.integers(9, (249 if fm else 257) + 1))
+        new = 1024 - 64 * (2 if n_taps + (8 if fm else 0) <= 129 else 3 if n_taps + (8 if fm else 0) <= 193 else 4)
+        n1 = int(rng.integers(4096, 5200)) * new + (0 if case % 2 == 0 else 8 * int(rng.integers(1, new // 8)))
+        n2 = (int(rng.integers(40000, 45000)) if case == 5 else int(rng.integers(300, 4500))) * new + 8 * int(rng.integers(0, new // 8))
+        taps = lowpass_taps(n_taps, 1 / 20.0)
+        x = torch.empty(n1 + n2, dtype=torch.complex64, device="cuda:0")
+        c.synth_iq_dev(x.data_ptr(), n1 + n2, 0, int(rng.integers(1, 1 << 30)))
+        ys = []
+        for kern in ("poly", "freq"):
+            node = c.ChainNode(0.7, 0.2, taps, 8, fm, mixer_after_fir=not fm and case % 2 == 0, kernel=kern)
+            y = torch.empty((n1 + n2) // 8, dtype=torch.float32 if fm else torch.complex64, device="cuda:0")
+            node.run_dev(x.data_ptr(), n1, y.data_ptr(), s)
+            node.run_dev(x.data_ptr() + 8 * n1, n2, y.data_ptr() + (4 if fm else 8) * (n1 // 8), s)
+            torch.cuda.synchronize()
+            ys.append(y)
+        d = (ys[0] - ys[1]).abs()
+        bound = 2 * TOL * float(np.sum(np.abs(taps))) * x[: 1 << 20].abs().max().item()
+        if fm:  # angles: on the circle, and only a statistic -- the filtered synthetic stream passes close to zero now and then
+            d = torch.minimum(d, 2 * np.pi - d)
+            assert d.median().item() <= 1e-5 and (d > 1e-2).float().mean().item() <= 1e-4, (case, n_taps, d.max().item())
+        else:
+            assert d.max().item() <= 2 * bound, (case, n_taps, d.max().item(), bound)
+        del x, ys
