@@ -47,7 +47,7 @@ struct P8Geom {
 };
 // LDS: G [16][64], forward twiddle [16][8], sin / cos table [64], 16 exchange buffers, ticket
 constexpr int P8_TAB = 1024 + 128 + 64;
-constexpr size_t P8_LDS_BYTES = (P8_TAB + 16 * P8_BUF) * sizeof(float2) + 16;
+constexpr size_t p8_lds_bytes(int wpb) { return (P8_TAB + static_cast<size_t>(wpb) * P8_BUF) * sizeof(float2) + 16; }
 
 struct P8Tables {
     const cf* g;     // [16][64]  G_{cg + 4 ci}[k1 + 16 k2] / 128 at [8 ci + k2][lane], k1 = lane & 15, cg = lane >> 4
@@ -205,8 +205,10 @@ struct P8Fm {
 // (Nontemporal rows and outputs, which help the wave-private time-domain kernel, were measured here and dropped: level at 2^26
 // samples, 6 % slower at 2^25 -- a segment's halo rows are its neighbour's rows, and plain loads leave them in L2.)
 // In: Complex<f32>, or raw i16 / u8 IQ converted in the load stage with iqformat.hip's arithmetic (fir_handle.hpp).
-template <int HR, bool FM, class In>
-__global__ __launch_bounds__(1024, 4) void fir_poly8_kernel(In in, const float2* __restrict__ hist,
+// WPB waves per workgroup: 16 (one workgroup per CU), or 4 for short batches -- four times as many workgroups, so that a
+// batch of a few hundred segments still reaches every CU.
+template <int HR, bool FM, class In, int WPB>
+__global__ __launch_bounds__(64 * WPB, 4) void fir_poly8_kernel(In in, const float2* __restrict__ hist,
                                                             int hist_len, void* __restrict__ out_any, size_t n, P8Tables tb,
                                                             float2* __restrict__ new_hist, unsigned chunk_log2, P8Mix mx,
                                                             P8Fm fmx, KStamp ks) {
@@ -220,8 +222,8 @@ __global__ __launch_bounds__(1024, 4) void fir_poly8_kernel(In in, const float2*
     const int l = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     cf* lds = sc + 64 + wave * P8_BUF;
-    unsigned* ticket = reinterpret_cast<unsigned*>(sc + 64 + 16 * P8_BUF);
-    gsp[threadIdx.x] = tb.g[threadIdx.x];
+    unsigned* ticket = reinterpret_cast<unsigned*>(sc + 64 + WPB * P8_BUF);
+    for (int i = threadIdx.x; i < 1024; i += 64 * WPB) gsp[i] = tb.g[i];
     if (threadIdx.x < 128) tw[threadIdx.x] = tb.tw[threadIdx.x];
     if (threadIdx.x < 64) sc[threadIdx.x] = tb.sc[threadIdx.x];
     if (threadIdx.x == 0) *ticket = 0;
@@ -420,29 +422,41 @@ int poly8_halo_rows(int n_eff, bool fm) {
     return hr <= 4 ? hr : 0;
 }
 
-template <int HR, bool FM, class In>
-comms_status_t poly8_launch(comms_fir* h, hipStream_t s, In in, void* out, size_t n, const P8Tables& tb, const P8Mix& mx,
-                            const P8Fm& fmx) {
+template <int HR, bool FM, class In, int WPB>
+comms_status_t poly8_launch_w(comms_fir* h, hipStream_t s, In in, void* out, size_t n, const P8Tables& tb, const P8Mix& mx,
+                              const P8Fm& fmx) {
     using Gm = P8Geom<HR>;
+    constexpr size_t lds = p8_lds_bytes(WPB);
     const size_t nseg = (n + Gm::NEW - 1) / Gm::NEW;
-    const size_t want = (nseg + 15) / 16;
-    const dim3 grid(static_cast<unsigned>(want < static_cast<size_t>(kNumCU) ? want : kNumCU));
+    const size_t want = (nseg + WPB - 1) / WPB;
+    const size_t slots = static_cast<size_t>(kNumCU) * (16 / WPB);
+    const dim3 grid(static_cast<unsigned>(want < slots ? want : slots));
     static const int chunk_knob = diag_knob("COMMS_POLY8_CHUNK_LOG2", -1);
-    const unsigned chunk_log2 = chunk_knob >= 0 ? static_cast<unsigned>(chunk_knob) : nseg < 160u * static_cast<size_t>(grid.x) ? 1u : 3u;
+    const unsigned chunk_log2 = chunk_knob >= 0 ? static_cast<unsigned>(chunk_knob) : nseg < 160u * static_cast<size_t>(kNumCU) ? 1u : 3u;
     static DeviceOnce attr_once;
     if (attr_once.need())
-        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_poly8_kernel<HR, FM, In>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(P8_LDS_BYTES)));
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_poly8_kernel<HR, FM, In, WPB>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     hipEvent_t ea = nullptr, eb = nullptr;
     (void)h->take_events(ea, eb);
     const KStamp ks = h->next_stamp();
     if (ea)
-        hipExtLaunchKernelGGL((fir_poly8_kernel<HR, FM, In>), grid, dim3(1024), static_cast<uint32_t>(P8_LDS_BYTES), s, ea, eb, 0u, in,
+        hipExtLaunchKernelGGL((fir_poly8_kernel<HR, FM, In, WPB>), grid, dim3(64 * WPB), static_cast<uint32_t>(lds), s, ea, eb, 0u, in,
                               h->d_hist[h->cur], h->n_eff, out, n, tb, h->d_hist[h->cur ^ 1], chunk_log2, mx, fmx, ks);
     else
-        fir_poly8_kernel<HR, FM, In><<<grid, dim3(1024), P8_LDS_BYTES, s>>>(in, h->d_hist[h->cur], h->n_eff, out, n, tb,
+        fir_poly8_kernel<HR, FM, In, WPB><<<grid, dim3(64 * WPB), lds, s>>>(in, h->d_hist[h->cur], h->n_eff, out, n, tb,
                                                                            h->d_hist[h->cur ^ 1], chunk_log2, mx, fmx, ks);
     return launch_ok("fir_poly8_kernel");
+}
+
+template <int HR, bool FM, class In>
+comms_status_t poly8_launch(comms_fir* h, hipStream_t s, In in, void* out, size_t n, const P8Tables& tb, const P8Mix& mx,
+                            const P8Fm& fmx) {
+    // short batches (fewer segments than the chip has wave slots): four-wave workgroups
+    static const int wpb_knob = diag_knob("COMMS_POLY8_WPB", 0);
+    const size_t nseg = (n + P8Geom<HR>::NEW - 1) / P8Geom<HR>::NEW;
+    const bool small = wpb_knob ? wpb_knob == 4 : nseg < 16u * static_cast<size_t>(kNumCU);
+    return small ? poly8_launch_w<HR, FM, In, 4>(h, s, in, out, n, tb, mx, fmx) : poly8_launch_w<HR, FM, In, 16>(h, s, in, out, n, tb, mx, fmx);
 }
 
 template <class In>
