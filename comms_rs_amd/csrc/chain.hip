@@ -128,8 +128,13 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
                              ? comms_fir_decim_supported_for(h->fir, static_cast<uint32_t>(rate), h->fm_demod ? 1 : 0,
                                                              can_fuse || can_hybrid ? 1 : 0)
                              : 0;
+    // (rate 4 with a long filter: too many MACs for the time-domain kernel, but its chain kind is the one that reaches the polyphase
+    // frequency-domain kernel, which takes every call from 64 taps -- fir_poly8.hip)
+    const bool poly_pref = decim_ok >= 1 && !(flags & COMMS_CHAIN_TIME_DOMAIN) &&
+                           comms_fir_poly8_supported(h->fir, static_cast<uint32_t>(rate), COMMS_CHAIN_DEC | (h->fm_demod ? COMMS_CHAIN_FM : 0),
+                                                     static_cast<size_t>(1) << 26) == 2;
     const bool can_decim = !(flags & (COMMS_CHAIN_UNFUSED | COMMS_CHAIN_FREQ_DOMAIN)) &&
-                           (decim_ok == 2 || (decim_ok == 1 && (flags & COMMS_CHAIN_TIME_DOMAIN)));
+                           (decim_ok == 2 || poly_pref || (decim_ok == 1 && (flags & COMMS_CHAIN_TIME_DOMAIN)));
     // Rates the per-rate kernel is not built for (17 and up; 11 / 13 / 15 with complex taps): the any-rate kernel (half
     // a wave per output).  Against the overlap-save launch it replaces (58-61 us at 2^24 samples whatever the rate): 255
     // taps 60 us at rate 17, 53 at 20, 39 at 32, 30 at 100, 11 at 1000; 127 taps 49 at 17; 63 taps 45 at 17
@@ -142,7 +147,7 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
                          ((flags & COMMS_CHAIN_TIME_DOMAIN) || rate >= any_from);
     const int32_t poly_mode = (h->mixer_after ? COMMS_CHAIN_POST : COMMS_CHAIN_PRE) | COMMS_CHAIN_DEC | (h->fm_demod ? COMMS_CHAIN_FM : 0);
     const bool force_poly8 = st == COMMS_OK && (flags & COMMS_CHAIN_POLYPHASE) && !(flags & COMMS_CHAIN_UNFUSED) &&
-                             comms_fir_poly8_supported(h->fir, static_cast<uint32_t>(rate), poly_mode, 8) != 0;
+                             comms_fir_poly8_supported(h->fir, static_cast<uint32_t>(rate), poly_mode, static_cast<size_t>(1) << 26) != 0;
     if (force_poly8) {
         h->fused = true;
         h->poly8 = true;
@@ -248,7 +253,7 @@ comms_status_t comms_chain_create(double dphase, double phase, const comms_c32* 
 
 comms_status_t comms_chain_is_fused(const comms_chain_t* h, int32_t* out_fused) {
     COMMS_ARG(h && out_fused, "NULL argument");
-    *out_fused = h->fused ? (h->poly8 || (h->decim && h->fir && h->fir->last_poly8) ? 4 : h->decim_any ? 3 : h->decim ? 2 : 1) : 0;
+    *out_fused = h->fused ? (h->poly8 || ((h->decim || h->decim_any) && h->fir && h->fir->last_poly8) ? 4 : h->decim_any ? 3 : h->decim ? 2 : 1) : 0;
     return COMMS_OK;
 }
 
@@ -287,7 +292,7 @@ comms_status_t comms_chain_run_dev(comms_chain_t* h, const comms_c32* d_in_any, 
             stage_out = h->t3.p;
         }
         if (h->poly8)
-            COMMS_TRY(comms_fir_run_poly8_dev(h->fir, d_in, n, stage_out, h->mode, h->turns, h->frac, h->d_prev[h->cur], h->d_prev[h->cur ^ 1], s));
+            COMMS_TRY(comms_fir_run_poly8_dev(h->fir, d_in, n, stage_out, h->mode, h->turns, h->frac, static_cast<uint32_t>(h->rate), h->d_prev[h->cur], h->d_prev[h->cur ^ 1], s));
         else if (h->decim_any)
             COMMS_TRY(comms_fir_run_decim_any_dev(h->fir, d_in, n, stage_out, h->mode, h->turns, h->frac, static_cast<uint32_t>(h->rate),
                                                   h->d_prev[h->cur], h->d_prev[h->cur ^ 1], s));

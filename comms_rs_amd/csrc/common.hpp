@@ -49,8 +49,8 @@ extern "C" COMMS_INTERNAL comms_status_t comms_fir_run_decim_any_dev(comms_fir_t
 // ... and, at rate 8, as eight polyphase branches in the frequency domain (fir_poly8.hip): long filters on long batches
 extern "C" COMMS_INTERNAL int32_t comms_fir_poly8_supported(const comms_fir_t* h, uint32_t rate, int32_t mode, size_t n);
 extern "C" COMMS_INTERNAL comms_status_t comms_fir_run_poly8_dev(comms_fir_t* h, const void* d_in, size_t n, void* d_out,
-                                                  int32_t mode, uint64_t turns0, uint64_t frac, const void* fm_prev,
-                                                  void* fm_prev_new, void* stream);
+                                                  int32_t mode, uint64_t turns0, uint64_t frac, uint32_t rate,
+                                                  const void* fm_prev, void* fm_prev_new, void* stream);
 
 namespace comms {
 

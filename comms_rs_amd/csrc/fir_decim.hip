@@ -898,7 +898,7 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
     if (!n) return COMMS_OK;
     // long filters on long batches at rate 8: the polyphase frequency-domain kernel (fir_poly8.hip)
     if (comms_fir_poly8_supported(h, rate, mode, n) == 2)
-        return comms_fir_run_poly8_dev(h, d_in, n, d_out, mode, turns0, frac, fm_prev, fm_prev_new, stream);
+        return comms_fir_run_poly8_dev(h, d_in, n, d_out, mode, turns0, frac, rate, fm_prev, fm_prev_new, stream);
     h->last_poly8 = false;
     const size_t in_elem = h->in_fmt == COMMS_IQ_I16 ? 4 : h->in_fmt == COMMS_IQ_U8 ? 2 : 8;
     COMMS_ARG(!ranges_overlap(d_in, n * in_elem, d_out, (n / rate) * ((mode & COMMS_CHAIN_FM) ? 4 : 8)),

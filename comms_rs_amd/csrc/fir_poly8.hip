@@ -46,11 +46,12 @@ struct P8Geom {
     static constexpr int HQ = 8 * HR, HALO = 64 * HR, NEW = 1024 - 64 * HR, OUT = 128 - 8 * HR;
 };
 // LDS: G [16][64], forward twiddle [16][8], sin / cos table [64], 16 exchange buffers, ticket
-constexpr int P8_TAB = 1024 + 128 + 64;
-constexpr size_t p8_lds_bytes(int wpb) { return (P8_TAB + static_cast<size_t>(wpb) * P8_BUF) * sizeof(float2) + 16; }
+constexpr int P8_TAB = 128 + 64;  // forward twiddle + sin / cos table; in front of them NPH spectra tables of 1024
+constexpr size_t p8_lds_bytes(int wpb, int nph) { return (1024 * static_cast<size_t>(nph) + P8_TAB + static_cast<size_t>(wpb) * P8_BUF) * sizeof(float2) + 16; }
 
 struct P8Tables {
-    const cf* g;     // [16][64]  G_{cg + 4 ci}[k1 + 16 k2] / 128 at [8 ci + k2][lane], k1 = lane & 15, cg = lane >> 4
+    const cf* g;     // [16][64]  G_{cg + 4 ci}[k1 + 16 k2] / 128 at [8 ci + k2][lane], k1 = lane & 15, cg = lane >> 4; behind it
+                     //           the same for the outputs y[8j + 4] (branch filters h[8m - c + 4]): the second output phase
     const cf* tw;    // [16][8]   W128^{d k1} at [k1][d]
     const cf* sc;    // [64]      (cos, sin)(2 pi i / 64)
     const cf* lane;  // [7][64]   per-lane constants of the inverse (below)
@@ -58,6 +59,9 @@ struct P8Tables {
 struct P8Mix {
     uint64_t turns0, frac;  // mixer phase of input sample 0, increment per input sample (turns of fl(2 pi) x 2^64)
     float2 step512;         // e^{i 512 dphi}: 64 outputs on
+    float2 step4;           // e^{i 4 dphi}: the second output phase (rate 4)
+    unsigned keep;          // rates 8 m: every m-th output is kept (1: all) ...
+    unsigned div_m, div_s;  //   ... and o / m for 32-bit o: t = mulhi(div_m, o); (t + ((o - t) >> 1)) >> div_s
 };
 
 __device__ __forceinline__ void p8_lds_sync() {
@@ -103,7 +107,8 @@ struct P8Lane {
 
 // One segment, first half: v[a] = samples base + 64a + lane -> the spectrum products of the lane's two phases, written to
 // exchange 2.  v is dead afterwards (the caller fetches the next segment's rows into it while the second half runs).
-__device__ __forceinline__ void poly8_forward(cf (&v)[16], cf* lds, const cf* tw, const cf* gsp, int l) {
+template <int NPH>
+__device__ __forceinline__ void poly8_forward(cf (&v)[16], cf* lds, const cf* tw, const cf* gsp, int l, cf (&p2)[8]) {
     const int d = l >> 3;
     radix16<-1>(v);
 #pragma unroll
@@ -131,7 +136,18 @@ __device__ __forceinline__ void poly8_forward(cf (&v)[16], cf* lds, const cf* tw
         cf p = cmulf(va[k2], gsp[k2 * 64 + l]);
         p = cmacf(p, vb[k2], gsp[(8 + k2) * 64 + l]);
         lds[k2 * 80 + cg * 16 + k1] = p;
+        if (NPH == 2) {  // the same transforms through the second phase's branch spectra: kept in registers until the first
+                         // phase's inverse half has read exchange 2
+            p2[k2] = cmacf(cmulf(va[k2], gsp[1024 + k2 * 64 + l]), vb[k2], gsp[1024 + (8 + k2) * 64 + l]);
+        }
     }
+    p8_lds_sync();
+}
+// the second phase's products into exchange 2 (behind the first phase's inverse half)
+__device__ __forceinline__ void poly8_put(cf* lds, const cf (&p2)[8], int l) {
+    const int k1 = l & 15, cg = l >> 4;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) lds[k2 * 80 + cg * 16 + k1] = p2[k2];
     p8_lds_sync();
 }
 
@@ -207,7 +223,10 @@ struct P8Fm {
 // In: Complex<f32>, or raw i16 / u8 IQ converted in the load stage with iqformat.hip's arithmetic (fir_handle.hpp).
 // WPB waves per workgroup: 16 (one workgroup per CU), or 4 for short batches -- four times as many workgroups, so that a
 // batch of a few hundred segments still reaches every CU.
-template <int HR, bool FM, class In, int WPB>
+// NPH = 2: rate 4 -- the outputs y[8j + 4] too, from the same forward transforms through a second set of branch spectra
+// (h[8m - c + 4]) and a second inverse half; the two phases leave interleaved.  mx.keep = m > 1: rates 8 m -- every m-th output of
+// the rate-8 form is kept (the forward transforms, which are most of the work, are what any rate needs).
+template <int HR, bool FM, class In, int WPB, int NPH>
 __global__ __launch_bounds__(64 * WPB, 4) void fir_poly8_kernel(In in, const float2* __restrict__ hist,
                                                             int hist_len, void* __restrict__ out_any, size_t n, P8Tables tb,
                                                             float2* __restrict__ new_hist, unsigned chunk_log2, P8Mix mx,
@@ -216,14 +235,15 @@ __global__ __launch_bounds__(64 * WPB, 4) void fir_poly8_kernel(In in, const flo
     extern __shared__ __attribute__((aligned(16))) char smem[];
     kstamp_begin(ks);
     hist_advance(hist, in, n, new_hist, hist_len);
-    cf* gsp = reinterpret_cast<cf*>(smem);  // [16][64]
-    cf* tw = gsp + 1024;                    // [16][8]
+    static_assert(NPH == 1 || !FM, "the second output phase comes without the FM demodulator");
+    cf* gsp = reinterpret_cast<cf*>(smem);  // [NPH][16][64]
+    cf* tw = gsp + 1024 * NPH;              // [16][8]
     cf* sc = tw + 128;                      // [64]
     const int l = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     cf* lds = sc + 64 + wave * P8_BUF;
     unsigned* ticket = reinterpret_cast<unsigned*>(sc + 64 + WPB * P8_BUF);
-    for (int i = threadIdx.x; i < 1024; i += 64 * WPB) gsp[i] = tb.g[i];
+    for (int i = threadIdx.x; i < 1024 * NPH; i += 64 * WPB) gsp[i] = tb.g[i];
     if (threadIdx.x < 128) tw[threadIdx.x] = tb.tw[threadIdx.x];
     if (threadIdx.x < 64) sc[threadIdx.x] = tb.sc[threadIdx.x];
     if (threadIdx.x == 0) *ticket = 0;
@@ -260,17 +280,38 @@ __global__ __launch_bounds__(64 * WPB, 4) void fir_poly8_kernel(In in, const flo
     const uint64_t lane_turns = mx.turns0 + static_cast<uint64_t>(static_cast<long long>(8 * (l - Gm::HQ))) * mx.frac;
     const uint64_t seg_turns = static_cast<uint64_t>(Gm::NEW) * mx.frac;
     const cf step512 = to_cf(mx.step512);
-    auto emit = [&](size_t sg, cf ya, cf yb, bool guard) {
+    const cf step4 = to_cf(mx.step4);
+    auto emit = [&](size_t sg, cf ya, cf yb, cf ya2, cf yb2, bool guard) {
         const uint64_t tl = lane_turns + static_cast<uint64_t>(sg) * seg_turns;
         const cf rot = p8_rotor(static_cast<unsigned>(tl >> 32), sc);
+        const cf rotb = cmulf_s(rot, step512);
         ya = cmulf(ya, rot);
-        yb = cmulf(yb, cmulf_s(rot, step512));
+        yb = cmulf(yb, rotb);
         const long long o = static_cast<long long>(sg * Gm::OUT) + l - Gm::HQ;  // ya's output; yb's: o + 64
         const bool a_on = l >= Gm::HQ && (!guard || static_cast<size_t>(o) < n_out);
         const bool b_on = !guard || static_cast<size_t>(o + 64) < n_out;
-        if (!FM) {
-            if (a_on) out[o] = to_f2(ya);
-            if (b_on) out[o + 64] = to_f2(yb);
+        if (NPH == 2) {  // rate 4: outputs 2 o (y[8 o]) and 2 o + 1 (y[8 o + 4]); n / 4 of them (n a multiple of 4, not of 8)
+            ya2 = cmulf(ya2, cmulf_s(rot, step4));
+            yb2 = cmulf(yb2, cmulf_s(rotb, step4));
+            const size_t n4 = n >> 2;
+            const size_t oa = static_cast<size_t>(2 * o), ob = oa + 128;
+            if (l >= Gm::HQ) {
+                if (!guard || oa < n4) out[oa] = to_f2(ya);
+                if (!guard || oa + 1 < n4) out[oa + 1] = to_f2(ya2);
+            }
+            if (!guard || ob < n4) out[ob] = to_f2(yb);
+            if (!guard || ob + 1 < n4) out[ob + 1] = to_f2(yb2);
+        } else if (!FM) {
+            if (mx.keep > 1) {  // rates 8 m: output o is kept when m divides it (o < 2^32: the launcher's condition)
+                const unsigned oa = static_cast<unsigned>(o), ob = oa + 64u;
+                const unsigned ta = __umulhi(mx.div_m, oa), tb2 = __umulhi(mx.div_m, ob);
+                const unsigned qa = (ta + ((oa - ta) >> 1)) >> mx.div_s, qb = (tb2 + ((ob - tb2) >> 1)) >> mx.div_s;
+                if (a_on && qa * mx.keep == oa) out[qa] = to_f2(ya);
+                if (b_on && qb * mx.keep == ob) out[qb] = to_f2(yb);
+            } else {
+                if (a_on) out[o] = to_f2(ya);
+                if (b_on) out[o + 64] = to_f2(yb);
+            }
         } else {
             // y[j - 1]: the lane below; position 64's comes from lane 63 of ya.  Position HQ - 1 is a valid output (of the
             // segment before) whenever the filter leaves one spare halo position, which the launcher guarantees.
@@ -288,7 +329,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void fir_poly8_kernel(In in, const flo
         }
     };
 
-    cf v[16], ya, yb;
+    cf v[16], p2[8], ya, yb, ya2 = cf{0.f, 0.f}, yb2 = cf{0.f, 0.f};
     // The stream's first segment (halo from the history) and its partial last one: wave 0 of the first / last workgroup,
     // before it joins the ticket loop
     if (wave == 0) {
@@ -299,9 +340,13 @@ __global__ __launch_bounds__(64 * WPB, 4) void fir_poly8_kernel(In in, const flo
             const long long b0 = static_cast<long long>(sg * Gm::NEW) - Gm::HALO + l;
 #pragma unroll
             for (int a = 0; a < 16; ++a) v[a] = to_cf(stream_at(in, hist, hist_len, b0 + 64 * a, n));
-            poly8_forward(v, lds, tw, gsp, l);
+            poly8_forward<NPH>(v, lds, tw, gsp, l, p2);
             poly8_inverse(lds, lc, l, ya, yb);
-            emit(sg, ya, yb, true);
+            if (NPH == 2) {
+                poly8_put(lds, p2, l);
+                poly8_inverse(lds, lc, l, ya2, yb2);
+            }
+            emit(sg, ya, yb, ya2, yb2, true);
         }
     }
     auto fetch = [&](size_t sg) {
@@ -317,15 +362,19 @@ __global__ __launch_bounds__(64 * WPB, 4) void fir_poly8_kernel(In in, const flo
     if (seg < hi) fetch(seg);
     while (seg < hi) {
         const size_t seg_next = draw();
-        poly8_forward(v, lds, tw, gsp, l);
-        if (have) emit(seg_prev, ya, yb, false);
+        poly8_forward<NPH>(v, lds, tw, gsp, l, p2);
+        if (have) emit(seg_prev, ya, yb, ya2, yb2, false);
         if (seg_next < hi) fetch(seg_next);  // v is dead: the rows travel while the inverse half runs (few registers)
         poly8_inverse(lds, lc, l, ya, yb);
+        if (NPH == 2) {
+            poly8_put(lds, p2, l);
+            poly8_inverse(lds, lc, l, ya2, yb2);
+        }
         seg_prev = seg;
         have = true;
         seg = seg_next;
     }
-    if (have) emit(seg_prev, ya, yb, false);
+    if (have) emit(seg_prev, ya, yb, ya2, yb2, false);
     kstamp_end(ks);
 }
 
@@ -364,33 +413,34 @@ static comms_status_t poly8_prepare(comms_fir* h, bool pre, uint64_t frac, hipSt
         hr[k] = tr;
         hi[k] = ti;
     }
-    std::vector<float2> t(static_cast<size_t>(P8_TAB) + 7 * 64);
+    std::vector<float2> t(2048 + static_cast<size_t>(P8_TAB) + 7 * 64);
     float2* g = t.data();
-    float2* tw = g + 1024;
+    float2* tw = g + 2048;
     float2* sc = tw + 128;
     float2* ln = sc + 64;
-    // G_c[k] = (1/128) sum_m h[8m - c] W128^{mk}
+    // G_c[k] = (1/128) sum_m h[8m - c + shift] W128^{mk}: shift 0 for the outputs y[8j], 4 for y[8j + 4] (rate 4)
     std::vector<double> cs(128), sn(128);
     for (int i = 0; i < 128; ++i) {
         cs[i] = std::cos(2.0 * kPi8 * i / 128.0);
         sn[i] = -std::sin(2.0 * kPi8 * i / 128.0);
     }
-    for (int lane = 0; lane < 64; ++lane) {
-        const int k1 = lane & 15, cg = lane >> 4;
-        for (int ci = 0; ci < 2; ++ci)
-            for (int k2 = 0; k2 < 8; ++k2) {
-                const int c = cg + 4 * ci, k = k1 + 16 * k2;
-                double re = 0.0, im = 0.0;
-                for (int m = 0; m <= 32; ++m) {
-                    const int tap = 8 * m - c;
-                    if (tap < 0 || tap >= N) continue;
-                    const int e = (m * k) & 127;
-                    re += hr[tap] * cs[e] - hi[tap] * sn[e];
-                    im += hr[tap] * sn[e] + hi[tap] * cs[e];
+    for (int ph = 0; ph < 2; ++ph)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int k1 = lane & 15, cg = lane >> 4;
+            for (int ci = 0; ci < 2; ++ci)
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    const int c = cg + 4 * ci, k = k1 + 16 * k2;
+                    double re = 0.0, im = 0.0;
+                    for (int m = 0; m <= 32; ++m) {
+                        const int tap = 8 * m - c + 4 * ph;
+                        if (tap < 0 || tap >= N) continue;
+                        const int e = (m * k) & 127;
+                        re += hr[tap] * cs[e] - hi[tap] * sn[e];
+                        im += hr[tap] * sn[e] + hi[tap] * cs[e];
+                    }
+                    g[1024 * ph + (8 * ci + k2) * 64 + lane] = make_float2(static_cast<float>(re / 128.0), static_cast<float>(im / 128.0));
                 }
-                g[(8 * ci + k2) * 64 + lane] = make_float2(static_cast<float>(re / 128.0), static_cast<float>(im / 128.0));
-            }
-    }
+        }
     for (int k1 = 0; k1 < 16; ++k1)
         for (int d = 0; d < 8; ++d) tw[k1 * 8 + d] = root(static_cast<long long>(d) * k1, 128, -1);
     for (int i = 0; i < 64; ++i) sc[i] = root(i, 64, +1);
@@ -422,11 +472,11 @@ int poly8_halo_rows(int n_eff, bool fm) {
     return hr <= 4 ? hr : 0;
 }
 
-template <int HR, bool FM, class In, int WPB>
+template <int HR, bool FM, class In, int WPB, int NPH>
 comms_status_t poly8_launch_w(comms_fir* h, hipStream_t s, In in, void* out, size_t n, const P8Tables& tb, const P8Mix& mx,
                               const P8Fm& fmx) {
     using Gm = P8Geom<HR>;
-    constexpr size_t lds = p8_lds_bytes(WPB);
+    constexpr size_t lds = p8_lds_bytes(WPB, NPH);
     const size_t nseg = (n + Gm::NEW - 1) / Gm::NEW;
     const size_t want = (nseg + WPB - 1) / WPB;
     const size_t slots = static_cast<size_t>(kNumCU) * (16 / WPB);
@@ -435,39 +485,50 @@ comms_status_t poly8_launch_w(comms_fir* h, hipStream_t s, In in, void* out, siz
     const unsigned chunk_log2 = chunk_knob >= 0 ? static_cast<unsigned>(chunk_knob) : nseg < 160u * static_cast<size_t>(kNumCU) ? 1u : 3u;
     static DeviceOnce attr_once;
     if (attr_once.need())
-        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_poly8_kernel<HR, FM, In, WPB>),
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_poly8_kernel<HR, FM, In, WPB, NPH>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     hipEvent_t ea = nullptr, eb = nullptr;
     (void)h->take_events(ea, eb);
     const KStamp ks = h->next_stamp();
     if (ea)
-        hipExtLaunchKernelGGL((fir_poly8_kernel<HR, FM, In, WPB>), grid, dim3(64 * WPB), static_cast<uint32_t>(lds), s, ea, eb, 0u, in,
+        hipExtLaunchKernelGGL((fir_poly8_kernel<HR, FM, In, WPB, NPH>), grid, dim3(64 * WPB), static_cast<uint32_t>(lds), s, ea, eb, 0u, in,
                               h->d_hist[h->cur], h->n_eff, out, n, tb, h->d_hist[h->cur ^ 1], chunk_log2, mx, fmx, ks);
     else
-        fir_poly8_kernel<HR, FM, In, WPB><<<grid, dim3(64 * WPB), lds, s>>>(in, h->d_hist[h->cur], h->n_eff, out, n, tb,
-                                                                           h->d_hist[h->cur ^ 1], chunk_log2, mx, fmx, ks);
+        fir_poly8_kernel<HR, FM, In, WPB, NPH><<<grid, dim3(64 * WPB), lds, s>>>(in, h->d_hist[h->cur], h->n_eff, out, n, tb,
+                                                                                h->d_hist[h->cur ^ 1], chunk_log2, mx, fmx, ks);
     return launch_ok("fir_poly8_kernel");
 }
 
-template <int HR, bool FM, class In>
+template <int HR, bool FM, class In, int NPH>
 comms_status_t poly8_launch(comms_fir* h, hipStream_t s, In in, void* out, size_t n, const P8Tables& tb, const P8Mix& mx,
                             const P8Fm& fmx) {
     // short batches (fewer segments than the chip has wave slots): four-wave workgroups
     static const int wpb_knob = diag_knob("COMMS_POLY8_WPB", 0);
     const size_t nseg = (n + P8Geom<HR>::NEW - 1) / P8Geom<HR>::NEW;
     const bool small = wpb_knob ? wpb_knob == 4 : nseg < 16u * static_cast<size_t>(kNumCU);
-    return small ? poly8_launch_w<HR, FM, In, 4>(h, s, in, out, n, tb, mx, fmx) : poly8_launch_w<HR, FM, In, 16>(h, s, in, out, n, tb, mx, fmx);
+    return small ? poly8_launch_w<HR, FM, In, 4, NPH>(h, s, in, out, n, tb, mx, fmx) : poly8_launch_w<HR, FM, In, 16, NPH>(h, s, in, out, n, tb, mx, fmx);
 }
 
 template <class In>
-comms_status_t poly8_launch_in(int hr, bool fm, comms_fir* h, hipStream_t s, In in, void* out, size_t n, const P8Tables& tb,
+comms_status_t poly8_launch_in(int hr, bool fm, int nph, comms_fir* h, hipStream_t s, In in, void* out, size_t n, const P8Tables& tb,
                                const P8Mix& mx, const P8Fm& fmx) {
+    if (nph == 2) {
+        switch (hr) {
+            case 2: return poly8_launch<2, false, In, 2>(h, s, in, out, n, tb, mx, fmx);
+            case 3: return poly8_launch<3, false, In, 2>(h, s, in, out, n, tb, mx, fmx);
+            default: return poly8_launch<4, false, In, 2>(h, s, in, out, n, tb, mx, fmx);
+        }
+    }
     switch (hr) {
-        case 2: return fm ? poly8_launch<2, true, In>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<2, false, In>(h, s, in, out, n, tb, mx, fmx);
-        case 3: return fm ? poly8_launch<3, true, In>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<3, false, In>(h, s, in, out, n, tb, mx, fmx);
-        default: return fm ? poly8_launch<4, true, In>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<4, false, In>(h, s, in, out, n, tb, mx, fmx);
+        case 2: return fm ? poly8_launch<2, true, In, 1>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<2, false, In, 1>(h, s, in, out, n, tb, mx, fmx);
+        case 3: return fm ? poly8_launch<3, true, In, 1>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<3, false, In, 1>(h, s, in, out, n, tb, mx, fmx);
+        default: return fm ? poly8_launch<4, true, In, 1>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<4, false, In, 1>(h, s, in, out, n, tb, mx, fmx);
     }
 }
+
+// What the kernel does for a decimation rate: 8 (one output phase), 4 (two), 8 m up to 64 (every m-th output of the rate-8 form:
+// the forward transforms are what any rate needs); 0: not this kernel
+int poly8_rate_kind(uint32_t rate) { return rate == 8 ? 1 : rate == 4 ? 2 : (rate % 8 == 0 && rate >= 16 && rate <= 64) ? 3 : 0; }
 
 }  // namespace
 
@@ -475,8 +536,11 @@ extern "C" {
 
 // 0: no; 1: this chain (taps, rate, stages, batch) can run on the polyphase frequency-domain kernel; 2: and it is the faster form
 int32_t comms_fir_poly8_supported(const comms_fir_t* h, uint32_t rate, int32_t mode, size_t n) {
-    if (!h || rate != 8 || h->n_eff < 1 || n < 8) return 0;
-    if (!(mode & COMMS_CHAIN_DEC) || !poly8_halo_rows(h->n_eff, (mode & COMMS_CHAIN_FM) != 0)) return 0;
+    const int kind = poly8_rate_kind(rate);
+    if (!h || !kind || h->n_eff < 1 || n < rate) return 0;
+    const bool fm = (mode & COMMS_CHAIN_FM) != 0;
+    if (!(mode & COMMS_CHAIN_DEC) || !poly8_halo_rows(h->n_eff, fm) || (fm && kind != 1)) return 0;
+    if (kind == 3 && (n >> 3) > 0xFFFFFFFFull) return 0;  // (its output index arithmetic is 32 bits wide)
     static const int knob = diag_knob("COMMS_POLY8", 1);          // 0: never, 1: where it wins, 2: wherever it can run
     if (!knob || h->no_poly8) return 0;
     if (knob == 2) return 2;
@@ -485,47 +549,71 @@ int32_t comms_fir_poly8_supported(const comms_fir_t* h, uint32_t rate, int32_t m
     // at 2^24 samples, 12 -> 7 us at 2^14), level with them on shorter filters up to 2^24 samples, 7 % ahead at 2^26.
     static const int min_taps = diag_knob("COMMS_POLY8_MIN_TAPS", 64);
     static const int min_log2 = diag_knob("COMMS_POLY8_MIN_LOG2", 25);
-    return h->n_eff >= min_taps || n >= (static_cast<size_t>(1) << min_log2) ? 2 : 1;
+    const int N = h->n_eff;
+    if (kind == 1) return N >= min_taps || n >= (static_cast<size_t>(1) << min_log2) ? 2 : 1;
+    // Rates 4 and 8 m against the time-domain kernels and the overlap-save fusion (scripts/sweep_poly8_rates.py,
+    // profiles/r05_sweep_poly8_rates.txt).  Rate 4 (two output phases; 255 taps at 2^24 samples: 61 -> 36 us): ahead from 64 taps
+    // on long batches, from 128 taps at every length.  Rates 16 ... 56: ahead or level everywhere from 32 taps (255 taps at rate
+    // 16: 38.8 -> 26.5 us).  Rate 64: the any-rate kernel reads only its windows when rate >= taps and keeps the short batches
+    // (4.5 against 6.6 us at 2^16 samples); from 2^23 samples, or 128 taps, this one.
+    if (kind == 2) return N >= 2 * min_taps || (N >= min_taps && n >= (static_cast<size_t>(1) << 22)) ? 2 : 1;
+    if (rate < 64) return N >= min_taps / 2 ? 2 : 1;
+    return N >= 2 * min_taps || n >= (static_cast<size_t>(1) << 23) ? 2 : 1;
 }
 
 comms_status_t comms_fir_run_poly8_dev(comms_fir_t* h, const void* d_in, size_t n, void* d_out, int32_t mode,
-                                       uint64_t turns0, uint64_t frac, const void* fm_prev, void* fm_prev_new, void* stream) {
+                                       uint64_t turns0, uint64_t frac, uint32_t rate, const void* fm_prev, void* fm_prev_new,
+                                       void* stream) {
     COMMS_ARG(h != nullptr, "handle is NULL");
     COMMS_ARG((d_in && d_out) || !n, "NULL device pointer");
-    COMMS_ARG(n % 8 == 0, "n must be a multiple of the decimation rate");
+    const int kind = poly8_rate_kind(rate);
+    COMMS_ARG(kind != 0, "the polyphase kernel runs rates 4, 8 and multiples of 8 up to 64");
+    COMMS_ARG(n % rate == 0, "n must be a multiple of the decimation rate");
     const bool fm = (mode & COMMS_CHAIN_FM) != 0;
     const int hr = poly8_halo_rows(h->n_eff, fm);
     COMMS_ARG(hr != 0, "the polyphase kernel takes <= 257 taps (249 with FM demod)");
+    COMMS_ARG(!fm || kind == 1, "the polyphase kernel demodulates at rate 8 only");
+    COMMS_ARG(kind != 3 || (n >> 3) <= 0xFFFFFFFFull, "batch too long for the polyphase kernel at this rate");
     COMMS_ARG((mode & COMMS_CHAIN_DEC) && !((mode & COMMS_CHAIN_PRE) && (mode & COMMS_CHAIN_POST)), "bad chain mode");
     COMMS_ARG(!fm || (fm_prev && fm_prev_new), "FM demod needs its state");
     COMMS_TRY(fir_check_sticky(h));
     COMMS_TRY(use_device(h->device));
     if (!n) return COMMS_OK;
     const size_t in_elem = h->in_fmt == COMMS_IQ_I16 ? 4 : h->in_fmt == COMMS_IQ_U8 ? 2 : 8;
-    COMMS_ARG(!ranges_overlap(d_in, n * in_elem, d_out, (n / 8) * (fm ? 4 : 8)), "the decimating chain cannot run in place");
+    COMMS_ARG(!ranges_overlap(d_in, n * in_elem, d_out, (n / rate) * (fm ? 4 : 8)), "the decimating chain cannot run in place");
     COMMS_ARG((reinterpret_cast<uintptr_t>(d_in) & (in_elem - 1)) == 0, "input must be aligned to one IQ sample");
     hipStream_t s = nullptr;
     COMMS_TRY(h->enter(stream, &s));
     COMMS_TRY(poly8_prepare(h, (mode & COMMS_CHAIN_PRE) != 0, frac, s));
     P8Tables tb;
     tb.g = reinterpret_cast<const cf*>(h->d_p8);
-    tb.tw = tb.g + 1024;
+    tb.tw = tb.g + 2048;
     tb.sc = tb.tw + 128;
     tb.lane = tb.sc + 64;
-    P8Mix mx;
+    P8Mix mx{};
     mx.turns0 = turns0;
     mx.frac = frac;
     double c, sn;
     mix_host_rotor(512u * frac, c, sn);
     mx.step512 = make_float2(static_cast<float>(c), static_cast<float>(sn));
+    mix_host_rotor(4u * frac, c, sn);
+    mx.step4 = make_float2(static_cast<float>(c), static_cast<float>(sn));
+    mx.keep = kind == 3 ? rate / 8 : 1;
+    if (mx.keep > 1) {  // o / m by multiplication (Granlund - Montgomery): l = ceil(log2 m), M = floor(2^32 (2^l - m) / m) + 1
+        unsigned lg = 0;
+        while ((1u << lg) < mx.keep) ++lg;
+        mx.div_m = static_cast<unsigned>(((static_cast<uint64_t>((1u << lg) - mx.keep) << 32) / mx.keep) + 1);
+        mx.div_s = lg - 1;
+    }
     P8Fm fmx{static_cast<const float2*>(fm_prev), static_cast<float2*>(fm_prev_new)};
+    const int nph = kind == 2 ? 2 : 1;
     comms_status_t st;
     if (h->in_fmt == COMMS_IQ_I16)
-        st = poly8_launch_in(hr, fm, h, s, InI16{static_cast<const short2*>(d_in), h->in_scale}, d_out, n, tb, mx, fmx);
+        st = poly8_launch_in(hr, fm, nph, h, s, InI16{static_cast<const short2*>(d_in), h->in_scale}, d_out, n, tb, mx, fmx);
     else if (h->in_fmt == COMMS_IQ_U8)
-        st = poly8_launch_in(hr, fm, h, s, InU8{static_cast<const uchar2*>(d_in)}, d_out, n, tb, mx, fmx);
+        st = poly8_launch_in(hr, fm, nph, h, s, InU8{static_cast<const uchar2*>(d_in)}, d_out, n, tb, mx, fmx);
     else
-        st = poly8_launch_in(hr, fm, h, s, static_cast<const float2*>(d_in), d_out, n, tb, mx, fmx);
+        st = poly8_launch_in(hr, fm, nph, h, s, static_cast<const float2*>(d_in), d_out, n, tb, mx, fmx);
     COMMS_TRY(st);
     h->cur ^= 1;
     h->last_poly8 = true;

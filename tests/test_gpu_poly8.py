@@ -103,7 +103,12 @@ def test_poly8_where_it_runs(c):
     # no spare halo position for the demodulator / more than 257 taps / another rate: the flag asks, the chain falls back
     assert c.ChainNode(0.3, 0.1, lpf(250, 0.05), 8, True, kernel="poly").kernel != "poly"
     assert c.ChainNode(0.3, 0.1, lpf(300, 0.05), 8, False, kernel="poly").kernel != "poly"
-    assert c.ChainNode(0.3, 0.1, t127, 4, False, kernel="poly").kernel != "poly"
+    assert c.ChainNode(0.3, 0.1, t127, 5, False, kernel="poly").kernel != "poly"
+    assert c.ChainNode(0.3, 0.1, t127, 72, False, kernel="poly").kernel != "poly"
+    assert c.ChainNode(0.3, 0.1, t127, 4, True, kernel="poly").kernel != "poly"  # FM demod: at rate 8 only
+    # rates 4 (two output phases) and 8 m up to 64 (every m-th output of the rate-8 form)
+    for rate in (4, 16, 24, 32, 40, 48, 56, 64):
+        assert c.ChainNode(0.3, 0.1, t127, rate, False, kernel="poly").kernel == "poly"
     rng = np.random.default_rng(3)
     x = rand_c(rng, 8 * 4096)
     # a chain of kind "time" at rate 8: from 64 taps every call runs on the polyphase kernel, and says so afterwards
@@ -216,3 +221,76 @@ def test_poly8_reads_raw_iq(c, fmt, fm, n_taps):
         assert np.max((circ(got.astype(np.float64) - want) * mag)[n_taps // 8 + 2:]) <= 4 * TOL * np.sum(np.abs(taps)) * np.max(np.abs(x))
     else:
         chain_close(got, y, taps, x)
+
+
+@pytest.mark.parametrize("rate", [4, 16, 24, 32, 40, 48, 56, 64])
+@pytest.mark.parametrize("n_taps,cplx,after", [(255, False, True), (257, True, False), (131, False, False), (100, True, True), (33, False, True)])
+def test_poly8_other_rates_against_oracle(c, rate, n_taps, cplx, after):
+    """Rate 4: the outputs y[8j + 4] too, from the same forward transforms through a second set of branch spectra (taps h[8m - c + 4])
+    and a second inverse half, interleaved with y[8j].  Rates 8 m: every m-th output of the rate-8 form.  Ragged calls (a single
+    output; lengths that are multiples of the rate but not of 8 at rate 4), state carried, both mixer orders."""
+    rng = np.random.default_rng(rate * 1000 + n_taps)
+    taps = oracle.rrc_taps(n_taps, 8.0, 0.35)
+    if cplx:
+        taps = (taps * np.exp(1j * 0.01 * np.arange(n_taps))).astype(np.complex64)
+    dphase, phase = 2 * np.pi * 0.1, 0.3
+    node = c.ChainNode(dphase, phase, taps, rate, False, mixer_after_fir=after, kernel="poly")
+    assert node.kernel == "poly"
+    n = rate * (34000 // rate + 11)
+    x = rand_c(rng, n)
+    ost, om = oracle.default_state(taps), oracle.Mixer(phase, dphase)
+    cuts = [0, rate, rate * 9, rate * (2500 // rate), rate * (9000 // rate + 1), n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if after:
+            w = oracle.decimate(om.mix(oracle.batch_fir(x[a:b], taps, ost, norotate=True)), rate)
+        else:
+            w = oracle.decimate(oracle.batch_fir(om.mix(x[a:b]), taps, ost, norotate=True), rate)
+        chain_close(node.run(x[a:b]), w, taps, x)
+    np.testing.assert_array_equal(node.fir_state(n_taps), x[::-1][:n_taps])
+
+
+def test_poly8_other_rates_where_the_chain_uses_it(c):
+    """An unforced chain reaches the kernel at rate 4 from 128 taps (64 on long batches), at rates 16 ... 56 from 32 taps, at rate 64
+    from 128 taps (the any-rate kernel keeps short filters on short batches: it reads only its windows), and says so."""
+    rng = np.random.default_rng(4)
+    x = rand_c(rng, 64 * 600)
+    for rate, n_taps, want in [(4, 255, "poly"), (4, 100, "time"), (16, 63, "poly"), (16, 17, "time"), (24, 200, "poly"), (40, 40, "poly"),
+                               (64, 255, "poly"), (64, 100, "time_any"), (72, 255, "time_any"), (12, 255, "time")]:
+        node = c.ChainNode(0.3, 0.1, lpf(n_taps, 1 / (2.5 * rate)), rate, False, mixer_after_fir=True)
+        node.run(x[: x.size - x.size % rate])
+        assert node.kernel == want, (rate, n_taps, node.kernel)
+    # and at rate 4 with the FM demodulator the chain stays where it was (overlap-save launch + demodulator)
+    assert c.ChainNode(0.3, 0.1, lpf(255, 0.1), 4, True).kernel == "freq"
+
+
+@pytest.mark.parametrize("rate", [4, 32])
+def test_poly8_other_rates_raw_iq_and_long_batches(c, rate):
+    """Raw i16 input at the other rates (bit for bit the converted stream's outputs), and a batch of thousands of ticketed segments
+    against the overlap-save fusion on every output."""
+    import torch
+
+    idx = np.arange(rate * 4000, dtype=np.float64)
+    z = np.exp(1j * (-2 * np.pi * 0.05 * idx + 8.0 * np.cos(2 * np.pi * idx / 4096)))
+    raw = np.stack([np.rint(z.real * 8192), np.rint(z.imag * 8192)], 1).astype(np.int16)
+    x = oracle.iq_i16_to_c32(raw, 1.0 / 8192)
+    taps = lpf(201, 1 / (2.5 * rate))
+    a = c.ChainNode(0.05, 0.3, taps, rate, False, kernel="poly").set_input_format("i16", 1.0 / 8192)
+    b = c.ChainNode(0.05, 0.3, taps, rate, False, kernel="poly")
+    cuts = [0, rate, rate * 1700, x.size]
+    got = np.concatenate([a.run(raw[p:q]) for p, q in zip(cuts[:-1], cuts[1:])])
+    ref = np.concatenate([b.run(x[p:q]) for p, q in zip(cuts[:-1], cuts[1:])])
+    assert np.array_equal(got, ref)
+    n = 768 * 9000 + rate * 5
+    n -= n % rate
+    xd = torch.empty(n, dtype=torch.complex64, device="cuda:0")
+    c.synth_iq_dev(xd.data_ptr(), n, 0, 77)
+    s = torch.cuda.current_stream().cuda_stream
+    ys = []
+    for kern in ("poly", "freq"):
+        node = c.ChainNode(0.7, 0.2, taps, rate, False, mixer_after_fir=True, kernel=kern)
+        y = torch.empty(n // rate, dtype=torch.complex64, device="cuda:0")
+        node.run_dev(xd.data_ptr(), n, y.data_ptr(), s)
+        torch.cuda.synchronize()
+        ys.append(y)
+    bound = 2 * TOL * float(np.sum(np.abs(taps))) * xd[: 1 << 20].abs().max().item()
+    assert (ys[0] - ys[1]).abs().max().item() <= 2 * bound
