@@ -25,7 +25,16 @@
 //             lower digit -> lane nu = l & 31 holds z[nu + 32 t], t = 0..3; t = 0 is the segment's halo, dropped
 //   store     out[96 seg + l] (64 lanes: t = 1 from lanes 0-31, t = 2 from lanes 32-63), out[96 seg + 64 + l] (t = 3)
 // A wave's LDS operations execute in order: the four exchanges share one private buffer, no barrier after set-up.
-// Segments are drawn from an LDS ticket counter per workgroup, dealt in round-robin chunks as in fir_os1024_dyn_kernel.
+// Segments are drawn from an LDS ticket counter per workgroup, dealt in round-robin chunks as in fir_os1024_dyn_kernel; the next
+// segment's rows are requested behind the forward half, with the previous segment's stores issued in front of them.
+//
+// Other rates on the same forward transforms (which are most of the work and are what every rate needs):
+//   rate 4       the outputs y[8j + 4] are the same phase streams through a second set of branch filters h[8m - c + 4]: a second
+//                spectra table, a second multiply and a second inverse half per segment; the two phases leave interleaved;
+//   rates 8 m    (16 ... 64) every m-th output of the rate-8 form is stored.
+// The FM demodulator (y[j-1] from the lane below; the halo position in front of a segment's first output serves that output:
+// 249 taps at most) comes at rate 8 only.  Halo rows by tap count (HR = 2 / 3 / 4: 896 / 832 / 768 new samples per segment), raw
+// i16 / u8 IQ converted in the load stage, four-wave workgroups for short batches.  Lane-accurate numpy model: scripts/proto_poly8.py.
 #include <hip/hip_ext.h>
 
 #include <cmath>
