@@ -304,12 +304,23 @@ __global__ __launch_bounds__(64 * WPB, 4) void fir_poly8_kernel(In in, const flo
             yb2 = cmulf(yb2, cmulf_s(rotb, step4));
             const size_t n4 = n >> 2;
             const size_t oa = static_cast<size_t>(2 * o), ob = oa + 128;
-            if (l >= Gm::HQ) {
-                if (!guard || oa < n4) out[oa] = to_f2(ya);
-                if (!guard || oa + 1 < n4) out[oa + 1] = to_f2(ya2);
+            if (mx.keep > 1) {  // rates 4 m (m odd): every m-th output of the rate-4 stream (32-bit indices: the launcher's condition)
+                const unsigned f[4] = {static_cast<unsigned>(oa), static_cast<unsigned>(oa) + 1u, static_cast<unsigned>(ob), static_cast<unsigned>(ob) + 1u};
+                const cf y4[4] = {ya, ya2, yb, yb2};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned t = __umulhi(mx.div_m, f[i]);
+                    const unsigned q = (t + ((f[i] - t) >> 1)) >> mx.div_s;
+                    if ((i >= 2 || l >= Gm::HQ) && q * mx.keep == f[i] && (!guard || f[i] < n4)) out[q] = to_f2(y4[i]);
+                }
+            } else {
+                if (l >= Gm::HQ) {
+                    if (!guard || oa < n4) out[oa] = to_f2(ya);
+                    if (!guard || oa + 1 < n4) out[oa + 1] = to_f2(ya2);
+                }
+                if (!guard || ob < n4) out[ob] = to_f2(yb);
+                if (!guard || ob + 1 < n4) out[ob + 1] = to_f2(yb2);
             }
-            if (!guard || ob < n4) out[ob] = to_f2(yb);
-            if (!guard || ob + 1 < n4) out[ob + 1] = to_f2(yb2);
         } else if (!FM) {
             if (mx.keep > 1) {  // rates 8 m: output o is kept when m divides it (o < 2^32: the launcher's condition)
                 const unsigned oa = static_cast<unsigned>(o), ob = oa + 64u;
@@ -535,9 +546,12 @@ comms_status_t poly8_launch_in(int hr, bool fm, int nph, comms_fir* h, hipStream
     }
 }
 
-// What the kernel does for a decimation rate: 8 (one output phase), 4 (two), 8 m up to 64 (every m-th output of the rate-8 form:
-// the forward transforms are what any rate needs); 0: not this kernel
-int poly8_rate_kind(uint32_t rate) { return rate == 8 ? 1 : rate == 4 ? 2 : (rate % 8 == 0 && rate >= 16 && rate <= 64) ? 3 : 0; }
+// What the kernel does for a decimation rate: 1: 8 (one output phase), 2: 4 (two), 3: 8 m up to 64 (every m-th output of the rate-8
+// form: the forward transforms are what any rate needs); 0: not this kernel
+// 4: rates 4 m', m' odd, up to 60 (every m'-th output of the rate-4 form)
+int poly8_rate_kind(uint32_t rate) {
+    return rate == 8 ? 1 : rate == 4 ? 2 : (rate % 8 == 0 && rate >= 16 && rate <= 64) ? 3 : (rate % 4 == 0 && rate >= 12 && rate <= 60) ? 4 : 0;
+}
 
 }  // namespace
 
@@ -549,7 +563,7 @@ int32_t comms_fir_poly8_supported(const comms_fir_t* h, uint32_t rate, int32_t m
     if (!h || !kind || h->n_eff < 1 || n < rate) return 0;
     const bool fm = (mode & COMMS_CHAIN_FM) != 0;
     if (!(mode & COMMS_CHAIN_DEC) || !poly8_halo_rows(h->n_eff, fm) || (fm && kind != 1)) return 0;
-    if (kind == 3 && (n >> 3) > 0xFFFFFFFFull) return 0;  // (its output index arithmetic is 32 bits wide)
+    if (kind >= 3 && (n >> 2) > 0xFFFFFFFFull) return 0;  // (its output index arithmetic is 32 bits wide)
     static const int knob = diag_knob("COMMS_POLY8", 1);          // 0: never, 1: where it wins, 2: wherever it can run
     if (!knob || h->no_poly8) return 0;
     if (knob == 2) return 2;
@@ -566,6 +580,9 @@ int32_t comms_fir_poly8_supported(const comms_fir_t* h, uint32_t rate, int32_t m
     // 16: 38.8 -> 26.5 us).  Rate 64: the any-rate kernel reads only its windows when rate >= taps and keeps the short batches
     // (4.5 against 6.6 us at 2^16 samples); from 2^23 samples, or 128 taps, this one.
     if (kind == 2) return N >= 2 * min_taps || (N >= min_taps && n >= (static_cast<size_t>(1) << 22)) ? 2 : 1;
+    // rates 12, 20, ... 60 (two output phases, every (rate / 4)-th output kept; 255 taps at 2^24 samples: rate 12 39.2 -> 34.7 us, 20
+    // 41.8 -> 34.9, 28 level, 44 and 60 behind the any-rate kernel): ahead at 12 and 20 with long filters only
+    if (kind == 4) return rate <= 20 && N >= 3 * min_taps ? 2 : 1;
     if (rate < 64) return N >= min_taps / 2 ? 2 : 1;
     return N >= 2 * min_taps || n >= (static_cast<size_t>(1) << 23) ? 2 : 1;
 }
@@ -576,13 +593,13 @@ comms_status_t comms_fir_run_poly8_dev(comms_fir_t* h, const void* d_in, size_t 
     COMMS_ARG(h != nullptr, "handle is NULL");
     COMMS_ARG((d_in && d_out) || !n, "NULL device pointer");
     const int kind = poly8_rate_kind(rate);
-    COMMS_ARG(kind != 0, "the polyphase kernel runs rates 4, 8 and multiples of 8 up to 64");
+    COMMS_ARG(kind != 0, "the polyphase kernel runs rates 4, 8 and multiples of 4 up to 64");
     COMMS_ARG(n % rate == 0, "n must be a multiple of the decimation rate");
     const bool fm = (mode & COMMS_CHAIN_FM) != 0;
     const int hr = poly8_halo_rows(h->n_eff, fm);
     COMMS_ARG(hr != 0, "the polyphase kernel takes <= 257 taps (249 with FM demod)");
     COMMS_ARG(!fm || kind == 1, "the polyphase kernel demodulates at rate 8 only");
-    COMMS_ARG(kind != 3 || (n >> 3) <= 0xFFFFFFFFull, "batch too long for the polyphase kernel at this rate");
+    COMMS_ARG(kind < 3 || (n >> 2) <= 0xFFFFFFFFull, "batch too long for the polyphase kernel at this rate");
     COMMS_ARG((mode & COMMS_CHAIN_DEC) && !((mode & COMMS_CHAIN_PRE) && (mode & COMMS_CHAIN_POST)), "bad chain mode");
     COMMS_ARG(!fm || (fm_prev && fm_prev_new), "FM demod needs its state");
     COMMS_TRY(fir_check_sticky(h));
@@ -607,7 +624,7 @@ comms_status_t comms_fir_run_poly8_dev(comms_fir_t* h, const void* d_in, size_t 
     mx.step512 = make_float2(static_cast<float>(c), static_cast<float>(sn));
     mix_host_rotor(4u * frac, c, sn);
     mx.step4 = make_float2(static_cast<float>(c), static_cast<float>(sn));
-    mx.keep = kind == 3 ? rate / 8 : 1;
+    mx.keep = kind == 3 ? rate / 8 : kind == 4 ? rate / 4 : 1;
     if (mx.keep > 1) {  // o / m by multiplication (Granlund - Montgomery): l = ceil(log2 m), M = floor(2^32 (2^l - m) / m) + 1
         unsigned lg = 0;
         while ((1u << lg) < mx.keep) ++lg;
@@ -615,7 +632,7 @@ comms_status_t comms_fir_run_poly8_dev(comms_fir_t* h, const void* d_in, size_t 
         mx.div_s = lg - 1;
     }
     P8Fm fmx{static_cast<const float2*>(fm_prev), static_cast<float2*>(fm_prev_new)};
-    const int nph = kind == 2 ? 2 : 1;
+    const int nph = kind == 2 || kind == 4 ? 2 : 1;
     comms_status_t st;
     if (h->in_fmt == COMMS_IQ_I16)
         st = poly8_launch_in(hr, fm, nph, h, s, InI16{static_cast<const short2*>(d_in), h->in_scale}, d_out, n, tb, mx, fmx);

@@ -18,13 +18,13 @@ def rand_c(n):
 
 
 worst = 0.0
-for rate in (4, 16, 24, 32, 40, 64):
+for rate in (4, 12, 20, 28, 60, 16, 24, 32, 40, 64):
     for n_taps, cplx, after in [(255, False, True), (257, True, False), (131, False, False), (100, True, True), (65, False, True)]:
         taps = oracle.rrc_taps(n_taps, 8.0, 0.35)
         if cplx:
             taps = (taps * np.exp(1j * 0.01 * np.arange(n_taps))).astype(np.complex64)
         dphase, phase = 2 * np.pi * 0.1, 0.3
-        node = c.ChainNode(dphase, phase, taps, rate, False, mixer_after_fir=after)
+        node = c.ChainNode(dphase, phase, taps, rate, False, mixer_after_fir=after, kernel="poly")
         n = rate * (896 * 37 // rate * 8 // 8 + 11)
         x = rand_c(n)
         ost, om = oracle.default_state(taps), oracle.Mixer(phase, dphase)
@@ -47,7 +47,7 @@ n = 1 << 24
 x = torch.empty(n, dtype=torch.complex64, device="cuda:0")
 c.synth_iq_dev(x.data_ptr(), n, 0)
 s = torch.cuda.current_stream().cuda_stream
-for rate in (4, 8, 16, 24, 32, 48, 64):
+for rate in (4, 8, 12, 20, 28, 44, 60, 16, 24, 32, 48, 64):
     nn = n - n % (rate * 1024)
     kerns = ("time", "freq", "auto")
     nodes = [c.ChainNode(2 * np.pi * 0.05, 0.1, taps, rate, False, mixer_after_fir=True, kernel=k) for k in kerns]

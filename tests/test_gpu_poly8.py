@@ -107,7 +107,7 @@ def test_poly8_where_it_runs(c):
     assert c.ChainNode(0.3, 0.1, t127, 72, False, kernel="poly").kernel != "poly"
     assert c.ChainNode(0.3, 0.1, t127, 4, True, kernel="poly").kernel != "poly"  # FM demod: at rate 8 only
     # rates 4 (two output phases) and 8 m up to 64 (every m-th output of the rate-8 form)
-    for rate in (4, 16, 24, 32, 40, 48, 56, 64):
+    for rate in (4, 16, 24, 32, 40, 48, 56, 64, 12, 20, 60):
         assert c.ChainNode(0.3, 0.1, t127, rate, False, kernel="poly").kernel == "poly"
     rng = np.random.default_rng(3)
     x = rand_c(rng, 8 * 4096)
@@ -223,11 +223,12 @@ def test_poly8_reads_raw_iq(c, fmt, fm, n_taps):
         chain_close(got, y, taps, x)
 
 
-@pytest.mark.parametrize("rate", [4, 16, 24, 32, 40, 48, 56, 64])
+@pytest.mark.parametrize("rate", [4, 16, 24, 32, 40, 48, 56, 64, 12, 20, 28, 36, 44, 52, 60])
 @pytest.mark.parametrize("n_taps,cplx,after", [(255, False, True), (257, True, False), (131, False, False), (100, True, True), (33, False, True)])
 def test_poly8_other_rates_against_oracle(c, rate, n_taps, cplx, after):
     """Rate 4: the outputs y[8j + 4] too, from the same forward transforms through a second set of branch spectra (taps h[8m - c + 4])
-    and a second inverse half, interleaved with y[8j].  Rates 8 m: every m-th output of the rate-8 form.  Ragged calls (a single
+    and a second inverse half, interleaved with y[8j].  Rates 8 m: every m-th output of the rate-8 form; rates 4 m (m odd): every
+    m-th output of the rate-4 form.  Ragged calls (a single
     output; lengths that are multiples of the rate but not of 8 at rate 4), state carried, both mixer orders."""
     rng = np.random.default_rng(rate * 1000 + n_taps)
     taps = oracle.rrc_taps(n_taps, 8.0, 0.35)
@@ -255,7 +256,8 @@ def test_poly8_other_rates_where_the_chain_uses_it(c):
     rng = np.random.default_rng(4)
     x = rand_c(rng, 64 * 600)
     for rate, n_taps, want in [(4, 255, "poly"), (4, 100, "time"), (16, 63, "poly"), (16, 17, "time"), (24, 200, "poly"), (40, 40, "poly"),
-                               (64, 255, "poly"), (64, 100, "time_any"), (72, 255, "time_any"), (12, 255, "time")]:
+                               (64, 255, "poly"), (64, 100, "time_any"), (72, 255, "time_any"), (12, 255, "poly"), (12, 127, "time"),
+                               (20, 255, "poly"), (28, 255, "time_any"), (10, 255, "time")]:
         node = c.ChainNode(0.3, 0.1, lpf(n_taps, 1 / (2.5 * rate)), rate, False, mixer_after_fir=True)
         node.run(x[: x.size - x.size % rate])
         assert node.kernel == want, (rate, n_taps, node.kernel)
