@@ -103,6 +103,28 @@ def pmc_traffic(kernel, n):
     return None
 
 
+def copy_ceiling(torch, src, dst, reps=9):
+    """What the memory system gives a plain device copy of this footprint in this run (hipMemcpyDtoD: 8 B read + 8 B written per
+    Complex<f32>): the practical ceiling of a kernel that reads its input once and writes as much -- the spec peak the roofline
+    fraction is quoted against is not reachable by any such kernel on this chip."""
+    n = min(src.numel(), dst.numel())
+    for _ in range(2):
+        dst[:n].copy_(src[:n])
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        dst[:n].copy_(src[:n])
+        b.record()
+    torch.cuda.synchronize()
+    ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+    gbs = 2.0 * n * src.element_size() / (ms * 1e-3) / 1e9
+    return {"copy_GBps": round(gbs, 1), "copy_ms": round(ms, 5), "copy_bytes": 2 * n * src.element_size(),
+            "frac_at_copy_rate": round(gbs / HBM_PEAK_GBS, 4),
+            "note": "a plain device copy (hipMemcpyDtoD) of the same footprint, timed in this run" +
+                    (": about the size of the 256 MiB Infinity Cache, which serves part of it -- above what HBM alone gives"
+                     if 2 * n * src.element_size() <= (320 << 20) else ": far past the Infinity Cache, HBM's own rate for this read + write mix")}
+
+
 def fm_radio_taps():
     """The 63 taps of examples/fm_radio.rs:30-52 (a fixture: data the reference holds)."""
     with open(os.path.join(ROOT, "tests", "golden", "reference_kats.json")) as f:
@@ -718,7 +740,8 @@ def fir_chain_pass(ctx, n, first_index, steps, warmup, algo="auto", stride=TIMER
     zf = torch.empty_like(z)
     fused_elapsed = ctx.timed(lambda: chain.run_dev(x.data_ptr(), n, zf.data_ptr(), s), steps, max(warmup, 1))
     kernel_ms = float(np.mean(kms)) if kms.size else float("nan")
-    res = {"elapsed": elapsed, "fused_elapsed": fused_elapsed, "ranks": rank_report(ctx, kernel_ms),
+    ceiling = copy_ceiling(torch, x, y)  # (behind every timed region)
+    res = {"elapsed": elapsed, "fused_elapsed": fused_elapsed, "ranks": rank_report(ctx, kernel_ms), "ceiling": ceiling,
            "kernel_ms": kernel_ms, "launches_timed": int(kms.size), "kernel_ms_each": [round(float(v), 5) for v in kms],
            "in_stream": in_stream_fields(sms), "in_stream_each": [round(float(v), 5) for v in sms],
            "timer_stride": stride, "algo": fir.kernel_for(n), "fused": chain.fused, "fused_kernel": chain.kernel, "transfer": transfer}
@@ -854,7 +877,7 @@ def run_config2(ctx):
                      **head["in_stream"],
                      "frac_in_stream": (round(FIR_BYTES_PER_SAMPLE * n / (head["in_stream"]["kernel_ms_in_stream"] * 1e-3) / 1e9
                                               / HBM_PEAK_GBS, 4) if head["in_stream"]["kernel_ms_in_stream"] else None),
-                     "algorithmic_bytes_per_launch": FIR_BYTES_PER_SAMPLE * n},
+                     "algorithmic_bytes_per_launch": FIR_BYTES_PER_SAMPLE * n, "ceiling": head["ceiling"]},
         "ranks": head["ranks"],
         "box": box_info(ctx.torch, ctx.local_rank),
     }
@@ -885,7 +908,7 @@ def run_config2(ctx):
             "fir_kernel": st["algo"], "fir_kernel_ms": round(st["kernel_ms"], 5),
             "fir_kernel_ms_each": st["kernel_ms_each"], "timer_stride": st["timer_stride"],
             "fir_kernel_ms_in_stream": st["in_stream"]["kernel_ms_in_stream"], "fir_kernel_ms_in_stream_each": st["in_stream_each"],
-            "fir_hbm_GBps": round(ach, 1), "fir_frac_of_peak": round(ach / HBM_PEAK_GBS, 4),
+            "fir_hbm_GBps": round(ach, 1), "fir_frac_of_peak": round(ach / HBM_PEAK_GBS, 4), "ceiling": st["ceiling"],
             "fir_kernel_ms_per_rank": st["ranks"]["kernel_ms_per_rank"],
             "note": "%.2f GiB of FIR input + output per GPU (HBM-resident once this is far past the 256 MiB "
                     "Infinity Cache)" % (16.0 * st["per"] / 2 ** 30)}
@@ -961,6 +984,8 @@ def run_config3(ctx):
     ctx.collect(out, transfer)
     kernel_ms = float(np.mean(kms))
     ranks = rank_report(ctx, kernel_ms)
+    # (a plain copy moving about as many bytes as the chain does: half the input onto itself's other half, 8 n of its 8.5 n bytes)
+    ceiling = copy_ceiling(torch, x[: n // 2], x[n // 2:]) if args.variant != "scatter" else None
     # ---- the literal example beside it (examples/fm_radio.rs:144-152 with its own 63 taps): RTL-SDR bytes -> 63-tap FIR
     # -> /5 -> FM demod as ONE launch (u8 read by the kernel's load stage), then Convert2 -> 63-tap FIR -> Convert3 -> /5
     # as the example wires them, device-resident
@@ -1004,7 +1029,7 @@ def run_config3(ctx):
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                         "traffic": pmc_traffic(c3_kernel, n),
                         "kernel_ms": round(kernel_ms, 5), "launches_timed": int(kms.size), "timer_stride": TIMER_STRIDE,
-                        **in_stream_fields(sms), "algorithmic_bytes_per_launch": C3_BYTES_PER_SAMPLE * n}}
+                        **in_stream_fields(sms), "algorithmic_bytes_per_launch": C3_BYTES_PER_SAMPLE * n, "ceiling": ceiling}}
     res["literal_example"] = {"value": round(float(world) * nl * lit_steps / lit_elapsed / 1e6, 1), "unit": "Msamples/s",
                               "ms_per_step": round(lit_elapsed / lit_steps * 1e3, 4), "input_samples_per_gpu_per_step": nl,
                               "front_kernel": lit_kernel,
@@ -1073,6 +1098,7 @@ def run_config5(ctx):
     ctx.collect(y, transfer)
     kernel_ms = float(np.mean(kms))
     ranks = rank_report(ctx, kernel_ms)
+    ceiling = copy_ceiling(torch, x, y)
     if rank != 0:
         return None
     ach = FIR_BYTES_PER_SAMPLE * n / (kernel_ms * 1e-3) / 1e9
@@ -1088,7 +1114,7 @@ def run_config5(ctx):
            "roofline": {"bound": "hbm", "kernel": fir.kernel_for(n), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(fir.kernel_for(n), n),
                         "kernel_ms": round(kernel_ms, 5), "launches_timed": int(kms.size), "timer_stride": TIMER_STRIDE,
-                        **in_stream_fields(sms), "algorithmic_bytes_per_launch": FIR_BYTES_PER_SAMPLE * n}}
+                        **in_stream_fields(sms), "algorithmic_bytes_per_launch": FIR_BYTES_PER_SAMPLE * n, "ceiling": ceiling}}
     res["world_size_seen"], res["ranks"] = ranks["world_size_seen"], ranks
     if transfer:
         res["transfer"] = transfer
