@@ -388,9 +388,11 @@ __device__ __forceinline__ void load_rows(In in, size_t nb, int l, size_t n,
 // `lds` is the calling wave's private exchange buffer; stamp(i) marks the diagnostic phases.
 // hsp[i * HS + l] is the spectrum factor of register i (LDS table, HS = 64; or global memory, HS = 1024: the
 // 16384-point kernel, whose 16 waves each filter one 1024-point slice with their own part of the spectrum).
-template <int HS = 64, class Stamp>
-__device__ __forceinline__ void os1024_core(cf (&v)[16], cf* lds, const cf* tw1, const cf* hsp, const cf* tw2, int l,
-                                            Stamp&& stamp, int hl = -1) {
+// t1r / t2r: this lane's column of the stage-1 / stage-2 twiddle tables held in registers by the caller (the tables are read-only,
+// but the compiler must reload them from LDS for every segment), or null
+template <int HS = 64, int RT = 0, class Stamp>
+__device__ __forceinline__ void os1024_core_rt(cf (&v)[16], cf* lds, const cf* tw1, const cf* hsp, const cf* tw2, int l,
+                                               Stamp&& stamp, int hl, const cf (&t1r)[16], const cf (&t2r)[16]) {
     if (HS == 64) hl = l;  // hl: this lane's column of the spectrum table (the 16384-point kernel: its thread index,
                            // on a workgroup-uniform base pointer -- the loads then take the SGPR-base form and share
                            // one offset register instead of sixteen 64-bit addresses)
@@ -400,7 +402,7 @@ __device__ __forceinline__ void os1024_core(cf (&v)[16], cf* lds, const cf* tw1,
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         cf x = v[R16_POS(k)];
-        if (k) x = cmulf(x, tw1[k * 64 + l]);
+        if (k) x = cmulf(x, (RT & 2) ? t1r[k] : tw1[k * 64 + l]);
         lds[k * W_S1 + l] = x;
     }
     wave_lds_sync();
@@ -422,7 +424,7 @@ __device__ __forceinline__ void os1024_core(cf (&v)[16], cf* lds, const cf* tw1,
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         r[k] = v[R16_POS(k)];
-        if (k) r[k] = cmulf(r[k], tw2[k * 4 + q1]);
+        if (k) r[k] = cmulf(r[k], (RT & 1) ? t2r[k] : tw2[k * 4 + q1]);
     }
     stamp(3);  // R16 + twiddle (stage 2)
     // The 16384-point kernel's spectrum lives in global memory (L2).  Its sixteen loads go out in two batches
@@ -483,7 +485,7 @@ __device__ __forceinline__ void os1024_core(cf (&v)[16], cf* lds, const cf* tw1,
     stamp(5);  // spectrum multiply + inverse radix-4 across lanes
     // ---- inverse: lane (k0,c) = (q0,q1): conj W64^{c*k1}, R16 over k1 -> b
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = k ? cmulcf(r[k], tw2[k * 4 + q1]) : r[k];
+    for (int k = 0; k < 16; ++k) v[k] = k ? cmulcf(r[k], (RT & 1) ? t2r[k] : tw2[k * 4 + q1]) : r[k];
     stamp(6);  // conj twiddle (stage 2)
     radix16<1>(v);
 #pragma unroll
@@ -494,11 +496,18 @@ __device__ __forceinline__ void os1024_core(cf (&v)[16], cf* lds, const cf* tw1,
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         cf x = lds[k * W_S4 + l];
-        v[k] = k ? cmulcf(x, tw1[k * 64 + l]) : x;
+        v[k] = k ? cmulcf(x, (RT & 2) ? t1r[k] : tw1[k * 64 + l]) : x;
     }
     wave_lds_sync();
     stamp(8);  // exchange-4 reads + twiddle
     radix16<1>(v);
+}
+
+template <int HS = 64, class Stamp>
+__device__ __forceinline__ void os1024_core(cf (&v)[16], cf* lds, const cf* tw1, const cf* hsp, const cf* tw2, int l,
+                                            Stamp&& stamp, int hl = -1) {
+    const cf none[16] = {};
+    os1024_core_rt<HS, 0>(v, lds, tw1, hsp, tw2, l, stamp, hl, none, none);
 }
 
 // Diagnostic builds only: when a wave started, finished the workgroup's set-up and ended
@@ -781,6 +790,23 @@ __global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(In in,
         for (int a = 0; a < 16; ++a) r[a] = to_cf(in[p + 64 * a]);
     };
     auto nostamp = [](int) {};
+#ifndef COMMS_OS1024_REG_TW
+#define COMMS_OS1024_REG_TW 1
+#endif
+    // The lane's column of the stage-2 twiddle table (bit 0) in registers instead of 30 LDS reads per segment: the tables are
+    // read-only, but the compiler must reload them for every segment; the kernel has 64 VGPRs to spare at its sixteen waves per
+    // CU.  Same values, same arithmetic.  Three builds alternating launch by launch (scripts/build_variant.sh, ab_libs.py; 255
+    // taps): 2^22 samples 19.2 -> 18.8 us, 2^24 50.0 -> 49.3, 2^26 199.2 -> 198.7; with the stage-1 column as well (bit 1: 124
+    // VGPRs) 18.2 / 49.5 / 198.0 -- no better where it matters, not used.
+    cf t1r[16], t2r[16];
+    if (COMMS_OS1024_REG_TW & 1) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t2r[k] = tw2[k * 4 + (l >> 4)];
+    }
+    if (COMMS_OS1024_REG_TW & 2) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t1r[k] = tw1[k * 64 + l];
+    }
 
     size_t count = 0;
     cf v[16];
@@ -801,7 +827,7 @@ __global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(In in,
             load_rows(in, nb, l, n, nw);
 #pragma unroll
             for (int a = HR; a < 16; ++a) v[a] = nw[a - HR];
-            os1024_core(v, lds, tw1, hsp, tw2, l, nostamp);
+            os1024_core_rt<64, COMMS_OS1024_REG_TW>(v, lds, tw1, hsp, tw2, l, nostamp, -1, t1r, t2r);
 #pragma unroll
             for (int a = HR; a < 16; ++a) {
                 const size_t i = nb + 64 * (a - HR) + l;
@@ -822,7 +848,7 @@ __global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(In in,
     // gives its 1.33x-overlapped read stream and its write stream together (NOTES.md).
     cf w[16];
     auto finish = [&](size_t sg, cf (&r)[16]) {
-        os1024_core(r, lds, tw1, hsp, tw2, l, nostamp);
+        os1024_core_rt<64, COMMS_OS1024_REG_TW>(r, lds, tw1, hsp, tw2, l, nostamp, -1, t1r, t2r);
         float2* o = out + sg * WVK + l;
 #pragma unroll
         for (int a = HR; a < 16; ++a) o[64 * (a - HR)] = to_f2(r[R16_POS(a)]);
@@ -844,7 +870,7 @@ __global__ __launch_bounds__(1024, 4) void fir_os1024_dyn_kernel(In in,
     while (seg < hi) {
         fetch(seg, v);
         const size_t seg_next = draw();  // the ticket's LDS round trip hides behind the loads
-        os1024_core(v, lds, tw1, hsp, tw2, l, nostamp);
+        os1024_core_rt<64, COMMS_OS1024_REG_TW>(v, lds, tw1, hsp, tw2, l, nostamp, -1, t1r, t2r);
         float2* o = out + seg * WVK + l;
 #pragma unroll
         for (int a = HR; a < 16; ++a) o[64 * (a - HR)] = to_f2(v[R16_POS(a)]);
