@@ -432,3 +432,13 @@ def test_no_environment_switch_reaches_a_product_launch_path():
     assert allowed <= found, "allow-list entries that no longer exist: %s" % sorted(allowed - found)
     # and the results-changing debug switch of round 4 is gone from every build's launch path
     assert 'getenv("COMMS_DECIM_DEBUG_NOMAC")' not in open(os.path.join(csrc, "fir_decim.hip")).read()
+
+
+def test_polyphase_chain_kernel_lane_model():
+    """scripts/proto_poly8.py: the lane-accurate numpy model of fir_poly8_kernel (index maps, exchange layouts, lane swaps, both
+    output phases) against the direct sum y[8j] = sum_k h[k] x[8j - k] -- the description the kernel was written from."""
+    import subprocess
+    import sys
+
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "proto_poly8.py")], text=True, timeout=300)
+    assert out.strip().endswith("OK"), out
