@@ -133,8 +133,13 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
     const bool poly_pref = decim_ok >= 1 && !(flags & COMMS_CHAIN_TIME_DOMAIN) &&
                            comms_fir_poly8_supported(h->fir, static_cast<uint32_t>(rate), COMMS_CHAIN_DEC | (h->fm_demod ? COMMS_CHAIN_FM : 0),
                                                      static_cast<size_t>(1) << 26) == 2;
+    // FM chains at the rates that kernel runs without its demodulator (4, 16 ... 64): mixer / FIR / decimate on it and the
+    // demodulator as its own small launch over the n / rate kept samples, where the kernel takes EVERY call of this filter (asked
+    // with the shortest batch) -- rate 4, 255 taps, 2^24 samples: ~46 us against 70 for the overlap-save launch + demodulator
+    const bool poly_sep = h->fm_demod && st == COMMS_OK && rate != 8 && !(flags & (COMMS_CHAIN_TIME_DOMAIN | COMMS_CHAIN_FREQ_DOMAIN | COMMS_CHAIN_UNFUSED)) &&
+                          comms_fir_poly8_supported(h->fir, static_cast<uint32_t>(rate), COMMS_CHAIN_DEC, rate) == 2;
     const bool can_decim = !(flags & (COMMS_CHAIN_UNFUSED | COMMS_CHAIN_FREQ_DOMAIN)) &&
-                           (decim_ok == 2 || poly_pref || (decim_ok == 1 && (flags & COMMS_CHAIN_TIME_DOMAIN)));
+                           (decim_ok == 2 || poly_pref || (poly_sep && decim_ok >= 1) || (decim_ok == 1 && (flags & COMMS_CHAIN_TIME_DOMAIN)));
     // Rates the per-rate kernel is not built for (17 and up; 11 / 13 / 15 with complex taps): the any-rate kernel (half
     // a wave per output).  Against the overlap-save launch it replaces (58-61 us at 2^24 samples whatever the rate): 255
     // taps 60 us at rate 17, 53 at 20, 39 at 32, 30 at 100, 11 at 1000; 127 taps 49 at 17; 63 taps 45 at 17
@@ -185,7 +190,9 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
     if (st == COMMS_OK && can_any) {
         h->fused = true;
         h->decim_any = true;
-        h->mode = COMMS_CHAIN_POST | COMMS_CHAIN_DEC | (h->fm_demod ? COMMS_CHAIN_FM : 0);
+        h->fm_separate = poly_sep;
+        h->mode = COMMS_CHAIN_POST | COMMS_CHAIN_DEC | (h->fm_demod && !poly_sep ? COMMS_CHAIN_FM : 0);
+        if (h->fm_separate) st = comms_fmdemod_create(device, &h->fm);
         h->frac = mix_to_turns(mix_wrap_dphase(dphase));
         h->turns = mix_to_turns(phase);
         for (int i = 0; i < 2 && st == COMMS_OK; ++i) {
@@ -196,7 +203,7 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
     } else if (st == COMMS_OK && (can_fuse || can_decim || can_hybrid)) {
         h->fused = true;
         h->decim = can_decim;
-        h->fm_separate = !can_decim && !can_fuse;
+        h->fm_separate = (!can_decim && !can_fuse) || (can_decim && poly_sep);
         h->mode = (h->mixer_after ? COMMS_CHAIN_POST : COMMS_CHAIN_PRE) | COMMS_CHAIN_DEC |
                   (h->fm_demod && !h->fm_separate ? COMMS_CHAIN_FM : 0);
         if (h->fm_separate) st = comms_fmdemod_create(device, &h->fm);

@@ -261,8 +261,8 @@ def test_poly8_other_rates_where_the_chain_uses_it(c):
         node = c.ChainNode(0.3, 0.1, lpf(n_taps, 1 / (2.5 * rate)), rate, False, mixer_after_fir=True)
         node.run(x[: x.size - x.size % rate])
         assert node.kernel == want, (rate, n_taps, node.kernel)
-    # and at rate 4 with the FM demodulator the chain stays where it was (overlap-save launch + demodulator)
-    assert c.ChainNode(0.3, 0.1, lpf(255, 0.1), 4, True).kernel == "freq"
+    # at rate 4 with the FM demodulator and a short filter the chain stays where it was
+    assert c.ChainNode(0.3, 0.1, lpf(63, 0.1), 4, True).kernel == "time"
 
 
 @pytest.mark.parametrize("rate", [4, 32])
@@ -296,3 +296,27 @@ def test_poly8_other_rates_raw_iq_and_long_batches(c, rate):
         ys.append(y)
     bound = 2 * TOL * float(np.sum(np.abs(taps))) * xd[: 1 << 20].abs().max().item()
     assert (ys[0] - ys[1]).abs().max().item() <= 2 * bound
+
+
+@pytest.mark.parametrize("rate,n_taps", [(4, 255), (4, 129), (16, 200), (24, 65), (32, 255), (64, 249), (12, 255)])
+def test_poly8_other_rates_with_a_separate_demodulator(c, rate, n_taps):
+    """FM chains at the rates the polyphase kernel runs without its own demodulator: mixer / FIR / decimate on it, FMDemodNode's
+    kernel behind it over the kept samples -- the oracle's four nodes in series, ragged calls, FM.prev carried."""
+    rng = np.random.default_rng(rate + n_taps)
+    taps = lpf(n_taps, 1 / (2.5 * rate))
+    n = rate * (40000 // rate + 7)
+    t = np.arange(n)
+    x = (np.exp(1j * (0.02 * t + 3.0 * np.sin(2 * np.pi * t / 5000.0))) * (1 + 0.1 * rng.standard_normal(n))).astype(np.complex64)
+    node = c.ChainNode(0.3, 0.1, taps, rate, True)
+    ost, om, ofm = oracle.default_state(taps), oracle.Mixer(0.1, 0.3), oracle.FM()
+    cuts = [0, rate, rate * 3, rate * (9000 // rate), n]
+    last = 0j
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        y = oracle.decimate(oracle.batch_fir(om.mix(x[a:b]), taps, ost, norotate=True), rate)
+        w = ofm.demod(y)
+        got = node.run(x[a:b])
+        assert node.kernel == "poly"
+        mag = np.minimum(np.abs(y), np.abs(np.concatenate([[last], y[:-1]])))
+        last = y[-1]
+        assert np.max(circ(got.astype(np.float64) - w) * mag) <= 4 * TOL * np.sum(np.abs(taps)) * np.max(np.abs(x))
+    assert abs(complex(node.fm_prev) - complex(y[-1])) <= 2 * TOL * np.sum(np.abs(taps)) * np.max(np.abs(x))
