@@ -22,8 +22,9 @@
 //   reduce    exchange 2 [k2][cg][k1]; lane (k1, j = l >> 4) sums the four cg of k2 = j and k2 = j + 4
 //   inverse   DFT8 over k2: in-lane radix 2, then v_permlane32_swap / v_permlane16_swap butterflies over j;
 //             x w128^{q1 k1}; exchange 3 [q1][k1]; DFT4 over k1's upper digit; twiddle; exchange 4; DFT4 over the
-//             lower digit -> lane nu = l & 31 holds z[nu + 32 t], t = 0..3; t = 0 is the segment's halo, dropped
-//   store     out[96 seg + l] (64 lanes: t = 1 from lanes 0-31, t = 2 from lanes 32-63), out[96 seg + 64 + l] (t = 3)
+//             lower digit -> lane nu = l & 31 holds z[nu + 32 t], t = 0..3, folded into two registers of 64 positions
+//             (ya = z[l], yb = z[64 + l]); the first 8 HR positions are the segment's halo
+//   store     out[OUT seg + l - 8 HR] (lanes from 8 HR on) and 64 further on, behind the mixer rotor (and the FM demodulator)
 // A wave's LDS operations execute in order: the four exchanges share one private buffer, no barrier after set-up.
 // Segments are drawn from an LDS ticket counter per workgroup, dealt in round-robin chunks as in fir_os1024_dyn_kernel; the next
 // segment's rows are requested behind the forward half, with the previous segment's stores issued in front of them.
@@ -54,7 +55,7 @@ template <int HR>
 struct P8Geom {
     static constexpr int HQ = 8 * HR, HALO = 64 * HR, NEW = 1024 - 64 * HR, OUT = 128 - 8 * HR;
 };
-// LDS: G [16][64], forward twiddle [16][8], sin / cos table [64], 16 exchange buffers, ticket
+// LDS: NPH spectra tables G [16][64], forward twiddle [16][8], sin / cos table [64], WPB exchange buffers, ticket
 constexpr int P8_TAB = 128 + 64;  // forward twiddle + sin / cos table; in front of them NPH spectra tables of 1024
 constexpr size_t p8_lds_bytes(int wpb, int nph) { return (1024 * static_cast<size_t>(nph) + P8_TAB + static_cast<size_t>(wpb) * P8_BUF) * sizeof(float2) + 16; }
 
