@@ -1033,7 +1033,8 @@ public:
         if (st != COMMS_OK) return to_node_error(st);
         return out;
     }
-    int fused_kind() const {  // 0 four kernels, 1 overlap-save fusion, 2 time-domain decimating kernel, 3 its any-rate form
+    int fused_kind() const {  // 0 four kernels, 1 overlap-save fusion, 2 time-domain decimating kernel, 3 its any-rate form, 4 the polyphase
+                              // frequency-domain kernel (what the last call ran on: rates 4, 8, 12 ... 64)
         int32_t f = 0;
         comms_chain_is_fused(h_, &f);
         return f;
