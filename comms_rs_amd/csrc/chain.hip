@@ -136,7 +136,7 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
     // FM chains at the rates that kernel runs without its demodulator (4, 16 ... 64): mixer / FIR / decimate on it and the
     // demodulator as its own small launch over the n / rate kept samples, where the kernel takes EVERY call of this filter (asked
     // with the shortest batch) -- rate 4, 255 taps, 2^24 samples: ~46 us against 70 for the overlap-save launch + demodulator
-    const bool poly_sep = h->fm_demod && st == COMMS_OK && rate != 8 && !(flags & (COMMS_CHAIN_TIME_DOMAIN | COMMS_CHAIN_FREQ_DOMAIN | COMMS_CHAIN_UNFUSED)) &&
+    const bool poly_sep = h->fm_demod && st == COMMS_OK && rate != 8 && !poly_pref && !(flags & (COMMS_CHAIN_TIME_DOMAIN | COMMS_CHAIN_FREQ_DOMAIN | COMMS_CHAIN_UNFUSED)) &&
                           comms_fir_poly8_supported(h->fir, static_cast<uint32_t>(rate), COMMS_CHAIN_DEC, rate) == 2;
     const bool can_decim = !(flags & (COMMS_CHAIN_UNFUSED | COMMS_CHAIN_FREQ_DOMAIN)) &&
                            (decim_ok == 2 || poly_pref || (poly_sep && decim_ok >= 1) || (decim_ok == 1 && (flags & COMMS_CHAIN_TIME_DOMAIN)));

@@ -245,7 +245,6 @@ __global__ __launch_bounds__(64 * WPB, 4) void fir_poly8_kernel(In in, const flo
     extern __shared__ __attribute__((aligned(16))) char smem[];
     kstamp_begin(ks);
     hist_advance(hist, in, n, new_hist, hist_len);
-    static_assert(NPH == 1 || !FM, "the second output phase comes without the FM demodulator");
     cf* gsp = reinterpret_cast<cf*>(smem);  // [NPH][16][64]
     cf* tw = gsp + 1024 * NPH;              // [16][8]
     cf* sc = tw + 128;                      // [64]
@@ -303,6 +302,30 @@ __global__ __launch_bounds__(64 * WPB, 4) void fir_poly8_kernel(In in, const flo
         if (NPH == 2) {  // rate 4: outputs 2 o (y[8 o]) and 2 o + 1 (y[8 o + 4]); n / 4 of them (n a multiple of 4, not of 8)
             ya2 = cmulf(ya2, cmulf_s(rot, step4));
             yb2 = cmulf(yb2, cmulf_s(rotb, step4));
+            if (FM) {
+                // the kept stream is A_l, B_l, A_{l+1}, ...: y[j - 1] of A_l is B of the lane below (position 64: lane 63 of the first
+                // register pair), of B_l it is A_l.  Position HQ - 1 is a valid output of the segment before (the launcher's halo rule).
+                const size_t n4f = n >> 2;
+                float cx, cy;
+                asm volatile("s_nop 1\n\tv_readlane_b32 %0, %2, 63\n\tv_readlane_b32 %1, %3, 63" : "=s"(cx), "=s"(cy) : "v"(ya2.x), "v"(ya2.y));
+                float2 pa = make_float2(wave_shr1(ya2.x, 0.f), wave_shr1(ya2.y, 0.f));
+                const float2 pb = make_float2(wave_shr1(yb2.x, cx), wave_shr1(yb2.y, cy));
+                if (guard && o == 0) pa = fmx.prev[0];
+                const float f0 = fm_step_fast(to_f2(ya), pa), f1 = fm_step_fast(to_f2(ya2), to_f2(ya));
+                const float g0 = fm_step_fast(to_f2(yb), pb), g1 = fm_step_fast(to_f2(yb2), to_f2(yb));
+                const size_t fa = static_cast<size_t>(2 * o), fb = fa + 128;
+                if (l >= Gm::HQ) {
+                    if (!guard || fa < n4f) outf[fa] = f0;
+                    if (!guard || fa + 1 < n4f) outf[fa + 1] = f1;
+                    if (fa + 1 == n4f) fmx.prev_new[0] = to_f2(ya);
+                    if (fa + 2 == n4f) fmx.prev_new[0] = to_f2(ya2);
+                }
+                if (!guard || fb < n4f) outf[fb] = g0;
+                if (!guard || fb + 1 < n4f) outf[fb + 1] = g1;
+                if (fb + 1 == n4f) fmx.prev_new[0] = to_f2(yb);
+                if (fb + 2 == n4f) fmx.prev_new[0] = to_f2(yb2);
+                return;
+            }
             const size_t n4 = n >> 2;
             const size_t oa = static_cast<size_t>(2 * o), ob = oa + 128;
             if (mx.keep > 1) {  // rates 4 m (m odd): every m-th output of the rate-4 stream (32-bit indices: the launcher's condition)
@@ -535,9 +558,9 @@ comms_status_t poly8_launch_in(int hr, bool fm, int nph, comms_fir* h, hipStream
                                const P8Mix& mx, const P8Fm& fmx) {
     if (nph == 2) {
         switch (hr) {
-            case 2: return poly8_launch<2, false, In, 2>(h, s, in, out, n, tb, mx, fmx);
-            case 3: return poly8_launch<3, false, In, 2>(h, s, in, out, n, tb, mx, fmx);
-            default: return poly8_launch<4, false, In, 2>(h, s, in, out, n, tb, mx, fmx);
+            case 2: return fm ? poly8_launch<2, true, In, 2>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<2, false, In, 2>(h, s, in, out, n, tb, mx, fmx);
+            case 3: return fm ? poly8_launch<3, true, In, 2>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<3, false, In, 2>(h, s, in, out, n, tb, mx, fmx);
+            default: return fm ? poly8_launch<4, true, In, 2>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<4, false, In, 2>(h, s, in, out, n, tb, mx, fmx);
         }
     }
     switch (hr) {
@@ -563,7 +586,7 @@ int32_t comms_fir_poly8_supported(const comms_fir_t* h, uint32_t rate, int32_t m
     const int kind = poly8_rate_kind(rate);
     if (!h || !kind || h->n_eff < 1 || n < rate) return 0;
     const bool fm = (mode & COMMS_CHAIN_FM) != 0;
-    if (!(mode & COMMS_CHAIN_DEC) || !poly8_halo_rows(h->n_eff, fm) || (fm && kind != 1)) return 0;
+    if (!(mode & COMMS_CHAIN_DEC) || !poly8_halo_rows(h->n_eff, fm) || (fm && kind > 2)) return 0;  // (FM demod: rates 8 and 4)
     if (kind >= 3 && (n >> 2) > 0xFFFFFFFFull) return 0;  // (its output index arithmetic is 32 bits wide)
     static const int knob = diag_knob("COMMS_POLY8", 1);          // 0: never, 1: where it wins, 2: wherever it can run
     if (!knob || h->no_poly8) return 0;
@@ -599,7 +622,7 @@ comms_status_t comms_fir_run_poly8_dev(comms_fir_t* h, const void* d_in, size_t 
     const bool fm = (mode & COMMS_CHAIN_FM) != 0;
     const int hr = poly8_halo_rows(h->n_eff, fm);
     COMMS_ARG(hr != 0, "the polyphase kernel takes <= 257 taps (249 with FM demod)");
-    COMMS_ARG(!fm || kind == 1, "the polyphase kernel demodulates at rate 8 only");
+    COMMS_ARG(!fm || kind <= 2, "the polyphase kernel demodulates at rates 8 and 4 only");
     COMMS_ARG(kind < 3 || (n >> 2) <= 0xFFFFFFFFull, "batch too long for the polyphase kernel at this rate");
     COMMS_ARG((mode & COMMS_CHAIN_DEC) && !((mode & COMMS_CHAIN_PRE) && (mode & COMMS_CHAIN_POST)), "bad chain mode");
     COMMS_ARG(!fm || (fm_prev && fm_prev_new), "FM demod needs its state");

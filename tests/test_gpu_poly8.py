@@ -69,22 +69,24 @@ def test_poly8_chain_against_oracle_ragged_calls(c, n_taps, cplx, after):
     np.testing.assert_array_equal(node.fir_state(n_taps), x[::-1][:n_taps])
 
 
+@pytest.mark.parametrize("rate", [8, 4])
 @pytest.mark.parametrize("n_taps", [127, 63, 9, 121, 122, 185, 186, 249])
-def test_poly8_fm_chain_against_oracle(c, n_taps):
+def test_poly8_fm_chain_against_oracle(c, n_taps, rate):
     """mixer -> FIR -> /8 -> FM demod (BASELINE config 3's order): the demodulator takes y[j-1] from the lane below, the
     segment's first output from the halo position in front of it (121 / 185 / 249 taps: the last counts with that spare
-    position), the call's first from FM.prev."""
+    position), the call's first from FM.prev.  At rate 4 the kept stream interleaves the two output phases: y[j-1] of the first
+    phase is the second phase of the lane below."""
     rng = np.random.default_rng(n_taps)
     taps = lpf(n_taps, 1 / 16.0)
-    n = 896 * 30 + 8 * 7
+    n = 896 * 30 + 8 * 7 + (4 if rate == 4 else 0)
     t = np.arange(n)
     x = (np.exp(1j * (0.02 * t + 3.0 * np.sin(2 * np.pi * t / 5000.0))) * (1 + 0.1 * rng.standard_normal(n))).astype(np.complex64)
-    node = c.ChainNode(0.3, 0.1, taps, 8, True, kernel="poly")
+    node = c.ChainNode(0.3, 0.1, taps, rate, True, kernel="poly")
     assert node.kernel == "poly"
     ost, om, ofm = oracle.default_state(taps), oracle.Mixer(0.1, 0.3), oracle.FM()
-    cuts = [0, 8, 16, 896, 896 * 3 + 24, 832 * 11, n]
+    cuts = [0, 8, 16, 896, 896 * 3 + 24, 832 * 11, n] if rate == 8 else [0, 4, 8, 20, 896, 896 * 3 + 20, 832 * 11 + 4, n]
     for a, b in zip(cuts[:-1], cuts[1:]):
-        y = oracle.decimate(oracle.batch_fir(om.mix(x[a:b]), taps, ost, norotate=True), 8)
+        y = oracle.decimate(oracle.batch_fir(om.mix(x[a:b]), taps, ost, norotate=True), rate)
         yp = np.concatenate([[complex(ofm.prev[0]) if a else 1.0], y[:-1]])
         w = ofm.demod(y)
         got = node.run(x[a:b])
@@ -105,7 +107,8 @@ def test_poly8_where_it_runs(c):
     assert c.ChainNode(0.3, 0.1, lpf(300, 0.05), 8, False, kernel="poly").kernel != "poly"
     assert c.ChainNode(0.3, 0.1, t127, 5, False, kernel="poly").kernel != "poly"
     assert c.ChainNode(0.3, 0.1, t127, 72, False, kernel="poly").kernel != "poly"
-    assert c.ChainNode(0.3, 0.1, t127, 4, True, kernel="poly").kernel != "poly"  # FM demod: at rate 8 only
+    assert c.ChainNode(0.3, 0.1, t127, 4, True, kernel="poly").kernel == "poly"  # FM demod in the kernel: rates 8 and 4
+    assert c.ChainNode(0.3, 0.1, t127, 16, True, kernel="poly").kernel != "poly"
     # rates 4 (two output phases) and 8 m up to 64 (every m-th output of the rate-8 form)
     for rate in (4, 16, 24, 32, 40, 48, 56, 64, 12, 20, 60):
         assert c.ChainNode(0.3, 0.1, t127, rate, False, kernel="poly").kernel == "poly"
