@@ -17,7 +17,7 @@ c.synth_iq_dev(x.data_ptr(), 1 << 25, 0, 5)
 k = np.arange(249) - 124.0
 taps = (2 / 20 * np.sinc(2 / 20 * k) * np.hamming(249)).astype(np.complex64)
 cases = []
-for rate, fm, lg in [(8, False, 24), (8, True, 25), (4, False, 23), (32, False, 24), (8, True, 18), (8, False, 21), (16, False, 20)]:
+for rate, fm, lg in [(8, False, 24), (8, True, 25), (4, False, 23), (4, True, 22), (32, False, 24), (8, True, 18), (8, False, 21), (16, False, 20), (12, False, 21)]:
     n = (1 << lg) - 8 * 64 * 3 + rate * 5 * 8
     n -= n % (rate * 8)
     ref_node = c.ChainNode(0.4, 0.1, taps, rate, fm, mixer_after_fir=not fm, kernel="poly")
