@@ -151,21 +151,23 @@ def test_fir_ticketed_kernel_random_sweep(c):
 
 
 def test_poly8_chain_random_sweep(c):
-    """fir_poly8_kernel on random draws: tap count (every halo width, real / complex taps), mixer order, FM demod, oscillator, user
-    FIR state, batch cuts on multiples of 8 -- against the oracle's nodes in series."""
+    """fir_poly8_kernel on random draws: rate (8, 4 and the multiples of 4 up to 64), tap count (every halo width, real / complex
+    taps), mixer order, FM demod (rates 8 and 4), oscillator, user FIR state, batch cuts on multiples of the rate -- against the
+    oracle's nodes in series."""
     rng = np.random.default_rng(16 + 1000 * SEED_OFFSET)
-    for case in range(40):
-        fm = bool(rng.integers(0, 2))
+    for case in range(60):
+        rate = int(rng.choice([8, 8, 8, 4, 4, 12, 16, 20, 24, 28, 32, 40, 48, 56, 60, 64]))
+        fm = bool(rng.integers(0, 2)) and rate in (4, 8)
         n_taps = int(rng.integers(1, (249 if fm else 257) + 1))
         taps = lowpass_taps(n_taps, float(rng.uniform(0.02, 0.06)))
         if rng.integers(0, 2):
             taps = (taps * np.exp(1j * rng.uniform(-0.05, 0.05) * np.arange(n_taps))).astype(np.complex64)
         after = bool(rng.integers(0, 2)) and not fm
         dphase, phase = float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3))
-        n = 8 * int(rng.integers(1, 3000))
+        n = rate * int(rng.integers(1, 24000 // rate))
         t = np.arange(n)
         x = (np.exp(1j * (0.3 * dphase * t + 2.0 * np.sin(t / 700.0))) * (1 + 0.05 * rng.standard_normal(n))).astype(np.complex64)
-        node = c.ChainNode(dphase, phase, taps, 8, fm, mixer_after_fir=after, kernel="poly")
+        node = c.ChainNode(dphase, phase, taps, rate, fm, mixer_after_fir=after, kernel="poly")
         assert node.kernel == "poly", case
         ost, om, ofm = oracle.default_state(taps), oracle.Mixer(phase, dphase), oracle.FM()
         if rng.integers(0, 3) == 0:  # a user state: the halo of a sharded stream (raw samples, newest first)
@@ -177,19 +179,19 @@ def test_poly8_chain_random_sweep(c):
                 ost = (st.astype(np.complex128) * np.exp(1j * (phase - k * dphase))).astype(np.complex64)
         scale = np.sum(np.abs(taps)) * max(np.max(np.abs(x)), 1.0)
         last = 0j
-        for a, b in zip(*(lambda cs: (cs[:-1], cs[1:]))(cuts_of(rng, n, 3, 8))):
+        for a, b in zip(*(lambda cs: (cs[:-1], cs[1:]))(cuts_of(rng, n, 3, rate))):
             if after:
-                y = oracle.decimate(om.mix(oracle.batch_fir(x[a:b], taps, ost, norotate=True)), 8)
+                y = oracle.decimate(om.mix(oracle.batch_fir(x[a:b], taps, ost, norotate=True)), rate)
             else:
-                y = oracle.decimate(oracle.batch_fir(om.mix(x[a:b]), taps, ost, norotate=True), 8)
+                y = oracle.decimate(oracle.batch_fir(om.mix(x[a:b]), taps, ost, norotate=True), rate)
             got = node.run(x[a:b])
             if fm:
                 w = ofm.demod(y)
                 mag = np.minimum(np.abs(y), np.abs(np.concatenate([[last], y[:-1]])))
                 last = y[-1]
-                assert np.max(circ(got.astype(np.float64) - w) * mag) <= 4 * TOL * scale, (case, n_taps, a, b)
+                assert np.max(circ(got.astype(np.float64) - w) * mag) <= 4 * TOL * scale, (case, rate, n_taps, a, b)
             else:
-                assert np.max(np.abs(got - y)) <= 2 * TOL * scale, (case, n_taps, after, a, b)
+                assert np.max(np.abs(got - y)) <= 2 * TOL * scale, (case, rate, n_taps, after, a, b)
 
 
 def test_poly8_ticketed_batches_random_sweep(c):
