@@ -133,9 +133,10 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
     const bool poly_pref = decim_ok >= 1 && !(flags & COMMS_CHAIN_TIME_DOMAIN) &&
                            comms_fir_poly8_supported(h->fir, static_cast<uint32_t>(rate), COMMS_CHAIN_DEC | (h->fm_demod ? COMMS_CHAIN_FM : 0),
                                                      static_cast<size_t>(1) << 26) == 2;
-    // FM chains at the rates that kernel runs without its demodulator (4, 16 ... 64): mixer / FIR / decimate on it and the
-    // demodulator as its own small launch over the n / rate kept samples, where the kernel takes EVERY call of this filter (asked
-    // with the shortest batch) -- rate 4, 255 taps, 2^24 samples: ~46 us against 70 for the overlap-save launch + demodulator
+    // FM chains where that kernel runs without its demodulator (rates 12 ... 64; rate 4 beyond 249 taps): mixer / FIR / decimate on
+    // it and the demodulator as its own small launch over the n / rate kept samples, where the kernel takes EVERY call of this
+    // filter (asked with the shortest batch) -- rate 4, 255 taps, 2^24 samples: ~50 us against 70 for the overlap-save launch +
+    // demodulator (up to 249 taps the demodulator runs in the kernel: poly_pref above)
     const bool poly_sep = h->fm_demod && st == COMMS_OK && rate != 8 && !poly_pref && !(flags & (COMMS_CHAIN_TIME_DOMAIN | COMMS_CHAIN_FREQ_DOMAIN | COMMS_CHAIN_UNFUSED)) &&
                           comms_fir_poly8_supported(h->fir, static_cast<uint32_t>(rate), COMMS_CHAIN_DEC, rate) == 2;
     const bool can_decim = !(flags & (COMMS_CHAIN_UNFUSED | COMMS_CHAIN_FREQ_DOMAIN)) &&
