@@ -323,3 +323,30 @@ def test_poly8_other_rates_with_a_separate_demodulator(c, rate, n_taps):
         last = y[-1]
         assert np.max(circ(got.astype(np.float64) - w) * mag) <= 4 * TOL * np.sum(np.abs(taps)) * np.max(np.abs(x))
     assert abs(complex(node.fm_prev) - complex(y[-1])) <= 2 * TOL * np.sum(np.abs(taps)) * np.max(np.abs(x))
+
+
+def test_non_finite_sample_reach(c):
+    """A NaN input sample: the reference's direct sum carries it into the N outputs that follow.  The GPU kernels carry it at least
+    there and not much further: the time-domain chain kernel through its zero-padded tap window (0 x NaN = NaN: a few outputs either
+    side), the frequency-domain one through the segment the sample falls in and, as halo, the next.  Everything else matches."""
+    rng = np.random.default_rng(21)
+    taps = lpf(101, 0.05)
+    n = 8 * 2000
+    x = rand_c(rng, n)
+    p = 8 * 700 + 3
+    x[p] = np.nan + 0j
+    want = oracle.decimate(oracle.Mixer(0.0, 0.2).mix(oracle.batch_fir(x, taps, oracle.default_state(taps), norotate=True)), 8)
+    bad = np.isnan(want.real) | np.isnan(want.imag)
+    j = np.arange(n // 8)
+    assert np.array_equal(bad, (8 * j >= p) & (8 * j <= p + 100))  # the outputs whose sum holds sample p
+    t = c.ChainNode(0.2, 0.0, taps, 8, False, mixer_after_fir=True, kernel="time").run(x)
+    tb = np.isnan(t.real) | np.isnan(t.imag)
+    assert tb[bad].all() and not tb[8 * j < p - 64].any() and not tb[8 * j > p + 100 + 64].any()
+    chain_close(t[~tb], want[~tb], taps, np.nan_to_num(x))
+    f = c.ChainNode(0.2, 0.0, taps, 8, False, mixer_after_fir=True, kernel="poly").run(x)
+    fb = np.isnan(f.real) | np.isnan(f.imag)
+    assert fb[bad].all()
+    seg = 896 // 8  # (101 taps: two halo rows, 896 new samples = 112 outputs per segment)
+    lo, hi = (p // 896) * seg, (p // 896 + 2) * seg
+    assert not fb[:lo].any() and not fb[hi:].any()
+    chain_close(f[~fb], want[~fb], taps, np.nan_to_num(x))
