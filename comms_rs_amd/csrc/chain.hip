@@ -154,10 +154,22 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
     const int32_t poly_mode = (h->mixer_after ? COMMS_CHAIN_POST : COMMS_CHAIN_PRE) | COMMS_CHAIN_DEC | (h->fm_demod ? COMMS_CHAIN_FM : 0);
     const bool force_poly8 = st == COMMS_OK && (flags & COMMS_CHAIN_POLYPHASE) && !(flags & COMMS_CHAIN_UNFUSED) &&
                              comms_fir_poly8_supported(h->fir, static_cast<uint32_t>(rate), poly_mode, static_cast<size_t>(1) << 26) != 0;
-    if (force_poly8) {
+    // Filters too long for the other fusions (258 ... 513 taps; until round 5 these chains ran as overlap-save FIR + mixer-decimator
+    // [+ demodulator]: 80 us at 2^24 samples and rate 8): the polyphase kernel with five to eight halo rows, where it takes every
+    // call of the filter (asked with the shortest batch); the demodulator in the kernel where it has one (rates 8 and 4, 505
+    // taps), as its own launch over the kept samples otherwise.
+    bool poly_long = false, poly_long_fm = false;
+    if (st == COMMS_OK && n_taps > 257 && !force_poly8 &&
+        !(flags & (COMMS_CHAIN_UNFUSED | COMMS_CHAIN_TIME_DOMAIN | COMMS_CHAIN_FREQ_DOMAIN))) {
+        poly_long_fm = h->fm_demod && comms_fir_poly8_supported(h->fir, static_cast<uint32_t>(rate), poly_mode, rate) == 2;
+        poly_long = poly_long_fm || comms_fir_poly8_supported(h->fir, static_cast<uint32_t>(rate), poly_mode & ~COMMS_CHAIN_FM, rate) == 2;
+    }
+    if (force_poly8 || poly_long) {
         h->fused = true;
         h->poly8 = true;
-        h->mode = poly_mode;
+        h->mode = poly_long && !poly_long_fm ? (poly_mode & ~COMMS_CHAIN_FM) : poly_mode;
+        h->fm_separate = poly_long && h->fm_demod && !poly_long_fm;
+        if (h->fm_separate) st = comms_fmdemod_create(device, &h->fm);
         h->frac = mix_to_turns(mix_wrap_dphase(dphase));
         h->turns = mix_to_turns(phase);
         for (int i = 0; i < 2 && st == COMMS_OK; ++i) {

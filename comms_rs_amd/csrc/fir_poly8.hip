@@ -33,8 +33,10 @@
 //   rate 4       the outputs y[8j + 4] are the same phase streams through a second set of branch filters h[8m - c + 4]: a second
 //                spectra table, a second multiply and a second inverse half per segment; the two phases leave interleaved;
 //   rates 8 m    (16 ... 64) every m-th output of the rate-8 form is stored.
-// The FM demodulator (y[j-1] from the lane below; the halo position in front of a segment's first output serves that output:
-// 249 taps at most) comes at rate 8 only.  Halo rows by tap count (HR = 2 / 3 / 4: 896 / 832 / 768 new samples per segment), raw
+// The FM demodulator (y[j-1] from the lane below; the halo position in front of a segment's first output serves that output, so it
+// costs eight taps of the limit) comes at rates 8 and 4.  Halo rows by tap count: HR = 2 / 3 / 4 (up to 129 / 193 / 257 taps: 896 /
+// 832 / 768 new samples per segment), and 5 / 6 / 8 for filters of up to 321 / 385 / 513 taps (704 / 640 / 512 new samples: more
+// transforms per sample, still one launch where the alternative is the overlap-save FIR and a mixer-decimator behind it).  Raw
 // i16 / u8 IQ converted in the load stage, four-wave workgroups for short batches.  Lane-accurate numpy model: scripts/proto_poly8.py.
 #include <hip/hip_ext.h>
 
@@ -309,8 +311,9 @@ __global__ __launch_bounds__(64 * WPB, 4) void fir_poly8_kernel(In in, const flo
                 float cx, cy;
                 asm volatile("s_nop 1\n\tv_readlane_b32 %0, %2, 63\n\tv_readlane_b32 %1, %3, 63" : "=s"(cx), "=s"(cy) : "v"(ya2.x), "v"(ya2.y));
                 float2 pa = make_float2(wave_shr1(ya2.x, 0.f), wave_shr1(ya2.y, 0.f));
-                const float2 pb = make_float2(wave_shr1(yb2.x, cx), wave_shr1(yb2.y, cy));
+                float2 pb = make_float2(wave_shr1(yb2.x, cx), wave_shr1(yb2.y, cy));
                 if (guard && o == 0) pa = fmx.prev[0];
+                if (Gm::HQ == 64 && guard && o == -64) pb = fmx.prev[0];  // (eight halo rows: the call's first output is position 64)
                 const float f0 = fm_step_fast(to_f2(ya), pa), f1 = fm_step_fast(to_f2(ya2), to_f2(ya));
                 const float g0 = fm_step_fast(to_f2(yb), pb), g1 = fm_step_fast(to_f2(yb2), to_f2(yb));
                 const size_t fa = static_cast<size_t>(2 * o), fb = fa + 128;
@@ -362,8 +365,9 @@ __global__ __launch_bounds__(64 * WPB, 4) void fir_poly8_kernel(In in, const flo
             float cx, cy;
             asm volatile("s_nop 1\n\tv_readlane_b32 %0, %2, 63\n\tv_readlane_b32 %1, %3, 63" : "=s"(cx), "=s"(cy) : "v"(ya.x), "v"(ya.y));
             float2 pa = make_float2(wave_shr1(ya.x, 0.f), wave_shr1(ya.y, 0.f));
-            const float2 pb = make_float2(wave_shr1(yb.x, cx), wave_shr1(yb.y, cy));
+            float2 pb = make_float2(wave_shr1(yb.x, cx), wave_shr1(yb.y, cy));
             if (guard && o == 0) pa = fmx.prev[0];  // the call's first output: FM.prev of the batch before
+            if (Gm::HQ == 64 && guard && o == -64) pb = fmx.prev[0];  // (eight halo rows: it is position 64)
             const float fa = fm_step_fast(to_f2(ya), pa), fb = fm_step_fast(to_f2(yb), pb);
             if (a_on) outf[o] = fa;
             if (b_on) outf[o + 64] = fb;
@@ -443,7 +447,7 @@ float2 root(long long e, int denom, int sign) {  // e^{sign 2 pi i e / denom}
 static comms_status_t poly8_prepare(comms_fir* h, bool pre, uint64_t frac, hipStream_t s) {
     if (h->d_p8 && h->p8_pre == pre && (!pre || h->p8_frac == frac)) return COMMS_OK;
     const int N = h->n_eff;
-    std::vector<double> hr(264, 0.0), hi(264, 0.0);
+    std::vector<double> hr(528, 0.0), hi(528, 0.0);
     const double dphi = static_cast<double>(frac >> 11) * (kMixT * 0x1.0p-53);
     for (int k = 0; k < N; ++k) {
         double tr = h->taps[k].re, ti = h->taps[k].im;
@@ -475,7 +479,7 @@ static comms_status_t poly8_prepare(comms_fir* h, bool pre, uint64_t frac, hipSt
                 for (int k2 = 0; k2 < 8; ++k2) {
                     const int c = cg + 4 * ci, k = k1 + 16 * k2;
                     double re = 0.0, im = 0.0;
-                    for (int m = 0; m <= 32; ++m) {
+                    for (int m = 0; m <= 64; ++m) {
                         const int tap = 8 * m - c + 4 * ph;
                         if (tap < 0 || tap >= N) continue;
                         const int e = (m * k) & 127;
@@ -513,7 +517,7 @@ namespace {
 int poly8_halo_rows(int n_eff, bool fm) {
     const int hq = (n_eff - 1 + 7) / 8 + (fm ? 1 : 0);
     const int hr = hq <= 16 ? 2 : (hq + 7) / 8;
-    return hr <= 4 ? hr : 0;
+    return hr <= 6 ? hr : hr <= 8 ? 8 : 0;  // (built for 2 ... 6 and 8)
 }
 
 template <int HR, bool FM, class In, int WPB, int NPH>
@@ -556,18 +560,27 @@ comms_status_t poly8_launch(comms_fir* h, hipStream_t s, In in, void* out, size_
 template <class In>
 comms_status_t poly8_launch_in(int hr, bool fm, int nph, comms_fir* h, hipStream_t s, In in, void* out, size_t n, const P8Tables& tb,
                                const P8Mix& mx, const P8Fm& fmx) {
+#define P8_CASE(HRV, NPHV) \
+    case HRV: return fm ? poly8_launch<HRV, true, In, NPHV>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<HRV, false, In, NPHV>(h, s, in, out, n, tb, mx, fmx)
     if (nph == 2) {
         switch (hr) {
-            case 2: return fm ? poly8_launch<2, true, In, 2>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<2, false, In, 2>(h, s, in, out, n, tb, mx, fmx);
-            case 3: return fm ? poly8_launch<3, true, In, 2>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<3, false, In, 2>(h, s, in, out, n, tb, mx, fmx);
-            default: return fm ? poly8_launch<4, true, In, 2>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<4, false, In, 2>(h, s, in, out, n, tb, mx, fmx);
+            P8_CASE(2, 2);
+            P8_CASE(3, 2);
+            P8_CASE(4, 2);
+            P8_CASE(5, 2);
+            P8_CASE(6, 2);
+            default: return fm ? poly8_launch<8, true, In, 2>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<8, false, In, 2>(h, s, in, out, n, tb, mx, fmx);
         }
     }
     switch (hr) {
-        case 2: return fm ? poly8_launch<2, true, In, 1>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<2, false, In, 1>(h, s, in, out, n, tb, mx, fmx);
-        case 3: return fm ? poly8_launch<3, true, In, 1>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<3, false, In, 1>(h, s, in, out, n, tb, mx, fmx);
-        default: return fm ? poly8_launch<4, true, In, 1>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<4, false, In, 1>(h, s, in, out, n, tb, mx, fmx);
+        P8_CASE(2, 1);
+        P8_CASE(3, 1);
+        P8_CASE(4, 1);
+        P8_CASE(5, 1);
+        P8_CASE(6, 1);
+        default: return fm ? poly8_launch<8, true, In, 1>(h, s, in, out, n, tb, mx, fmx) : poly8_launch<8, false, In, 1>(h, s, in, out, n, tb, mx, fmx);
     }
+#undef P8_CASE
 }
 
 // What the kernel does for a decimation rate: 1: 8 (one output phase), 2: 4 (two), 3: 8 m up to 64 (every m-th output of the rate-8
@@ -606,7 +619,9 @@ int32_t comms_fir_poly8_supported(const comms_fir_t* h, uint32_t rate, int32_t m
     if (kind == 2) return N >= 2 * min_taps || (N >= min_taps && n >= (static_cast<size_t>(1) << 22)) ? 2 : 1;
     // rates 12, 20, ... 60 (two output phases, every (rate / 4)-th output kept; 255 taps at 2^24 samples: rate 12 39.2 -> 34.7 us, 20
     // 41.8 -> 34.9, 28 level, 44 and 60 behind the any-rate kernel): ahead at 12 and 20 with long filters only
-    if (kind == 4) return rate <= 20 && N >= 3 * min_taps ? 2 : 1;
+    // (beyond 257 taps the any-rate kernel is the alternative: 300 taps at 2^24 samples 70 us at rate 20, 50 at 32, 39 at 48 against
+    // 36 ... 45 us here -- profiles/r05_sweep_long_taps.txt)
+    if (kind == 4) return (rate <= 20 && N >= 3 * min_taps) || (N > 257 && rate <= 36) ? 2 : 1;
     if (rate < 64) return N >= min_taps / 2 ? 2 : 1;
     return N >= 2 * min_taps || n >= (static_cast<size_t>(1) << 23) ? 2 : 1;
 }
@@ -621,7 +636,7 @@ comms_status_t comms_fir_run_poly8_dev(comms_fir_t* h, const void* d_in, size_t 
     COMMS_ARG(n % rate == 0, "n must be a multiple of the decimation rate");
     const bool fm = (mode & COMMS_CHAIN_FM) != 0;
     const int hr = poly8_halo_rows(h->n_eff, fm);
-    COMMS_ARG(hr != 0, "the polyphase kernel takes <= 257 taps (249 with FM demod)");
+    COMMS_ARG(hr != 0, "the polyphase kernel takes <= 513 taps (505 with FM demod)");
     COMMS_ARG(!fm || kind <= 2, "the polyphase kernel demodulates at rates 8 and 4 only");
     COMMS_ARG(kind < 3 || (n >> 2) <= 0xFFFFFFFFull, "batch too long for the polyphase kernel at this rate");
     COMMS_ARG((mode & COMMS_CHAIN_DEC) && !((mode & COMMS_CHAIN_PRE) && (mode & COMMS_CHAIN_POST)), "bad chain mode");

@@ -575,7 +575,7 @@ class ChainNode(_Handle):
     def __init__(self, dphase, phase, taps, rate, fm_demod, device=0, mixer_after_fir=False, unfused=False,
                  kernel="auto"):
         """kernel: "auto", "freq" (always the overlap-save kernel), "time" (the decimating
-        time-domain kernel wherever it applies) or "poly" (the polyphase frequency-domain kernel: rate 8, <= 257 taps, 249 with
+        time-domain kernel wherever it applies) or "poly" (the polyphase frequency-domain kernel: rate 8, <= 513 taps, 505 with
         FM demod)."""
         super().__init__()
         taps = _as_c64(taps)

@@ -1305,7 +1305,9 @@ def test_fused_fm_chain_rates_and_fallbacks(c, rate, kernel):
     assert c.ChainNode(0.3, 0.1, lowpass_taps(255, 0.1), 7, True).kernel == "time"      # per-rate kernel for /7 since round 3
     assert c.ChainNode(0.3, 0.1, lowpass_taps(63, 0.1), 128, True).kernel == "time_any"  # any-rate kernel from /17
     assert c.ChainNode(0.3, 0.1, lowpass_taps(300, 0.1), 100, False).kernel == "time_any"  # ... and up to 512 taps
-    assert not c.ChainNode(0.3, 0.1, lowpass_taps(300, 0.1), 8, False).fused     # > 257 taps
+    assert c.ChainNode(0.3, 0.1, lowpass_taps(300, 0.1), 8, False).kernel == "poly"  # 258 ... 513 taps at rates 4, 8, ...: polyphase
+    assert not c.ChainNode(0.3, 0.1, lowpass_taps(300, 0.1), 2, False).fused     # > 257 taps at any other rate below 17
+    assert not c.ChainNode(0.3, 0.1, lowpass_taps(600, 0.1), 8, False).fused
     with pytest.raises(c.CommsError):
         c.ChainNode(0.3, 0.1, taps, 8, True).run(x[:12])  # n not a multiple of rate
 
@@ -1417,10 +1419,11 @@ def test_fm_chain_with_the_demodulator_as_its_own_kernel(c, n_taps, rate, after)
 
 @pytest.mark.parametrize("fm", [False, True])
 @pytest.mark.parametrize("after", [False, True])
-@pytest.mark.parametrize("n_taps,rate", [(300, 8), (777, 16), (2500, 5)])
+@pytest.mark.parametrize("n_taps,rate", [(300, 6), (777, 16), (2500, 5)])
 def test_chain_beyond_257_taps(c, n_taps, rate, after, fm):
     """Long filters: the chain is a series of launches (4096- / 16384-point overlap-save FIR, mixer + decimator,
-    demodulator) with the reference nodes' results; state and phase carried across calls."""
+    demodulator) with the reference nodes' results; state and phase carried across calls.  (258 ... 513 taps at rates 4, 8,
+    12, 16 ... 64 run on the polyphase kernel since round 5: tests/test_gpu_poly8.py.)"""
     n = 4096 * rate * 3
     x = fm_stream(n) if fm else rand_c(np.random.default_rng(n_taps), n)
     taps = lowpass_taps(n_taps, 1 / (2.5 * rate))

@@ -43,10 +43,13 @@ def chain_close(got, want, taps, x):
     assert d.max(initial=0.0) <= bound, (d.max(), bound, int(np.argmax(d)))
 
 
-# halo rows by tap count: <= 129 taps two, <= 193 three, <= 257 four; ragged calls cross segment sizes 896 / 832 / 768
+# halo rows by tap count: <= 129 taps two, <= 193 three, <= 257 four, <= 321 five, <= 385 six, <= 513 eight; ragged calls cross
+# segment sizes 896 / 832 / 768 / 704 / 640 / 512
 @pytest.mark.parametrize("after", [False, True])
 @pytest.mark.parametrize("n_taps,cplx", [(255, False), (255, True), (257, True), (256, False), (194, False), (193, True), (131, False),
-                                         (130, True), (129, False), (127, False), (65, True), (33, False), (8, True), (1, False)])
+                                         (130, True), (129, False), (127, False), (65, True), (33, False), (8, True), (1, False),
+                                         (258, True), (300, False), (321, True), (322, False), (385, True), (386, False), (449, False),
+                                         (511, True), (513, False)])
 def test_poly8_chain_against_oracle_ragged_calls(c, n_taps, cplx, after):
     rng = np.random.default_rng(n_taps * 2 + cplx)
     taps = oracle.rrc_taps(n_taps, 8.0, 0.35) if n_taps > 8 else np.ones(n_taps, np.complex64)
@@ -58,7 +61,7 @@ def test_poly8_chain_against_oracle_ragged_calls(c, n_taps, cplx, after):
     n = 896 * 37 + 8 * 11
     x = rand_c(rng, n)
     ost, om = oracle.default_state(taps), oracle.Mixer(phase, dphase)
-    cuts = [0, 8, 776, 768 * 3, 768 * 3 + 16, 832 * 20 + 8 * 50, n]
+    cuts = [0, 8, 776, 768 * 3, 768 * 3 + 16, 704 * 7 + 8, 640 * 12, 512 * 19 + 24, 832 * 20 + 8 * 50, n]
     for a, b in zip(cuts[:-1], cuts[1:]):
         if after:
             w = oracle.decimate(om.mix(oracle.batch_fir(x[a:b], taps, ost, norotate=True)), 8)
@@ -70,7 +73,7 @@ def test_poly8_chain_against_oracle_ragged_calls(c, n_taps, cplx, after):
 
 
 @pytest.mark.parametrize("rate", [8, 4])
-@pytest.mark.parametrize("n_taps", [127, 63, 9, 121, 122, 185, 186, 249])
+@pytest.mark.parametrize("n_taps", [127, 63, 9, 121, 122, 185, 186, 249, 250, 255, 313, 314, 377, 378, 441, 505])
 def test_poly8_fm_chain_against_oracle(c, n_taps, rate):
     """mixer -> FIR -> /8 -> FM demod (BASELINE config 3's order): the demodulator takes y[j-1] from the lane below, the
     segment's first output from the halo position in front of it (121 / 185 / 249 taps: the last counts with that spare
@@ -84,7 +87,7 @@ def test_poly8_fm_chain_against_oracle(c, n_taps, rate):
     node = c.ChainNode(0.3, 0.1, taps, rate, True, kernel="poly")
     assert node.kernel == "poly"
     ost, om, ofm = oracle.default_state(taps), oracle.Mixer(0.1, 0.3), oracle.FM()
-    cuts = [0, 8, 16, 896, 896 * 3 + 24, 832 * 11, n] if rate == 8 else [0, 4, 8, 20, 896, 896 * 3 + 20, 832 * 11 + 4, n]
+    cuts = [0, 8, 16, 896, 896 * 3 + 24, 512 * 13, 832 * 11, n] if rate == 8 else [0, 4, 8, 20, 896, 896 * 3 + 20, 512 * 13 + 4, 832 * 11 + 4, n]
     for a, b in zip(cuts[:-1], cuts[1:]):
         y = oracle.decimate(oracle.batch_fir(om.mix(x[a:b]), taps, ost, norotate=True), rate)
         yp = np.concatenate([[complex(ofm.prev[0]) if a else 1.0], y[:-1]])
@@ -102,9 +105,20 @@ def test_poly8_where_it_runs(c):
     t255, t127, t31 = lpf(255, 0.05), lpf(127, 0.05), lpf(31, 0.05)
     assert c.ChainNode(0.3, 0.1, t255, 8, False, kernel="poly").kernel == "poly"
     assert c.ChainNode(0.3, 0.1, lpf(249, 0.05), 8, True, kernel="poly").kernel == "poly"
-    # no spare halo position for the demodulator / more than 257 taps / another rate: the flag asks, the chain falls back
-    assert c.ChainNode(0.3, 0.1, lpf(250, 0.05), 8, True, kernel="poly").kernel != "poly"
-    assert c.ChainNode(0.3, 0.1, lpf(300, 0.05), 8, False, kernel="poly").kernel != "poly"
+    assert c.ChainNode(0.3, 0.1, lpf(250, 0.05), 8, True, kernel="poly").kernel == "poly"  # (a fifth halo row)
+    assert c.ChainNode(0.3, 0.1, lpf(513, 0.05), 8, False, kernel="poly").kernel == "poly"
+    assert c.ChainNode(0.3, 0.1, lpf(505, 0.05), 4, True, kernel="poly").kernel == "poly"
+    assert c.ChainNode(0.3, 0.1, lpf(506, 0.05), 8, True, kernel="poly").kernel == "poly"  # (no spare halo position: demodulator behind it)
+    # more than 513 taps / another rate: the flag asks, the chain falls back
+    assert c.ChainNode(0.3, 0.1, lpf(514, 0.05), 8, False, kernel="poly").kernel != "poly"
+    assert c.ChainNode(0.3, 0.1, lpf(514, 0.05), 8, True, kernel="poly").kernel != "poly"
+    # 258 ... 513 taps: the chain picks it by itself (the alternative is the overlap-save FIR + a mixer-decimator), with the
+    # demodulator as its own launch where the kernel has none (other rates; past 505 taps)
+    for rate, fm, nt in [(8, False, 300), (8, True, 400), (4, False, 511), (16, False, 385), (32, True, 300), (8, True, 510), (12, False, 300)]:
+        assert c.ChainNode(0.3, 0.1, lpf(nt, 0.05), rate, fm).kernel == "poly", (rate, fm, nt)
+    assert c.ChainNode(0.3, 0.1, lpf(300, 0.05), 8, False, kernel="time").kernel != "poly"
+    assert c.ChainNode(0.3, 0.1, lpf(300, 0.05), 28, False).kernel == "poly"  # (rates 4 m', m' odd: up to 36 with such filters)
+    assert c.ChainNode(0.3, 0.1, lpf(300, 0.05), 44, False).kernel == "time_any"
     assert c.ChainNode(0.3, 0.1, t127, 5, False, kernel="poly").kernel != "poly"
     assert c.ChainNode(0.3, 0.1, t127, 72, False, kernel="poly").kernel != "poly"
     assert c.ChainNode(0.3, 0.1, t127, 4, True, kernel="poly").kernel == "poly"  # FM demod in the kernel: rates 8 and 4
@@ -192,7 +206,7 @@ def test_poly8_shard_continues_its_left_neighbour(c):
     chain_close(np.concatenate([yl, yr]), whole, taps, x)
 
 
-@pytest.mark.parametrize("fm,n_taps", [(False, 255), (True, 127), (False, 100)])
+@pytest.mark.parametrize("fm,n_taps", [(False, 255), (True, 127), (False, 100), (False, 400), (True, 500)])
 @pytest.mark.parametrize("fmt", ["i16", "u8"])
 def test_poly8_reads_raw_iq(c, fmt, fm, n_taps):
     """Raw i16 / u8 IQ (src/io/raw_iq.rs:16,50-51; the RTL-SDR bytes of examples/fm_radio.rs:82-90) into the polyphase kernel:
@@ -227,7 +241,8 @@ def test_poly8_reads_raw_iq(c, fmt, fm, n_taps):
 
 
 @pytest.mark.parametrize("rate", [4, 16, 24, 32, 40, 48, 56, 64, 12, 20, 28, 36, 44, 52, 60])
-@pytest.mark.parametrize("n_taps,cplx,after", [(255, False, True), (257, True, False), (131, False, False), (100, True, True), (33, False, True)])
+@pytest.mark.parametrize("n_taps,cplx,after", [(255, False, True), (257, True, False), (131, False, False), (100, True, True), (33, False, True),
+                                               (300, True, False), (513, False, True)])
 def test_poly8_other_rates_against_oracle(c, rate, n_taps, cplx, after):
     """Rate 4: the outputs y[8j + 4] too, from the same forward transforms through a second set of branch spectra (taps h[8m - c + 4])
     and a second inverse half, interleaved with y[8j].  Rates 8 m: every m-th output of the rate-8 form; rates 4 m (m odd): every
@@ -301,7 +316,8 @@ def test_poly8_other_rates_raw_iq_and_long_batches(c, rate):
     assert (ys[0] - ys[1]).abs().max().item() <= 2 * bound
 
 
-@pytest.mark.parametrize("rate,n_taps", [(4, 255), (4, 129), (16, 200), (24, 65), (32, 255), (64, 249), (12, 255)])
+@pytest.mark.parametrize("rate,n_taps", [(4, 255), (4, 129), (16, 200), (24, 65), (32, 255), (64, 249), (12, 255), (16, 400), (64, 513),
+                                         (8, 510), (4, 511), (20, 300)])
 def test_poly8_other_rates_with_a_separate_demodulator(c, rate, n_taps):
     """FM chains at the rates the polyphase kernel runs without its own demodulator: mixer / FIR / decimate on it, FMDemodNode's
     kernel behind it over the kept samples -- the oracle's four nodes in series, ragged calls, FM.prev carried."""

@@ -158,7 +158,7 @@ def test_poly8_chain_random_sweep(c):
     for case in range(60):
         rate = int(rng.choice([8, 8, 8, 4, 4, 12, 16, 20, 24, 28, 32, 40, 48, 56, 60, 64]))
         fm = bool(rng.integers(0, 2)) and rate in (4, 8)
-        n_taps = int(rng.integers(1, (249 if fm else 257) + 1))
+        n_taps = int(rng.integers(1, (505 if fm else 513) + 1))
         taps = lowpass_taps(n_taps, float(rng.uniform(0.02, 0.06)))
         if rng.integers(0, 2):
             taps = (taps * np.exp(1j * rng.uniform(-0.05, 0.05) * np.arange(n_taps))).astype(np.complex64)
@@ -204,8 +204,9 @@ def test_poly8_ticketed_batches_random_sweep(c):
     s = torch.cuda.current_stream().cuda_stream
     for case in range(6):
         fm = case % 3 == 2
-        n_taps = int(rng.integers(9, (249 if fm else 257) + 1))
-        new = 1024 - 64 * (2 if n_taps + (8 if fm else 0) <= 129 else 3 if n_taps + (8 if fm else 0) <= 193 else 4)
+        n_taps = int(rng.integers(9, (505 if fm else 513) + 1))
+        rows = max(2, (n_taps + (8 if fm else 0) - 1 + 63) // 64)
+        new = 1024 - 64 * (8 if rows == 7 else rows)
         n1 = int(rng.integers(4096, 5200)) * new + (0 if case % 2 == 0 else 8 * int(rng.integers(1, new // 8)))
         n2 = (int(rng.integers(40000, 45000)) if case == 5 else int(rng.integers(300, 4500))) * new + 8 * int(rng.integers(0, new // 8))
         taps = lowpass_taps(n_taps, 1 / 20.0)
