@@ -33,6 +33,7 @@ struct comms_chain : Handle {
     bool decim_any = false;  // ... on its any-rate form (fir_decim_any.hip; a mixer in front is folded into the taps)
     bool poly8 = false;      // COMMS_CHAIN_POLYPHASE: always the polyphase frequency-domain kernel (fir_poly8.hip)
     bool fm_separate = false;  // fused mixer / FIR / decimate launch, FM demod as its own (small) kernel behind it
+    bool os_dec = false;       // fused: the 4096-point overlap-save kernel with mixer and decimator in its store stage (258 ... 1537 taps)
     bool pre_as_post = false;  // series of launches, mixer in front folded into the taps: runs as the mixer-behind form
     int mode = 0;
     // fused path state
@@ -228,6 +229,11 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
             if (e != hipSuccess) st = fail(COMMS_ERR_DEVICE, "chain state alloc: %s", hipGetErrorString(e));
         }
     } else if (st == COMMS_OK) {
+        // 258 ... 1537 taps at the rates the polyphase kernel does not run: the 4096-point overlap-save kernel keeps, mixes and stores
+        // every rate-th output itself (one launch instead of FIR + mixer-decimator; 383 taps at rate 5, 2^24 samples: 96 -> ~60 us);
+        // FM demod follows as its own launch over the kept samples
+        const bool os_dec = !(flags & (COMMS_CHAIN_UNFUSED | COMMS_CHAIN_TIME_DOMAIN)) &&
+                            comms_fir_os4096_decim_supported(h->fir, static_cast<uint32_t>(rate < (1u << 21) ? rate : 0)) != 0;
         if (!h->mixer_after && !(flags & COMMS_CHAIN_UNFUSED)) {
             // Mixer in front of a long filter: sum_k h[k] x[n-k] e^{i phi_(n-k)} = e^{i phi_n} sum_k (h[k] e^{-i k dphi}) x[n-k],
             // so the chain runs as FIR (modulated taps, raw samples) -> mixer + decimator in one pass over the kept
@@ -247,9 +253,18 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
             st = comms_fir_create(mod.data(), n_taps, nullptr, 0, device, &h->fir);
             h->pre_as_post = st == COMMS_OK;
         }
-        if (st == COMMS_OK) st = comms_mixer_create(dphase, phase, device, &h->mixer);
+        if (st == COMMS_OK && os_dec) {
+            h->fused = true;
+            h->os_dec = true;
+            h->fm_separate = h->fm_demod;
+            h->mode = COMMS_CHAIN_POST | COMMS_CHAIN_DEC;
+            h->frac = mix_to_turns(mix_wrap_dphase(dphase));
+            h->turns = mix_to_turns(phase);
+        } else if (st == COMMS_OK) {
+            st = comms_mixer_create(dphase, phase, device, &h->mixer);
+        }
         if (st == COMMS_OK && h->fm_demod) st = comms_fmdemod_create(device, &h->fm);
-        for (int i = 0; i < 2 && st == COMMS_OK && !h->mixer_after && !h->pre_as_post; ++i) {
+        for (int i = 0; i < 2 && st == COMMS_OK && !h->mixer_after && !h->pre_as_post && !h->os_dec; ++i) {
             const size_t bytes = static_cast<size_t>(h->fir->n_eff) * sizeof(float2);
             hipError_t e = hipMalloc(&h->raw_hist[i], bytes);
             if (e == hipSuccess) e = zero_device(h->raw_hist[i], bytes);
@@ -293,7 +308,7 @@ comms_status_t comms_chain_run_dev(comms_chain_t* h, const comms_c32* d_in_any, 
     hipStream_t hs = nullptr;
     COMMS_TRY(h->enter(stream, &hs));  // the stages' state (history, prev) advances in stream order
     void* s = static_cast<void*>(hs);
-    if (h->in_fmt != COMMS_IQ_C32 && !(h->fused && (h->decim || h->decim_any || h->poly8))) {
+    if (h->in_fmt != COMMS_IQ_C32 && !(h->fused && (h->decim || h->decim_any || h->poly8 || h->os_dec))) {
         // only the time-domain kernel reads wire formats in its load stage; everything else gets one
         // conversion pass first (same arithmetic, iqformat.hip)
         COMMS_TRY(h->t0.reserve(n * sizeof(comms_c32)));
@@ -311,7 +326,9 @@ comms_status_t comms_chain_run_dev(comms_chain_t* h, const comms_c32* d_in_any, 
             COMMS_TRY(h->t3.reserve(n_dec * sizeof(comms_c32)));
             stage_out = h->t3.p;
         }
-        if (h->poly8)
+        if (h->os_dec)
+            COMMS_TRY(comms_fir_run_os4096_decim_dev(h->fir, d_in, n, stage_out, h->turns, h->frac, static_cast<uint32_t>(h->rate), s));
+        else if (h->poly8)
             COMMS_TRY(comms_fir_run_poly8_dev(h->fir, d_in, n, stage_out, h->mode, h->turns, h->frac, static_cast<uint32_t>(h->rate), h->d_prev[h->cur], h->d_prev[h->cur ^ 1], s));
         else if (h->decim_any)
             COMMS_TRY(comms_fir_run_decim_any_dev(h->fir, d_in, n, stage_out, h->mode, h->turns, h->frac, static_cast<uint32_t>(h->rate),
@@ -387,7 +404,7 @@ comms_status_t comms_chain_set_input_format(comms_chain_t* h, int32_t format, fl
     COMMS_ARG(format != COMMS_IQ_I16 || std::isfinite(scale), "scale must be finite");
     h->in_fmt = format;
     h->in_scale = format == COMMS_IQ_I16 ? scale : 1.0f;
-    if (h->fused && (h->decim || h->decim_any || h->poly8)) COMMS_TRY(comms_fir_set_input_format(h->fir, format, scale));
+    if (h->fused && (h->decim || h->decim_any || h->poly8 || h->os_dec)) COMMS_TRY(comms_fir_set_input_format(h->fir, format, scale));
     return COMMS_OK;
 }
 

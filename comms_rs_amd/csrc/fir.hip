@@ -199,17 +199,49 @@ __device__ __forceinline__ void lds_read16_contig(const cf* __restrict__ p, cf (
     }
 }
 
-template <int WPS, class In = const float2*>
+// DEC: the decimating chains of filters too long for the one-wave kernels (comms_chain_*: 258 ... 1537 taps at the rates the
+// polyphase kernel does not run) -- mixer and decimator in the store stage: of a segment's outputs only those whose index the
+// rate divides leave, times the oscillator's rotor at that index, to out[index / rate].  (Until round 5 these chains stored every
+// output and ran a mixer-decimator pass over them.)
+struct OsDec {
+    uint64_t turns0, frac;  // oscillator phase of the call's first sample and its step, in turns x 2^64
+    unsigned rate;
+    unsigned c1, d1;        // 256 % rate, 256 / rate: from one row of a segment to the next
+    unsigned dr;            // ((segments per step) x V) % rate and / rate: from one of a workgroup's segments to its next
+    unsigned long long dq;
+    float2 step[16];        // e^{i 256 j dphi}
+};
+
+// (cos, sin) of 2 pi u / 2^32: a 64-entry table for the upper six bits, a short series for the rest (|error| ~ 1e-7)
+__device__ __forceinline__ cf os_table_rotor(unsigned u, const cf* sc) {
+    const cf tq = sc[u >> 26];
+    const float th = static_cast<float>(u & 0x3FFFFFFu) * 1.4629180792671596e-09f;  // 2 pi / 2^32
+    const float z = th * th;
+    float sp = __builtin_fmaf(z, 8.3333333e-3f, -1.6666667e-1f);
+    sp = __builtin_fmaf(z, sp, 1.0f);
+    const float sn = th * sp;
+    float cp = __builtin_fmaf(z, -1.3888889e-3f, 4.1666667e-2f);
+    cp = __builtin_fmaf(z, cp, -0.5f);
+    const float cs = __builtin_fmaf(z, cp, 1.0f);
+    return cmulf(tq, cf{cs, sn});
+}
+
+template <int WPS, class In = const float2*, bool DEC = false>
 __global__ __launch_bounds__(256, WPS) void fir_os4096_kernel(In in,
                                                             const float2* __restrict__ hist,
                                                             int hist_len, float2* __restrict__ out,
                                                             size_t n, int hblk, size_t nseg,
                                                             OsTables tb, float2* __restrict__ new_hist,
-                                                            int delay, int accumulate, int interleave) {
+                                                            int delay, int accumulate, int interleave, OsDec dec) {
     __shared__ __attribute__((aligned(16))) cf lds[OS_LDS];
+    __shared__ cf sc[DEC ? 64 : 1];  // e^{2 pi i m / 64}
     const int t = threadIdx.x;
     if (!accumulate) hist_advance(hist, in, n, new_hist, hist_len);  // once per call (first partition)
     const int hi = t >> 4, lo = t & 15;
+    if (DEC && t < 64) {  // from the stage-1 twiddles: W4096^{8 x 8m} = e^{-2 pi i m / 64}, m < 32; the other half by symmetry
+        const cf w = tb.tw1[8 * 256 + 8 * (t & 31)];
+        sc[t] = t < 32 ? cf{w.x, -w.y} : cf{-w.x, w.y};
+    }
 
     // persistent per-lane constants, all in VGPRs: stage-1 twiddles, the filter spectrum and (round 3) the lane's
     // column of the stage-2 twiddle table W256^{lo*j} -- it depends on the lane only, and as an LDS table (in the same
@@ -232,6 +264,14 @@ __global__ __launch_bounds__(256, WPS) void fir_os4096_kernel(In in,
     const size_t seg_lo = interleave ? blockIdx.x : static_cast<size_t>(blockIdx.x) * nseg / gridDim.x;
     const size_t seg_hi = interleave ? nseg : static_cast<size_t>(blockIdx.x + 1) * nseg / gridDim.x;
     const size_t seg_step = interleave ? gridDim.x : 1;
+    // DEC: output index of the lane's first row = rate x kq + kr, carried from segment to segment
+    unsigned long long kq = 0;
+    unsigned kr = 0;
+    if (DEC) {
+        const unsigned long long o_first = static_cast<unsigned long long>(seg_lo) * V + t;
+        kq = o_first / dec.rate;
+        kr = static_cast<unsigned>(o_first - kq * dec.rate);
+    }
     for (size_t seg = seg_lo; seg < seg_hi; seg += seg_step) {
         // partition p of a long filter sees the stream delayed by p*2049 samples
         const long long base = static_cast<long long>(seg) * V - H - delay;
@@ -296,6 +336,32 @@ __global__ __launch_bounds__(256, WPS) void fir_os4096_kernel(In in,
         radix16<1>(v);
         // ---- store the V valid outputs: y[256a + t], a >= hblk
         const size_t obase = seg * static_cast<size_t>(V) + t;
+        if (DEC) {
+            const uint64_t tl = dec.turns0 + static_cast<uint64_t>(obase) * dec.frac;
+            const cf rot0 = os_table_rotor(static_cast<unsigned>(tl >> 32), sc);
+            float2* outq = out + kq;  // (rows: 32-bit offsets from the segment's first kept output)
+            unsigned q = 0, r = kr;
+            const int rows = obase < n ? static_cast<int>((n - obase + 255) >> 8 < 16 ? (n - obase + 255) >> 8 : 16) : 0;
+#pragma unroll
+            for (int a = 1; a < 16; ++a) {
+                if (a >= hblk) {
+                    if (r == 0 && a - hblk < rows) {
+                        const cf rot = cmulf(rot0, to_cf(dec.step[a - hblk]));
+                        outq[q] = to_f2(cmulf(v[R16_POS(a)], rot));
+                    }
+                    r += dec.c1;
+                    const unsigned wrap = r >= dec.rate ? 1u : 0u;
+                    r -= wrap ? dec.rate : 0u;
+                    q += dec.d1 + wrap;
+                    __builtin_amdgcn_sched_barrier(0);  // (row by row: hoisting the fifteen rotors costs thirty registers the kernel does not have)
+                }
+            }
+            kr += dec.dr;
+            const unsigned wrap = kr >= dec.rate ? 1u : 0u;
+            kr -= wrap ? dec.rate : 0u;
+            kq += dec.dq + wrap;
+            continue;
+        }
 #pragma unroll
         for (int a = 1; a < 16; ++a) {
             if (a >= hblk) {
@@ -2082,18 +2148,18 @@ comms_status_t comms_fir_run_dev(comms_fir_t* h, const comms_c32* d_in_any, size
                         reinterpret_cast<const cf*>(h->d_hparts[pt])};
             const int dl = pt * OS_PART, acc = pt ? 1 : 0;
             if (wps == 4)
-                fir_os4096_kernel<4><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, dl, acc, il);
+                fir_os4096_kernel<4><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, dl, acc, il, OsDec{});
             else if (wps == 2)
-                fir_os4096_kernel<2><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, dl, acc, il);
+                fir_os4096_kernel<2><<<dim3(blocks), dim3(256), 0, s>>>(in, hist, h->n_eff, o, n, h->hblk, nseg, tb, nh, dl, acc, il, OsDec{});
             else if (h->in_fmt == COMMS_IQ_I16)
                 fir_os4096_kernel<3, InI16><<<dim3(blocks), dim3(256), 0, s>>>(InI16{static_cast<const short2*>(d_in), h->in_scale}, hist, h->n_eff, o, n,
-                                                                              h->hblk, nseg, tb, nh, dl, acc, il);
+                                                                              h->hblk, nseg, tb, nh, dl, acc, il, OsDec{});
             else if (h->in_fmt == COMMS_IQ_U8)
                 fir_os4096_kernel<3, InU8><<<dim3(blocks), dim3(256), 0, s>>>(InU8{static_cast<const uchar2*>(d_in)}, hist, h->n_eff, o, n, h->hblk, nseg,
-                                                                             tb, nh, dl, acc, il);
+                                                                             tb, nh, dl, acc, il, OsDec{});
             else
                 fir_os4096_kernel<3, InC32Split><<<dim3(blocks), dim3(256), 0, s>>>(InC32Split{reinterpret_cast<const float*>(in)}, hist, h->n_eff, o, n,
-                                                                                   h->hblk, nseg, tb, nh, dl, acc, il);
+                                                                                   h->hblk, nseg, tb, nh, dl, acc, il, OsDec{});
         }
         h->toc(s);
         COMMS_TRY(launch_ok("fir_os4096_kernel"));
@@ -2227,6 +2293,67 @@ comms_status_t comms_fir_run_fused_dev(comms_fir_t* h, const comms_c32* d_in, si
     h->toc(s);
     COMMS_TRY(launch_ok("fir_os1024_kernel (fused)"));
     h->cur ^= 1;
+    return COMMS_OK;
+}
+
+// ---- long-filter decimating chain entry (internal; used by chain.hip): FIR (4096-point overlap-save) -> mixer -> keep every
+// rate-th output, one launch.  d_in: n samples in the handle's input format; d_out: n / rate Complex<f32>.
+int32_t comms_fir_os4096_decim_supported(const comms_fir_t* h, uint32_t rate) {
+    return h && h->n_eff > 257 && h->n_eff <= 1537 && rate >= 2 && rate <= (1u << 20) ? 1 : 0;
+}
+
+comms_status_t comms_fir_run_os4096_decim_dev(comms_fir_t* h, const void* d_in, size_t n, void* d_out, uint64_t turns0,
+                                              uint64_t frac, uint32_t rate, void* stream) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG((d_in && d_out) || !n, "NULL device pointer");
+    COMMS_ARG(comms_fir_os4096_decim_supported(h, rate), "the 4096-point decimating chain kernel takes 258 ... 1537 taps and rates 2 ... 2^20");
+    COMMS_ARG(n % rate == 0, "n must be a multiple of the decimation rate");
+    COMMS_TRY(fir_check_sticky(h));
+    COMMS_TRY(use_device(h->device));
+    if (!n) return COMMS_OK;
+    const size_t in_elem = h->in_fmt == COMMS_IQ_I16 ? 4 : h->in_fmt == COMMS_IQ_U8 ? 2 : 8;
+    COMMS_ARG(!ranges_overlap(d_in, n * in_elem, d_out, (n / rate) * 8), "the decimating chain cannot run in place");
+    COMMS_ARG((reinterpret_cast<uintptr_t>(d_in) & (in_elem - 1)) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 7) == 0,
+              "device pointers must be aligned to one sample");
+    COMMS_TRY(fir_prepare_os(h));
+    hipStream_t s = nullptr;
+    COMMS_TRY(h->enter(stream, &s));
+    float2* o = reinterpret_cast<float2*>(d_out);
+    const float2* hist = h->d_hist[h->cur];
+    float2* nh = h->d_hist[h->cur ^ 1];
+    const size_t V = OSF - 256 * static_cast<size_t>(h->hblk);
+    const size_t nseg = (n + V - 1) / V;
+    const size_t slots = static_cast<size_t>(3) * kNumCU;
+    const unsigned blocks = static_cast<unsigned>(nseg < slots ? nseg : slots);
+    OsDec dc{};
+    dc.turns0 = turns0;
+    dc.frac = frac;
+    dc.rate = rate;
+    dc.c1 = 256u % rate;
+    dc.d1 = 256u / rate;
+    const unsigned long long hop = static_cast<unsigned long long>(blocks) * V;  // (segments b, b + G, ... per workgroup)
+    dc.dq = hop / rate;
+    dc.dr = static_cast<unsigned>(hop % rate);
+    for (int j = 0; j < 16; ++j) {
+        double c, sn;
+        mix_host_rotor(static_cast<uint64_t>(256 * j) * frac, c, sn);
+        dc.step[j] = make_float2(static_cast<float>(c), static_cast<float>(sn));
+    }
+    OsTables tb{reinterpret_cast<const cf*>(h->d_tw1), reinterpret_cast<const cf*>(h->d_tw2), reinterpret_cast<const cf*>(h->d_hparts[0])};
+    h->tic(s);
+    if (h->in_fmt == COMMS_IQ_I16)
+        fir_os4096_kernel<3, InI16, true><<<dim3(blocks), dim3(256), 0, s>>>(InI16{static_cast<const short2*>(d_in), h->in_scale}, hist, h->n_eff, o, n,
+                                                                            h->hblk, nseg, tb, nh, 0, 0, 1, dc);
+    else if (h->in_fmt == COMMS_IQ_U8)
+        fir_os4096_kernel<3, InU8, true><<<dim3(blocks), dim3(256), 0, s>>>(InU8{static_cast<const uchar2*>(d_in)}, hist, h->n_eff, o, n, h->hblk, nseg,
+                                                                           tb, nh, 0, 0, 1, dc);
+    else
+        fir_os4096_kernel<3, InC32Split, true><<<dim3(blocks), dim3(256), 0, s>>>(InC32Split{static_cast<const float*>(d_in)}, hist, h->n_eff, o, n,
+                                                                                 h->hblk, nseg, tb, nh, 0, 0, 1, dc);
+    h->toc(s);
+    COMMS_TRY(launch_ok("fir_os4096_kernel (decimating)"));
+    h->cur ^= 1;
+    h->last_poly8 = false;
     return COMMS_OK;
 }
 

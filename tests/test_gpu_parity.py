@@ -1306,8 +1306,10 @@ def test_fused_fm_chain_rates_and_fallbacks(c, rate, kernel):
     assert c.ChainNode(0.3, 0.1, lowpass_taps(63, 0.1), 128, True).kernel == "time_any"  # any-rate kernel from /17
     assert c.ChainNode(0.3, 0.1, lowpass_taps(300, 0.1), 100, False).kernel == "time_any"  # ... and up to 512 taps
     assert c.ChainNode(0.3, 0.1, lowpass_taps(300, 0.1), 8, False).kernel == "poly"  # 258 ... 513 taps at rates 4, 8, ...: polyphase
-    assert not c.ChainNode(0.3, 0.1, lowpass_taps(300, 0.1), 2, False).fused     # > 257 taps at any other rate below 17
-    assert not c.ChainNode(0.3, 0.1, lowpass_taps(600, 0.1), 8, False).fused
+    assert c.ChainNode(0.3, 0.1, lowpass_taps(300, 0.1), 2, False).kernel == "freq"  # ... at the other rates, and up to 1537 taps: the
+    assert c.ChainNode(0.3, 0.1, lowpass_taps(600, 0.1), 8, False).kernel == "freq"  # 4096-point overlap-save kernel, decimating
+    assert not c.ChainNode(0.3, 0.1, lowpass_taps(1600, 0.1), 8, False).fused    # a series of launches beyond
+    assert not c.ChainNode(0.3, 0.1, lowpass_taps(600, 0.1), 8, False, unfused=True).fused
     with pytest.raises(c.CommsError):
         c.ChainNode(0.3, 0.1, taps, 8, True).run(x[:12])  # n not a multiple of rate
 
@@ -1428,7 +1430,8 @@ def test_chain_beyond_257_taps(c, n_taps, rate, after, fm):
     x = fm_stream(n) if fm else rand_c(np.random.default_rng(n_taps), n)
     taps = lowpass_taps(n_taps, 1 / (2.5 * rate))
     node = c.ChainNode(0.3, 0.1, taps, rate, fm, mixer_after_fir=after)
-    assert not node.fused
+    # (up to 1537 taps the 4096-point kernel mixes and decimates in its store stage: tests/test_gpu_long_chains.py)
+    assert node.fused == (n_taps <= 1537) and node.kernel == ("freq" if n_taps <= 1537 else "unfused")
     ost, om, ofm = oracle.default_state(taps), oracle.Mixer(0.1, 0.3), oracle.FM()
 
     def ref(seg):
