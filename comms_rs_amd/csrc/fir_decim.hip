@@ -73,6 +73,14 @@ struct DcGeom {
     static constexpr size_t LDS = static_cast<size_t>(PR) * S * sizeof(float2);
     static constexpr int WGPC = (R <= 8 ? 4 : R <= 12 ? 3 : 2) * DC_TILE / TILE;  // workgroups per CU that fit in LDS
     static constexpr int WAVES_PER_SIMD = (WGPC * WG / 64 + 3) / 4;  // __launch_bounds__' second argument: sets the VGPR budget
+    // ... with the mixer in front (PRE: row rotors in registers) rate 12 does not fit three workgroups' budget of 168 VGPRs (148
+    // bytes of scratch per lane): two -- 2^24 samples, 31 / 63 / 127 / 255 taps: 33.6 / 35.3 / 38.9 / 46.5 -> 27.9 / 30.1 / 36.3 / 46.0 us
+    // (scripts/ab_pre_rates.py).  Rate 11 (92 bytes) gains as much on short filters and loses it on long ones (255 taps: 46.5 ->
+    // 50.0 us): it stays at three.
+    template <bool PRE>
+    static constexpr int wgpc() { return PRE && R == 12 ? 2 * DC_TILE / TILE : WGPC; }
+    template <bool PRE>
+    static constexpr int waves_per_simd() { return (wgpc<PRE>() * WG / 64 + 3) / 4; }
     static_assert(PR * (HLQ_MAX + 1) + (OPL - 1) * R + 4 <= DC_AMAX, "tap table too small");
 };
 
@@ -139,7 +147,7 @@ __device__ __forceinline__ void lds_barrier() {  // (kept light: nothing global 
 // PRE: the mixer sits in front of the FIR (samples are mixed on their way into LDS); otherwise it
 // follows the FIR (or is absent).
 template <int R, int OPL, bool REAL, bool PRE, int TILE = DC_TILE, int CHX = 0>
-__global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::WAVES_PER_SIMD)) void fir_decim_kernel(const DecimArgs a) {
+__global__ __launch_bounds__((DcGeom<R, OPL, TILE>::WG), (DcGeom<R, OPL, TILE>::template waves_per_simd<PRE>())) void fir_decim_kernel(const DecimArgs a) {
     using G = DcGeom<R, OPL, TILE>;
     constexpr int PR = G::PR, S = G::S, WG = G::WG, HROWS = G::HROWS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -761,7 +769,7 @@ static comms_status_t launch_decim_v(const DecimArgs& a, hipStream_t s) {
     using G = DcGeom<R, OPL, TILE>;
     constexpr size_t lds = G::LDS;
     // persistent grid: one workgroup per slot of the chip; tile b, b + slots, ... (or a contiguous run) each
-    const size_t slots = static_cast<size_t>(G::WGPC) * kNumCU;
+    const size_t slots = static_cast<size_t>(G::template wgpc<PRE>()) * kNumCU;
     const unsigned blocks = static_cast<unsigned>(a.n_tiles < slots ? a.n_tiles : slots);
     static DeviceOnce attr_once;
     if (attr_once.need())
