@@ -154,8 +154,10 @@ def test_poly8_chain_random_sweep(c):
     """fir_poly8_kernel on random draws: rate (8, 4 and the multiples of 4 up to 64), tap count (every halo width, real / complex
     taps), mixer order, FM demod (rates 8 and 4), oscillator, user FIR state, batch cuts on multiples of the rate -- against the
     oracle's nodes in series."""
+    import os
+
     rng = np.random.default_rng(16 + 1000 * SEED_OFFSET)
-    for case in range(60):
+    for case in range(int(os.environ.get("COMMS_TEST_POLY_CASES", "60"))):  # (more draws for a one-off soak)
         rate = int(rng.choice([8, 8, 8, 4, 4, 12, 16, 20, 24, 28, 32, 40, 48, 56, 60, 64]))
         fm = bool(rng.integers(0, 2)) and rate in (4, 8)
         n_taps = int(rng.integers(1, (505 if fm else 513) + 1))
@@ -192,6 +194,53 @@ def test_poly8_chain_random_sweep(c):
                 assert np.max(circ(got.astype(np.float64) - w) * mag) <= 4 * TOL * scale, (case, rate, n_taps, a, b)
             else:
                 assert np.max(np.abs(got - y)) <= 2 * TOL * scale, (case, rate, n_taps, after, a, b)
+
+
+def test_long_chain_random_sweep(c):
+    """The decimating 4096-point overlap-save kernel (258 ... 1537 taps, mixer and decimator in its store stage) on random draws:
+    rate (2 ... 3000, the polyphase kernel's rates excluded below 514 taps by the chain itself), taps, mixer order, FM demod (a second
+    launch), oscillator, user FIR state, batch cuts on multiples of the rate -- against the oracle's nodes in series.
+    COMMS_TEST_LONG_CASES: more draws (the default keeps the suite short)."""
+    import os
+
+    rng = np.random.default_rng(23 + 1000 * SEED_OFFSET)
+    for case in range(int(os.environ.get("COMMS_TEST_LONG_CASES", "40"))):
+        rate = int(rng.choice([2, 3, 5, 6, 7, 9, 10, 11, 13, 14, 15, 17, 25, 50, 100, 255, 256, 257, 1000, int(rng.integers(2, 3000))]))
+        n_taps = int(rng.integers(514, 1538)) if rng.integers(0, 2) else int(rng.integers(258, 514))
+        fm = bool(rng.integers(0, 3) == 0)
+        taps = lowpass_taps(n_taps, float(rng.uniform(0.01, 0.05)))
+        if rng.integers(0, 2):
+            taps = (taps * np.exp(1j * rng.uniform(-0.05, 0.05) * np.arange(n_taps))).astype(np.complex64)
+        after = bool(rng.integers(0, 2)) and not fm
+        dphase, phase = float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3))
+        n = rate * int(rng.integers(1, max(2, 30000 // rate)))
+        t = np.arange(n)
+        x = (np.exp(1j * (0.3 * dphase * t + 2.0 * np.sin(t / 700.0))) * (1 + 0.05 * rng.standard_normal(n))).astype(np.complex64)
+        node = c.ChainNode(dphase, phase, taps, rate, fm, mixer_after_fir=after, kernel="freq")
+        assert node.kernel == "freq", (case, rate, n_taps)
+        ost, om, ofm = oracle.default_state(taps), oracle.Mixer(phase, dphase), oracle.FM()
+        if rng.integers(0, 3) == 0:  # a user state: the halo of a sharded stream (raw samples, newest first)
+            st = rand_c(rng, n_taps)
+            node.set_fir_state(st)
+            ost = st.copy()
+            if not after:  # mixer first: the reference's FIR state holds MIXED samples, the oscillator running backwards from `phase`
+                k = np.arange(1, n_taps + 1)
+                ost = (st.astype(np.complex128) * np.exp(1j * (phase - k * dphase))).astype(np.complex64)
+        scale = np.sum(np.abs(taps)) * max(np.max(np.abs(x)), 1.0)
+        last = 0j
+        for a, b in zip(*(lambda cs: (cs[:-1], cs[1:]))(cuts_of(rng, n, 3, rate))):
+            if after:
+                y = oracle.decimate(om.mix(oracle.batch_fir(x[a:b], taps, ost, norotate=True)), rate)
+            else:
+                y = oracle.decimate(oracle.batch_fir(om.mix(x[a:b]), taps, ost, norotate=True), rate)
+            got = node.run(x[a:b])
+            if fm:
+                w = ofm.demod(y)
+                mag = np.minimum(np.abs(y), np.abs(np.concatenate([[last], y[:-1]])))
+                last = y[-1]
+                assert np.max(circ(got.astype(np.float64) - w) * mag, initial=0.0) <= 4 * TOL * scale, (case, rate, n_taps, a, b)
+            else:
+                assert np.max(np.abs(got - y), initial=0.0) <= 2 * TOL * scale, (case, rate, n_taps, after, a, b)
 
 
 def test_poly8_ticketed_batches_random_sweep(c):
