@@ -34,6 +34,7 @@ struct comms_chain : Handle {
     bool poly8 = false;      // COMMS_CHAIN_POLYPHASE: always the polyphase frequency-domain kernel (fir_poly8.hip)
     bool fm_separate = false;  // fused mixer / FIR / decimate launch, FM demod as its own (small) kernel behind it
     bool os_dec = false;       // fused: the 4096-point overlap-save kernel with mixer and decimator in its store stage (258 ... 1537 taps)
+    bool os_dec16 = false;     // ... the 16384-point kernel (1538 ... 4097 taps; Complex<f32> input: raw formats take the conversion pass)
     bool pre_as_post = false;  // series of launches, mixer in front folded into the taps: runs as the mixer-behind form
     int mode = 0;
     // fused path state
@@ -232,8 +233,10 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
         // 258 ... 1537 taps at the rates the polyphase kernel does not run: the 4096-point overlap-save kernel keeps, mixes and stores
         // every rate-th output itself (one launch instead of FIR + mixer-decimator; 383 taps at rate 5, 2^24 samples: 96 -> ~60 us);
         // FM demod follows as its own launch over the kept samples
-        const bool os_dec = !(flags & (COMMS_CHAIN_UNFUSED | COMMS_CHAIN_TIME_DOMAIN)) &&
-                            comms_fir_os4096_decim_supported(h->fir, static_cast<uint32_t>(rate < (1u << 21) ? rate : 0)) != 0;
+        const uint32_t rate32 = static_cast<uint32_t>(rate < (1u << 21) ? rate : 0);
+        const bool os_ok = !(flags & (COMMS_CHAIN_UNFUSED | COMMS_CHAIN_TIME_DOMAIN));
+        const bool os_dec16 = os_ok && comms_fir_os16k_decim_supported(h->fir, rate32) != 0;  // (1538 ... 4097 taps: the 16384-point kernel)
+        const bool os_dec = os_dec16 || (os_ok && comms_fir_os4096_decim_supported(h->fir, rate32) != 0);
         if (!h->mixer_after && !(flags & COMMS_CHAIN_UNFUSED)) {
             // Mixer in front of a long filter: sum_k h[k] x[n-k] e^{i phi_(n-k)} = e^{i phi_n} sum_k (h[k] e^{-i k dphi}) x[n-k],
             // so the chain runs as FIR (modulated taps, raw samples) -> mixer + decimator in one pass over the kept
@@ -255,7 +258,8 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
         }
         if (st == COMMS_OK && os_dec) {
             h->fused = true;
-            h->os_dec = true;
+            h->os_dec = !os_dec16;
+            h->os_dec16 = os_dec16;
             h->fm_separate = h->fm_demod;
             h->mode = COMMS_CHAIN_POST | COMMS_CHAIN_DEC;
             h->frac = mix_to_turns(mix_wrap_dphase(dphase));
@@ -264,7 +268,7 @@ comms_status_t comms_chain_create_ex(double dphase, double phase, const comms_c3
             st = comms_mixer_create(dphase, phase, device, &h->mixer);
         }
         if (st == COMMS_OK && h->fm_demod) st = comms_fmdemod_create(device, &h->fm);
-        for (int i = 0; i < 2 && st == COMMS_OK && !h->mixer_after && !h->pre_as_post && !h->os_dec; ++i) {
+        for (int i = 0; i < 2 && st == COMMS_OK && !h->mixer_after && !h->pre_as_post && !h->os_dec && !h->os_dec16; ++i) {
             const size_t bytes = static_cast<size_t>(h->fir->n_eff) * sizeof(float2);
             hipError_t e = hipMalloc(&h->raw_hist[i], bytes);
             if (e == hipSuccess) e = zero_device(h->raw_hist[i], bytes);
@@ -328,6 +332,8 @@ comms_status_t comms_chain_run_dev(comms_chain_t* h, const comms_c32* d_in_any, 
         }
         if (h->os_dec)
             COMMS_TRY(comms_fir_run_os4096_decim_dev(h->fir, d_in, n, stage_out, h->turns, h->frac, static_cast<uint32_t>(h->rate), s));
+        else if (h->os_dec16)
+            COMMS_TRY(comms_fir_run_os16k_decim_dev(h->fir, d_in, n, stage_out, h->turns, h->frac, static_cast<uint32_t>(h->rate), s));
         else if (h->poly8)
             COMMS_TRY(comms_fir_run_poly8_dev(h->fir, d_in, n, stage_out, h->mode, h->turns, h->frac, static_cast<uint32_t>(h->rate), h->d_prev[h->cur], h->d_prev[h->cur ^ 1], s));
         else if (h->decim_any)

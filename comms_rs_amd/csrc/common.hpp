@@ -28,6 +28,9 @@
 #define COMMS_INTERNAL __attribute__((visibility("hidden")))
 #endif
 extern "C" COMMS_INTERNAL int32_t comms_fir_os4096_decim_supported(const comms_fir_t* h, uint32_t rate);
+extern "C" COMMS_INTERNAL int32_t comms_fir_os16k_decim_supported(const comms_fir_t* h, uint32_t rate);
+extern "C" COMMS_INTERNAL comms_status_t comms_fir_run_os16k_decim_dev(comms_fir_t* h, const comms_c32* d_in, size_t n, void* d_out, uint64_t turns0,
+                                                                      uint64_t frac, uint32_t rate, void* stream);
 extern "C" COMMS_INTERNAL comms_status_t comms_fir_run_os4096_decim_dev(comms_fir_t* h, const void* d_in, size_t n, void* d_out, uint64_t turns0,
                                                                        uint64_t frac, uint32_t rate, void* stream);
 extern "C" COMMS_INTERNAL comms_status_t comms_fir_run_fused_dev(comms_fir_t* h, const comms_c32* d_in, size_t n, void* d_out,

@@ -22,6 +22,7 @@
 // the same data newest-first.
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -1068,12 +1069,15 @@ __device__ unsigned long long* g_x_trace = nullptr;
 #define X_MARK_AFTER(i, reg)
 #endif
 
-template <int HR, class In = const float2*>
+// DEC: mixer and decimator in the store stage (the decimating chains of 1538 ... 4097 taps: see OsDec / fir_os4096_kernel).
+struct OsNoDec {};
+template <int HR, class In = const float2*, bool DEC = false>
 __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
                                                             const float2* __restrict__ hist, int hist_len,
                                                             float2* __restrict__ out, size_t n, size_t nseg,
                                                             XTables tb, float2* __restrict__ new_hist, int delay,
-                                                            int accumulate, KStamp ks, unsigned* err, int fault) {
+                                                            int accumulate, KStamp ks, unsigned* err, int fault,
+                                                            std::conditional_t<DEC, OsDec, OsNoDec> dec = {}) {
     // err: the handle's sticky error word.  fault (diagnostic build, else 0): workgroup 0's wave 3 withholds one
     // signal, so that the waits above run out and the error path can be tested.
 #ifndef COMMS_OS16K_NO_STAMP
@@ -1163,6 +1167,14 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
     };
     if (seg_lo < seg_hi) fetch_rows(seg_lo, 0);
     unsigned done = 0;  // segments this workgroup has finished
+    // DEC: output index of the thread's first row = rate x kq + kr, carried from segment to segment
+    unsigned long long kq = 0;
+    unsigned kr = 0;
+    if constexpr (DEC) {
+        const unsigned long long o_first = static_cast<unsigned long long>(seg_lo) * xv + tid;
+        kq = o_first / dec.rate;
+        kr = static_cast<unsigned>(o_first - kq * dec.rate);
+    }
 #ifdef COMMS_DIAG
     unsigned long long* xt = g_x_trace;
     if (xt) xt += (static_cast<size_t>(blockIdx.x) * 16 + wave) * X_TRACE_SEGS * 16;
@@ -1235,6 +1247,43 @@ __global__ __launch_bounds__(1024, 4) void fir_os16k_kernel(In in,
 #endif
         radix16<1>(v);
         X_MARK_AFTER(10, v[R16_POS(15)].x);
+        if constexpr (DEC) {
+            const size_t obase = nb + tid;
+            const uint64_t tl = dec.turns0 + static_cast<uint64_t>(obase) * dec.frac;
+            // e^{2 pi i m / 64} from the stage table W1024^{8 x 2m}, m < 32; the other half by symmetry
+            const unsigned u = static_cast<unsigned>(tl >> 32), m = u >> 26;
+            const cf w = tw1[8 * 64 + 2 * (m & 31u)];
+            const cf tq = m < 32u ? cf{w.x, -w.y} : cf{-w.x, w.y};
+            const float th = static_cast<float>(u & 0x3FFFFFFu) * 1.4629180792671596e-09f;  // 2 pi / 2^32
+            const float z = th * th;
+            float sp = __builtin_fmaf(z, 8.3333333e-3f, -1.6666667e-1f);
+            sp = __builtin_fmaf(z, sp, 1.0f);
+            float cp = __builtin_fmaf(z, -1.3888889e-3f, 4.1666667e-2f);
+            cp = __builtin_fmaf(z, cp, -0.5f);
+            const cf rot0 = cmulf(tq, cf{__builtin_fmaf(z, cp, 1.0f), th * sp});
+            float2* outq = out + kq;
+            unsigned q = 0, r = kr;
+            const int nrows = obase < n ? static_cast<int>((n - obase + 1023) >> 10 < 16 ? (n - obase + 1023) >> 10 : 16) : 0;
+#pragma unroll
+            for (int a = 1; a < 16; ++a) {
+                if (a < hr) continue;
+                if (r == 0 && a - hr < nrows) {
+                    const cf rot = cmulf(rot0, to_cf(dec.step[a - hr]));
+                    outq[q] = to_f2(cmulf(v[R16_POS(a)], rot));
+                }
+                r += dec.c1;
+                const unsigned wrap = r >= dec.rate ? 1u : 0u;
+                r -= wrap ? dec.rate : 0u;
+                q += dec.d1 + wrap;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            kr += dec.dr;
+            const unsigned wrap = kr >= dec.rate ? 1u : 0u;
+            kr -= wrap ? dec.rate : 0u;
+            kq += dec.dq + wrap;
+            X_MARK(7);
+            continue;
+        }
         // stores (and the accumulating pass's loads) through a buffer resource that ends at sample n: nothing past it
         const __amdgpu_buffer_rsrc_t ors = make_rsrc(out + nb, nb < n ? (n - nb) * sizeof(float2) : 0);
 #pragma unroll
@@ -2300,6 +2349,71 @@ comms_status_t comms_fir_run_fused_dev(comms_fir_t* h, const comms_c32* d_in, si
 // rate-th output, one launch.  d_in: n samples in the handle's input format; d_out: n / rate Complex<f32>.
 int32_t comms_fir_os4096_decim_supported(const comms_fir_t* h, uint32_t rate) {
     return h && h->n_eff > 257 && h->n_eff <= 1537 && rate >= 2 && rate <= (1u << 20) ? 1 : 0;
+}
+// ... and on the 16384-point kernel (1538 ... 4097 taps; Complex<f32> input)
+int32_t comms_fir_os16k_decim_supported(const comms_fir_t* h, uint32_t rate) {
+    return h && h->n_eff > 1537 && h->n_eff <= 4097 && rate >= 2 && rate <= (1u << 20) ? 1 : 0;
+}
+
+comms_status_t comms_fir_run_os16k_decim_dev(comms_fir_t* h, const comms_c32* d_in, size_t n, void* d_out, uint64_t turns0,
+                                             uint64_t frac, uint32_t rate, void* stream) {
+    COMMS_ARG(h != nullptr, "handle is NULL");
+    COMMS_ARG((d_in && d_out) || !n, "NULL device pointer");
+    COMMS_ARG(comms_fir_os16k_decim_supported(h, rate), "the 16384-point decimating chain kernel takes 1538 ... 4097 taps and rates 2 ... 2^20");
+    COMMS_ARG(n % rate == 0, "n must be a multiple of the decimation rate");
+    COMMS_TRY(fir_check_sticky(h));
+    COMMS_TRY(use_device(h->device));
+    if (!n) return COMMS_OK;
+    COMMS_ARG(!ranges_overlap(d_in, n * 8, d_out, (n / rate) * 8), "the decimating chain cannot run in place");
+    COMMS_ARG((reinterpret_cast<uintptr_t>(d_in) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 7) == 0,
+              "device pointers must be aligned to one sample");
+    COMMS_TRY(fir_prepare_os16k(h));
+    COMMS_ARG(h->x_part == 1, "the filter does not fit one 16384-point pass");
+    hipStream_t s = nullptr;
+    COMMS_TRY(h->enter(stream, &s));
+    const float2* in = reinterpret_cast<const float2*>(d_in);
+    float2* o = reinterpret_cast<float2*>(d_out);
+    const float2* hist = h->d_hist[h->cur];
+    float2* nh = h->d_hist[h->cur ^ 1];
+    const int hr = h->n_eff <= 2049 ? 2 : h->n_eff <= 3073 ? 3 : 4;
+    const size_t xv = static_cast<size_t>(16 - hr) * 1024;
+    const size_t nseg = (n + xv - 1) / xv;
+    const unsigned blocks = static_cast<unsigned>(nseg < static_cast<size_t>(kNumCU) ? nseg : kNumCU);
+    OsDec dc{};
+    dc.turns0 = turns0;
+    dc.frac = frac;
+    dc.rate = rate;
+    dc.c1 = 1024u % rate;
+    dc.d1 = 1024u / rate;
+    dc.dq = xv / rate;  // (a workgroup walks consecutive segments)
+    dc.dr = static_cast<unsigned>(xv % rate);
+    for (int j = 0; j < 16; ++j) {
+        double c, sn;
+        mix_host_rotor(static_cast<uint64_t>(1024 * j) * frac, c, sn);
+        dc.step[j] = make_float2(static_cast<float>(c), static_cast<float>(sn));
+    }
+    XTables tb{reinterpret_cast<const cf*>(h->d_xt[0]), reinterpret_cast<const cf*>(h->d_xt[1]), reinterpret_cast<const cf*>(h->d_xt[2]),
+               reinterpret_cast<const cf*>(h->d_xt[3]), reinterpret_cast<const cf*>(h->d_xh[0])};
+    const size_t lds = X_LDS_BYTES;
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os16k_kernel<2, const float2*, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os16k_kernel<3, const float2*, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        COMMS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_os16k_kernel<4, const float2*, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    }
+    h->tic(s);
+    const KStamp ks = h->next_stamp();
+    const int fault = os16k_fault();
+    switch (hr) {
+        case 2: fir_os16k_kernel<2, const float2*, true><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, h->n_eff, o, n, nseg, tb, nh, 0, 0, ks, h->d_err, fault, dc); break;
+        case 3: fir_os16k_kernel<3, const float2*, true><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, h->n_eff, o, n, nseg, tb, nh, 0, 0, ks, h->d_err, fault, dc); break;
+        default: fir_os16k_kernel<4, const float2*, true><<<dim3(blocks), dim3(1024), lds, s>>>(in, hist, h->n_eff, o, n, nseg, tb, nh, 0, 0, ks, h->d_err, fault, dc); break;
+    }
+    h->toc(s);
+    COMMS_TRY(launch_ok("fir_os16k_kernel (decimating)"));
+    h->cur ^= 1;
+    h->last_poly8 = false;
+    return COMMS_OK;
 }
 
 comms_status_t comms_fir_run_os4096_decim_dev(comms_fir_t* h, const void* d_in, size_t n, void* d_out, uint64_t turns0,

@@ -1,6 +1,6 @@
-"""GPU parity tests of the decimating chains of long filters on the 4096-point overlap-save kernel (csrc/fir.hip,
-fir_os4096_kernel<.., DEC>: mixer and decimator in the store stage; 258 ... 1537 taps at the rates the polyphase kernel does not
-run): BatchFirNode (src/filter/fir.rs:87-102), MixerNode (src/mixer.rs:73-85), DecimateNode (src/util/resample_node.rs:53-65)
+"""GPU parity tests of the decimating chains of long filters on the 4096- and 16384-point overlap-save kernels (csrc/fir.hip,
+fir_os4096_kernel<.., DEC> / fir_os16k_kernel<.., DEC>: mixer and decimator in the store stage; 258 ... 1537 / 1538 ... 4097 taps at
+the rates the polyphase kernel does not run): BatchFirNode (src/filter/fir.rs:87-102), MixerNode (src/mixer.rs:73-85), DecimateNode (src/util/resample_node.rs:53-65)
 [, FMDemodNode (src/modulation/analog.rs:22-35)] in either mixer order against the oracle's nodes in series.
 
 Tolerances as for every other chain kernel: a chain's decimated output max|d| <= 2 * 1e-5 * sum|taps| * max|x| (FIR error plus the
@@ -54,7 +54,9 @@ def oracle_chain(x, taps, ost, om, rate, after):
 @pytest.mark.parametrize("after", [False, True])
 @pytest.mark.parametrize("n_taps,rate,cplx", [(258, 2, False), (300, 3, True), (383, 5, False), (511, 7, True), (514, 8, False), (600, 10, True),
                                               (769, 16, False), (1025, 4, True), (1281, 9, False), (1537, 6, True), (700, 100, False),
-                                              (900, 255, True), (600, 256, False), (1000, 257, False), (520, 1000, True), (600, 5000, False)])
+                                              (900, 255, True), (600, 256, False), (1000, 257, False), (520, 1000, True), (600, 5000, False),
+                                              (1538, 2, False), (2049, 5, True), (2050, 8, False), (3073, 3, True), (3074, 10, False),
+                                              (4097, 7, True), (2500, 1024, False), (3000, 1025, True), (4000, 100, False)])
 def test_long_chain_against_oracle_ragged_calls(c, n_taps, rate, cplx, after):
     rng = np.random.default_rng(n_taps + rate)
     taps = lpf(n_taps, 0.4 / max(rate, 2) if rate < 50 else 0.01)
@@ -64,7 +66,7 @@ def test_long_chain_against_oracle_ragged_calls(c, n_taps, rate, cplx, after):
     node = c.ChainNode(dphase, phase, taps, rate, False, mixer_after_fir=after)
     assert node.fused and node.kernel == "freq"
     unit = rate
-    n = unit * ((3840 * 5 + 777) // unit + 3)
+    n = unit * (((3840 * 5 if n_taps <= 1537 else 12288 * 3) + 777) // unit + 3)
     x = rand_c(rng, n)
     ost, om = oracle.default_state(taps), oracle.Mixer(phase, dphase)
     cuts = [0, unit, unit * 2, unit * (3000 // unit + 1), unit * (9000 // unit + 1), n]
@@ -77,7 +79,7 @@ def test_long_chain_against_oracle_ragged_calls(c, n_taps, rate, cplx, after):
     assert abs(((node.phase - want_phase) + np.pi) % (2 * np.pi) - np.pi) < 1e-6
 
 
-@pytest.mark.parametrize("n_taps,rate", [(300, 5), (600, 8), (1025, 10), (1537, 3), (700, 40)])
+@pytest.mark.parametrize("n_taps,rate", [(300, 5), (600, 8), (1025, 10), (1537, 3), (700, 40), (2049, 5), (4097, 16)])
 def test_long_fm_chain_against_oracle(c, n_taps, rate):
     """mixer -> FIR -> /R -> FM demod: the demodulator is FMDemodNode's kernel over the kept samples, FM.prev carried."""
     rng = np.random.default_rng(n_taps)
@@ -110,10 +112,11 @@ def test_long_fm_chain_against_oracle(c, n_taps, rate):
 
 
 @pytest.mark.parametrize("fmt", ["i16", "u8"])
-@pytest.mark.parametrize("n_taps,rate", [(400, 5), (1000, 8)])
+@pytest.mark.parametrize("n_taps,rate", [(400, 5), (1000, 8), (2000, 6)])
 def test_long_chain_reads_raw_iq(c, fmt, n_taps, rate):
-    """Raw i16 / u8 IQ converted in the kernel's load stage: the same bits as the chain over the converted samples."""
-    idx = np.arange(rate * 2500, dtype=np.float64)
+    """Raw i16 / u8 IQ converted in the kernel's load stage (the 16384-point kernel: in a pass in front of it): the same bits as
+    the chain over the converted samples."""
+    idx = np.arange(rate * 5000, dtype=np.float64)
     z = np.exp(1j * (-2 * np.pi * 0.05 * idx + 8.0 * np.cos(2 * np.pi * idx / 4096)))
     if fmt == "u8":
         raw = np.stack([np.clip(np.rint(z.real * 100 + 127.5), 0, 255), np.clip(np.rint(z.imag * 100 + 127.5), 0, 255)], 1).astype(np.uint8)
@@ -135,14 +138,15 @@ def test_long_chain_reads_raw_iq(c, fmt, n_taps, rate):
     chain_close(got, y, taps, x)
 
 
-def test_long_chain_at_2p24_matches_the_series_of_launches(c):
-    """2^24 samples (every workgroup of the persistent grid walks several segments: the carried output index), 769 taps, rate 5:
+@pytest.mark.parametrize("n_taps", [769, 2500])
+def test_long_chain_at_2p24_matches_the_series_of_launches(c, n_taps):
+    """2^24 samples (every workgroup of the persistent grid walks several segments: the carried output index), 769 / 2500 taps, rate 5:
     the one launch against the chain as a series of launches (FIR, mixer-decimator), which the tests above and
     tests/test_gpu_parity.py hold to the oracle."""
     import torch
 
     n = 5 * ((1 << 24) // 5)
-    taps = lpf(769, 0.08)
+    taps = lpf(n_taps, 0.08)
     xd = torch.empty(n, dtype=torch.complex64, device="cuda:0")
     c.synth_iq_dev(xd.data_ptr(), n, 0, 77)
     s = torch.cuda.current_stream().cuda_stream

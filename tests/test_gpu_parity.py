@@ -1308,7 +1308,8 @@ def test_fused_fm_chain_rates_and_fallbacks(c, rate, kernel):
     assert c.ChainNode(0.3, 0.1, lowpass_taps(300, 0.1), 8, False).kernel == "poly"  # 258 ... 513 taps at rates 4, 8, ...: polyphase
     assert c.ChainNode(0.3, 0.1, lowpass_taps(300, 0.1), 2, False).kernel == "freq"  # ... at the other rates, and up to 1537 taps: the
     assert c.ChainNode(0.3, 0.1, lowpass_taps(600, 0.1), 8, False).kernel == "freq"  # 4096-point overlap-save kernel, decimating
-    assert not c.ChainNode(0.3, 0.1, lowpass_taps(1600, 0.1), 8, False).fused    # a series of launches beyond
+    assert c.ChainNode(0.3, 0.1, lowpass_taps(1600, 0.1), 8, False).kernel == "freq"  # (the 16384-point kernel, decimating: to 4097 taps)
+    assert not c.ChainNode(0.3, 0.1, lowpass_taps(4200, 0.1), 8, False).fused    # a series of launches beyond
     assert not c.ChainNode(0.3, 0.1, lowpass_taps(600, 0.1), 8, False, unfused=True).fused
     with pytest.raises(c.CommsError):
         c.ChainNode(0.3, 0.1, taps, 8, True).run(x[:12])  # n not a multiple of rate
@@ -1421,7 +1422,7 @@ def test_fm_chain_with_the_demodulator_as_its_own_kernel(c, n_taps, rate, after)
 
 @pytest.mark.parametrize("fm", [False, True])
 @pytest.mark.parametrize("after", [False, True])
-@pytest.mark.parametrize("n_taps,rate", [(300, 6), (777, 16), (2500, 5)])
+@pytest.mark.parametrize("n_taps,rate", [(300, 6), (777, 16), (2500, 5), (4300, 7)])
 def test_chain_beyond_257_taps(c, n_taps, rate, after, fm):
     """Long filters: the chain is a series of launches (4096- / 16384-point overlap-save FIR, mixer + decimator,
     demodulator) with the reference nodes' results; state and phase carried across calls.  (258 ... 513 taps at rates 4, 8,
@@ -1430,8 +1431,8 @@ def test_chain_beyond_257_taps(c, n_taps, rate, after, fm):
     x = fm_stream(n) if fm else rand_c(np.random.default_rng(n_taps), n)
     taps = lowpass_taps(n_taps, 1 / (2.5 * rate))
     node = c.ChainNode(0.3, 0.1, taps, rate, fm, mixer_after_fir=after)
-    # (up to 1537 taps the 4096-point kernel mixes and decimates in its store stage: tests/test_gpu_long_chains.py)
-    assert node.fused == (n_taps <= 1537) and node.kernel == ("freq" if n_taps <= 1537 else "unfused")
+    # (up to 4097 taps the 4096- / 16384-point kernels mix and decimate in their store stage: tests/test_gpu_long_chains.py)
+    assert node.fused == (n_taps <= 4097) and node.kernel == ("freq" if n_taps <= 4097 else "unfused")
     ost, om, ofm = oracle.default_state(taps), oracle.Mixer(0.1, 0.3), oracle.FM()
 
     def ref(seg):

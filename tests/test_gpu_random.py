@@ -197,7 +197,7 @@ def test_poly8_chain_random_sweep(c):
 
 
 def test_long_chain_random_sweep(c):
-    """The decimating 4096-point overlap-save kernel (258 ... 1537 taps, mixer and decimator in its store stage) on random draws:
+    """The decimating 4096- / 16384-point overlap-save kernels (258 ... 1537 / 1538 ... 4097 taps, mixer and decimator in the store stage) on random draws:
     rate (2 ... 3000, the polyphase kernel's rates excluded below 514 taps by the chain itself), taps, mixer order, FM demod (a second
     launch), oscillator, user FIR state, batch cuts on multiples of the rate -- against the oracle's nodes in series.
     COMMS_TEST_LONG_CASES: more draws (the default keeps the suite short)."""
@@ -206,14 +206,14 @@ def test_long_chain_random_sweep(c):
     rng = np.random.default_rng(23 + 1000 * SEED_OFFSET)
     for case in range(int(os.environ.get("COMMS_TEST_LONG_CASES", "40"))):
         rate = int(rng.choice([2, 3, 5, 6, 7, 9, 10, 11, 13, 14, 15, 17, 25, 50, 100, 255, 256, 257, 1000, int(rng.integers(2, 3000))]))
-        n_taps = int(rng.integers(514, 1538)) if rng.integers(0, 2) else int(rng.integers(258, 514))
+        n_taps = int(rng.integers(258, 514)) if case % 3 == 0 else int(rng.integers(514, 1538)) if case % 3 == 1 else int(rng.integers(1538, 4098))
         fm = bool(rng.integers(0, 3) == 0)
         taps = lowpass_taps(n_taps, float(rng.uniform(0.01, 0.05)))
         if rng.integers(0, 2):
             taps = (taps * np.exp(1j * rng.uniform(-0.05, 0.05) * np.arange(n_taps))).astype(np.complex64)
         after = bool(rng.integers(0, 2)) and not fm
         dphase, phase = float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3))
-        n = rate * int(rng.integers(1, max(2, 30000 // rate)))
+        n = rate * int(rng.integers(1, max(2, (30000 if n_taps <= 1537 else 60000) // rate)))
         t = np.arange(n)
         x = (np.exp(1j * (0.3 * dphase * t + 2.0 * np.sin(t / 700.0))) * (1 + 0.05 * rng.standard_normal(n))).astype(np.complex64)
         node = c.ChainNode(dphase, phase, taps, rate, fm, mixer_after_fir=after, kernel="freq")

@@ -59,10 +59,13 @@ def _cases(c):
         out.append(("chain " + kern, ch, lambda ch=ch, m=m: ch.run_dev(x.data_ptr(), m, f.data_ptr(), s)))
     cu = c.ChainNode(0.2, 0.0, _lp(127), 8, True, unfused=True)       # the four kernels in series: the FIR stage is timed
     out.append(("chain unfused", cu, lambda: cu.run_dev(x.data_ptr(), n, f.data_ptr(), s)))
-    cl = c.ChainNode(0.2, 0.0, _lp(1600), 16, False)                  # beyond 1537 taps: FIR launch + mixer/decimator pass
+    cl = c.ChainNode(0.2, 0.0, _lp(4200), 16, False)                  # beyond 4097 taps: FIR launches + mixer/decimator pass
     assert not cl.fused
     yl, _, _ = _buffers(n // 16)
-    out.append(("chain 1600 taps", cl, lambda: cl.run_dev(x.data_ptr(), n, yl.data_ptr(), s)))
+    out.append(("chain 4200 taps", cl, lambda: cl.run_dev(x.data_ptr(), n, yl.data_ptr(), s)))
+    c16 = c.ChainNode(0.2, 0.0, _lp(1600), 16, False)                 # 1538 ... 4097 taps: the 16384-point kernel, decimating
+    assert c16.kernel == "freq"
+    out.append(("chain 1600 taps", c16, lambda: c16.run_dev(x.data_ptr(), n, yl.data_ptr(), s)))
     co = c.ChainNode(0.2, 0.0, _lp(600), 16, False)                   # 514 ... 1537 taps: the 4096-point kernel, decimating
     assert co.kernel == "freq"
     out.append(("chain 600 taps", co, lambda: co.run_dev(x.data_ptr(), n, yl.data_ptr(), s)))
