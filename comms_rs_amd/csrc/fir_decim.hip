@@ -1002,7 +1002,11 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
     // Up to 129 taps (two halo rows).  Longer filters stay on the workgroup kernel: with four halo rows a wave's LDS image is
     // 10.4 KB, fifteen waves per CU instead of sixteen, and the 255-tap chain then runs 164 -> 187 us at 2^26 samples and
     // 42.9 -> 48.8 us at 2^24 (scripts/ab_chain.py, CASES=c2,c2c,c2b with COMMS_DECIM_WAVE=2; NOTES.md round 5).
-    if (wave_knob && R == 8 && h->in_fmt == COMMS_IQ_C32 && opl == 2 && tile == DC_TILE && a.hlq * PR <= 128 &&
+    // Rates 2 and 4 too (round 5, second half; COMMS_DECIM_WAVE_R24=0 in the diagnostic build: the workgroup kernel as before) -- 2^24
+    // samples, 15 / 31 / 47 / 63 real taps: rate 2 41.1 / 50.4 / 55.3 / 61.8 -> 35.1 / 47.0 / 51.6 / 59.2 us, rate 4 level up to 47 taps,
+    // 35.1 -> 32.3 at 63 (scripts/time_rate2.py)
+    static const int wave_r24 = diag_knob("COMMS_DECIM_WAVE_R24", 1);
+    if (wave_knob && (R == 8 || (wave_r24 && (R == 2 || R == 4))) && h->in_fmt == COMMS_IQ_C32 && opl == 2 && tile == DC_TILE && a.hlq * PR <= 128 &&
         (reinterpret_cast<uintptr_t>(d_out) & 15) == 0) {  // (its stores are 8 / 16 bytes per lane)
         constexpr int HR = 2;
         const long long tiles = static_cast<long long>((a.n_out + 127) / 128);
@@ -1036,7 +1040,14 @@ comms_status_t comms_fir_run_decim_dev(comms_fir_t* h, const void* d_in, size_t 
 #else
 #define COMMS_DW(REAL_, PRE_, HR_) (nt_loads ? launch_decim_wave_v<8, REAL_, PRE_, HR_, 1, 6>(a, s) : launch_decim_wave_v<8, REAL_, PRE_, HR_, 1, 0>(a, s))
 #endif
-            st = real ? (pre ? COMMS_DW(true, true, 2) : COMMS_DW(true, false, 2)) : (pre ? COMMS_DW(false, true, 2) : COMMS_DW(false, false, 2));
+#define COMMS_DWR(RV, REAL_, PRE_) (nt_loads ? launch_decim_wave_v<RV, REAL_, PRE_, 2, 1, 6>(a, s) : launch_decim_wave_v<RV, REAL_, PRE_, 2, 1, 0>(a, s))
+            if (R == 2)
+                st = real ? (pre ? COMMS_DWR(2, true, true) : COMMS_DWR(2, true, false)) : (pre ? COMMS_DWR(2, false, true) : COMMS_DWR(2, false, false));
+            else if (R == 4)
+                st = real ? (pre ? COMMS_DWR(4, true, true) : COMMS_DWR(4, true, false)) : (pre ? COMMS_DWR(4, false, true) : COMMS_DWR(4, false, false));
+            else
+                st = real ? (pre ? COMMS_DW(true, true, 2) : COMMS_DW(true, false, 2)) : (pre ? COMMS_DW(false, true, 2) : COMMS_DW(false, false, 2));
+#undef COMMS_DWR
 #undef COMMS_DW
             COMMS_TRY(st);
             h->cur ^= 1;

@@ -162,3 +162,50 @@ def test_long_chain_at_2p24_matches_the_series_of_launches(c, n_taps):
     bound = 2 * TOL * float(np.sum(np.abs(taps))) * xd[: 1 << 20].abs().max().item()
     assert (ys[0] - ys[1]).abs().max().item() <= 2 * bound
     assert ys[0].abs().max().item() > 0.01
+
+
+@pytest.mark.parametrize("fm", [False, True])
+@pytest.mark.parametrize("rate,n_taps,cplx", [(2, 31, False), (2, 64, True), (2, 129, False), (4, 63, False), (4, 128, True)])
+def test_wave_private_kernel_at_rates_2_and_4(c, rate, n_taps, cplx, fm):
+    """fir_decim_wave_kernel at rates 2 and 4 (round 5; rate 8 since its first form): a batch whose 8000 tiles of 128 outputs spread
+    evenly over the chip's waves (two per wave, the last run ragged) reaches it in the product build.  Against the overlap-save
+    fusion (another algorithm) on every output, two calls with the state carried; the first 2^15 outputs against the oracle."""
+    import torch
+
+    n_out = 128 * 8000 - 37
+    n = rate * n_out
+    taps = lpf(n_taps, 0.4 / rate)
+    if cplx:
+        taps = (taps * np.exp(1j * 0.01 * np.arange(n_taps))).astype(np.complex64)
+    xd = torch.empty(n, dtype=torch.complex64, device="cuda:0")
+    c.synth_iq_dev(xd.data_ptr(), n, 0, 1234 + rate)
+    s = torch.cuda.current_stream().cuda_stream
+    dphase, phase = 2 * np.pi * 0.013, 0.2
+    ys = []
+    for kern in ("time", "freq"):
+        node = c.ChainNode(dphase, phase, taps, rate, fm, mixer_after_fir=not fm, kernel=kern)
+        assert node.kernel == kern
+        outs = []
+        for _ in range(2):  # (the second call continues the stream)
+            y = torch.empty(n_out, dtype=torch.float32 if fm else torch.complex64, device="cuda:0")
+            node.run_dev(xd.data_ptr(), n, y.data_ptr(), s)
+            outs.append(y)
+        torch.cuda.synchronize()
+        ys.append(outs)
+    scale = float(np.sum(np.abs(taps))) * xd[: 1 << 20].abs().max().item()
+    x_head = xd[: rate * (1 << 15)].cpu().numpy()
+    om = oracle.Mixer(phase, dphase)
+    if fm:
+        yo = oracle.decimate(oracle.batch_fir(om.mix(x_head), taps, oracle.default_state(taps), norotate=True), rate)
+        w = oracle.FM().demod(yo)
+        mag = np.minimum(np.abs(yo), np.abs(np.concatenate([[0.0], yo[:-1]])))
+        got = ys[0][0][: 1 << 15].cpu().numpy()
+        assert np.max(circ(got.astype(np.float64) - w) * mag) <= 4 * TOL * scale
+        for a, b in zip(*ys):  # the two kernels on every output, on the circle; the angle is ill-conditioned where the signal is ~0
+            d = torch.remainder(a.double() - b.double() + np.pi, 2 * np.pi) - np.pi
+            assert torch.quantile(d.abs()[:: 64], 0.999).item() <= 1e-3
+    else:
+        yo = oracle.decimate(om.mix(oracle.batch_fir(x_head, taps, oracle.default_state(taps), norotate=True)), rate)
+        chain_close(ys[0][0][: 1 << 15].cpu().numpy(), yo, taps, x_head)
+        for a, b in zip(*ys):
+            assert (a - b).abs().max().item() <= 4 * TOL * scale
