@@ -885,9 +885,10 @@ int32_t comms_fir_decim_supported_for(const comms_fir_t* h, uint32_t rate, int32
     const int macs = decim_macs(h, rate);
     if (macs < 0) return 0;
     static const int max_macs = diag_knob("COMMS_DECIM_MAX_MACS", 0);
-    // (rate 2 reads every sample for every other output: 63 taps at 2^24 samples 74 us here against 62 on the overlap-save fusion,
-    // 31 taps 53 against 60 -- profiles/r05_map_chains.txt)
-    const int limit = max_macs > 0 ? max_macs : !can_fuse ? 96 : rate == 2 ? (fm_demod ? 32 : 24) : fm_demod ? 48 : 44;
+    // (rate 2 computes every other output: its filter loop costs 12 us per 16 taps at 2^24 samples, and the overlap-save fusion
+    // (57 us, 74 with the demodulator behind it) is level with it at 63 / 79 real taps -- scripts/ab_rate2_tf.py, the two taking turns:
+    // 63 taps 56.1 against 57.9, 79 taps 63.4 against 57.5; FM chains 79 taps 71.7 against 74.4, 95 taps 80.7 against 74.0)
+    const int limit = max_macs > 0 ? max_macs : !can_fuse ? 96 : rate == 2 ? (fm_demod ? 40 : 32) : fm_demod ? 48 : 44;
     return macs <= limit ? 2 : 1;
 }
 int32_t comms_fir_decim_supported(const comms_fir_t* h, uint32_t rate) {
