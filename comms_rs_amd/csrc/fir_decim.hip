@@ -502,7 +502,12 @@ struct DwGeom {
     static constexpr int PR = 2 * R;
     static constexpr int RPE = 64 / PR;        // phase-array elements per row of 64 samples
     static constexpr int SCAP = HR * RPE;      // halo elements in front of the 64 new ones of a phase array
-    static constexpr int S = (64 + SCAP) | 1;  // phase-array stride (odd: the staging writes spread over the banks)
+    // phase-array stride.  A staging row is one ds_write_b64 per lane, served in groups of sixteen lanes over sixteen 8-byte bank
+    // pairs; the group's lanes hold PR phases x 16 / PR consecutive elements, so the stride must be 16 / PR modulo 16 (rate 8, sixteen
+    // phases: any odd stride; rate 4: 2 mod 16; rate 2: 4 mod 16 -- with an odd stride the rate-2 form spent 43 % of its LDS cycles
+    // in bank conflicts, profiles/r05_pmc_rate2_wave.txt)
+    static constexpr int SQ = 16 / PR > 0 ? 16 / PR : 1;
+    static constexpr int S = PR >= 16 ? ((64 + SCAP) | 1) : (64 + SCAP + 15 - ((64 + SCAP + 15 - SQ) % 16));
     static constexpr int WAVE_CF = PR * S;
     static constexpr size_t LDS_WAVE = static_cast<size_t>(WAVE_CF) * sizeof(float2);
     static_assert(64 % PR == 0, "a row of 64 samples must be whole phase-array columns");
