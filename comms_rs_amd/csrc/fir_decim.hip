@@ -69,7 +69,11 @@ struct DcGeom {
     static constexpr int WG = TILE / OPL;                          // lanes per workgroup
     static constexpr int HLQ_MAX = (DC_NMAX - 1 + PR - 1) / PR;    // halo in phase-array elements
     static constexpr int HROWS = (HLQ_MAX * PR + WG - 1) / WG;     // halo rows of WG samples
-    static constexpr int S = (WG + HLQ_MAX + 1) | 1;               // phase-array stride (odd: staging writes spread over the banks)
+    // phase-array stride: odd, so that a staging row (one ds_write_b64 per lane, sixteen lanes at a time over sixteen 8-byte bank
+    // pairs) spreads over the banks -- exact for sixteen phases and the best there is for the other rates (brute force: 0.3-1 extra
+    // cycle per group whatever the stride) except four and eight phases (rates 2 and 4), which need 16 / PR modulo 16 (see DwGeom)
+    static constexpr int SB = WG + HLQ_MAX + 1;
+    static constexpr int S = (PR == 4 || PR == 8) ? (SB + 15 - ((SB + 15 - 16 / PR) % 16)) : (SB | 1);
     static constexpr size_t LDS = static_cast<size_t>(PR) * S * sizeof(float2);
     static constexpr int WGPC = (R <= 8 ? 4 : R <= 12 ? 3 : 2) * DC_TILE / TILE;  // workgroups per CU that fit in LDS
     static constexpr int WAVES_PER_SIMD = (WGPC * WG / 64 + 3) / 4;  // __launch_bounds__' second argument: sets the VGPR budget
