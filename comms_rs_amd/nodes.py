@@ -574,9 +574,9 @@ class ChainNode(_Handle):
 
     def __init__(self, dphase, phase, taps, rate, fm_demod, device=0, mixer_after_fir=False, unfused=False,
                  kernel="auto"):
-        """kernel: "auto", "freq" (always the overlap-save kernel), "time" (the decimating
-        time-domain kernel wherever it applies) or "poly" (the polyphase frequency-domain kernel: rate 8, <= 513 taps, 505 with
-        FM demod)."""
+        """kernel: "auto", "freq" (always an overlap-save kernel: the 1024-point one up to 257 taps, the 4096- / 16384-point
+        ones with mixer and decimator in their store stage up to 1537 / 4097), "time" (the decimating time-domain kernels wherever
+        they apply) or "poly" (the polyphase frequency-domain kernel: rates 4, 8, 12 ... 64, <= 513 taps, 505 with FM demod)."""
         super().__init__()
         taps = _as_c64(taps)
         self.rate, self.fm_demod = int(rate), bool(fm_demod)
@@ -593,8 +593,9 @@ class ChainNode(_Handle):
 
     @property
     def kernel(self):
-        """"unfused", "freq" (fir_os1024_kernel), "time" (fir_decim_kernel), "time_any" (fir_decim_any_kernel) or "poly"
-        (fir_poly8_kernel: forced, or what the chain's last call ran on)."""
+        """"unfused", "freq" (fir_os1024_kernel; fir_os4096_kernel / fir_os16k_kernel in their decimating form for 258 ... 4097
+        taps), "time" (fir_decim_kernel / fir_decim_wave_kernel), "time_any" (fir_decim_any_kernel) or "poly" (fir_poly8_kernel:
+        forced, picked at creation for 258 ... 513 taps, or what the chain's last call ran on)."""
         f = C.c_int32()
         check(lib().comms_chain_is_fused(self._h, C.byref(f)))
         return ("unfused", "freq", "time", "time_any", "poly")[f.value]
